@@ -1,0 +1,823 @@
+// libgance_hip.so: the StyleGAN2 config-f engine behind include/gance_hip.h.
+//
+// Owns one network's weights (re-laid-out for the kernels) and a workspace sized for max_batch
+// frames in HBM, and turns a batch of dlatents (or z vectors) into uint8 NHWC frames with a fixed
+// sequence of kernel launches on the caller's stream. Replaces the TF1 session behind
+// gance/network_interface/network_functions.py:114-192 (wrap_loaded_network) for the reference's
+// two call forms (`network.run`, `network.components.synthesis.run`).
+//
+// There is NO CPU fallback: without a HIP device every entry point fails with an error code.
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/gance_hip.h"
+#include "kernels.h"
+
+namespace {
+
+thread_local std::string g_last_error;
+
+int fail(int code, const std::string& message) {
+    g_last_error = message;
+    return code;
+}
+
+#define GANCE_HIP_CHECK(expr)                                                              \
+    do {                                                                                   \
+        hipError_t gance_err_ = (expr);                                                    \
+        if (gance_err_ != hipSuccess) {                                                    \
+            return fail(gance_err_ == hipErrorOutOfMemory ? GANCE_ERR_OUT_OF_MEMORY        \
+                                                          : GANCE_ERR_HIP,                 \
+                        std::string(#expr) + ": " + hipGetErrorString(gance_err_));        \
+        }                                                                                  \
+    } while (0)
+
+constexpr int kDlatent = 512;
+constexpr int kMappingLayers = 8;
+constexpr float kMappingLrmul = 0.01f;
+
+int nf(int stage) {
+    const int v = (16 << 10) >> stage;
+    return std::min(std::max(v, 1), 512);
+}
+
+struct ConvLayerHost {
+    int layer_idx, res_log2, cin, cout;
+    bool up;
+};
+struct RgbLayerHost {
+    int res_log2, cin, row;
+};
+
+void build_spec(int res_log2, std::vector<ConvLayerHost>* convs, std::vector<RgbLayerHost>* rgbs) {
+    convs->push_back({0, 2, nf(1), nf(1), false});
+    rgbs->push_back({2, nf(1), 1});
+    for (int res = 3; res <= res_log2; ++res) {
+        convs->push_back({res * 2 - 5, res, nf(res - 2), nf(res - 1), true});
+        convs->push_back({res * 2 - 4, res, nf(res - 1), nf(res - 1), false});
+        rgbs->push_back({res, nf(res - 1), res * 2 - 3});
+    }
+}
+
+uint64_t blob_floats(int res_log2) {
+    std::vector<ConvLayerHost> convs;
+    std::vector<RgbLayerHost> rgbs;
+    build_spec(res_log2, &convs, &rgbs);
+    uint64_t n = 0;
+    n += (uint64_t)kMappingLayers * (kDlatent * kDlatent + kDlatent);
+    n += kDlatent;
+    n += (uint64_t)nf(1) * 16;
+    for (const auto& c : convs)
+        n += (uint64_t)9 * c.cin * c.cout + (uint64_t)kDlatent * c.cin + c.cin + 1 + c.cout;
+    for (const auto& r : rgbs) n += (uint64_t)r.cin * 3 + (uint64_t)kDlatent * r.cin + r.cin + 3;
+    for (const auto& c : convs) n += (uint64_t)1 << (2 * c.res_log2);
+    return n;
+}
+
+int ilog2_exact(int v) {
+    int l = 0;
+    while ((1 << l) < v) ++l;
+    return (1 << l) == v ? l : -1;
+}
+
+// One launch of the conv kernel: a stride-1 conv or one parity class of a transposed conv.
+struct ClassPlan {
+    int tile_id;
+    int OH, OW;
+    int tiles_x, tiles_y, tiles_b, m_tiles, nsplit, chunks_per_split, total_blocks;
+    int ntaps;
+    int dy[gance::kMaxTaps], dx[gance::kMaxTaps], tw[gance::kMaxTaps];
+    size_t plane_floats;  // B * Cout * OH * OW
+};
+
+int ceil_div(int a, int b) { return (a + b - 1) / b; }
+
+int choose_tile(int cout, int OH, int OW, int B) {
+    if (cout == 32) return 0;
+    if (cout == 64) return 1;
+    int best = 2;
+    long best_tiles = -1;
+    for (int id = 2; id < gance::kNumConvTiles; ++id) {
+        const auto& t = gance::kConvTiles[id];
+        const long tiles = (long)ceil_div(B, t.TB) * ceil_div(OH, t.TH) * ceil_div(OW, t.TW);
+        if (best_tiles < 0 || tiles < best_tiles) {
+            best_tiles = tiles;
+            best = id;
+        }
+    }
+    return best;
+}
+
+int choose_nsplit(int base_blocks, int chunks) {
+    if (base_blocks >= 384) return 1;
+    const int want = ceil_div(768, base_blocks);
+    for (int d = 1; d <= chunks; ++d)
+        if (chunks % d == 0 && d >= want) return d;
+    return chunks;
+}
+
+ClassPlan plan_class(int cin, int cout, int OH, int OW, int B, int force_nsplit) {
+    ClassPlan p{};
+    p.tile_id = choose_tile(cout, OH, OW, B);
+    const auto& t = gance::kConvTiles[p.tile_id];
+    p.OH = OH;
+    p.OW = OW;
+    p.tiles_x = ceil_div(OW, t.TW);
+    p.tiles_y = ceil_div(OH, t.TH);
+    p.tiles_b = ceil_div(B, t.TB);
+    p.m_tiles = cout / t.BM;
+    const int chunks = cin / t.KC;
+    const int base = p.m_tiles * p.tiles_x * p.tiles_y * p.tiles_b;
+    p.nsplit = force_nsplit > 0 ? force_nsplit : choose_nsplit(base, chunks);
+    p.chunks_per_split = chunks / p.nsplit;
+    p.total_blocks = base * p.nsplit;
+    p.plane_floats = (size_t)B * cout * OH * OW;
+    return p;
+}
+
+struct LayerPlan {
+    int num_classes;  // 1 (stride-1 conv) or 4 (transposed conv parity classes)
+    ClassPlan cls[4];
+    int nsplit;
+    size_t t_floats;  // scratch floats needed (all slabs, all classes); 0 if written directly
+};
+
+LayerPlan plan_layer(const ConvLayerHost& c, int B) {
+    LayerPlan lp{};
+    const int res = 1 << c.res_log2;
+    if (!c.up) {
+        lp.num_classes = 1;
+        lp.cls[0] = plan_class(c.cin, c.cout, res, res, B, 0);
+        ClassPlan& p = lp.cls[0];
+        p.ntaps = 9;
+        for (int t = 0; t < 9; ++t) {
+            p.dy[t] = t / 3 - 1;
+            p.dx[t] = t % 3 - 1;
+            p.tw[t] = t;
+        }
+        lp.nsplit = p.nsplit;
+        lp.t_floats = p.nsplit > 1 ? p.plane_floats * p.nsplit : 0;
+        return lp;
+    }
+    const int H = res / 2, W = res / 2;
+    lp.num_classes = 4;
+    // row taps of a parity: even -> (dy 0, w row 2), (dy -1, w row 0); odd -> (dy 0, w row 1)
+    const int even_d[2] = {0, -1}, even_w[2] = {2, 0};
+    const int odd_d[1] = {0}, odd_w[1] = {1};
+    int nsplit = 0;
+    for (int cls = 0; cls < 4; ++cls) {
+        const int py = cls >> 1, px = cls & 1;
+        const int OH = py ? H : H + 1, OW = px ? W : W + 1;
+        lp.cls[cls] = plan_class(c.cin, c.cout, OH, OW, B, nsplit);
+        ClassPlan& p = lp.cls[cls];
+        if (cls == 0) nsplit = p.nsplit;
+        const int ny = py ? 1 : 2, nx = px ? 1 : 2;
+        const int* yd = py ? odd_d : even_d;
+        const int* yw = py ? odd_w : even_w;
+        const int* xd = px ? odd_d : even_d;
+        const int* xw = px ? odd_w : even_w;
+        p.ntaps = 0;
+        for (int a = 0; a < ny; ++a)
+            for (int b = 0; b < nx; ++b) {
+                p.dy[p.ntaps] = yd[a];
+                p.dx[p.ntaps] = xd[b];
+                p.tw[p.ntaps] = yw[a] * 3 + xw[b];
+                ++p.ntaps;
+            }
+        lp.t_floats += p.plane_floats * p.nsplit;
+    }
+    lp.nsplit = nsplit;
+    return lp;
+}
+
+struct StepRecord {
+    char name[64];
+    double flops, bytes;
+    hipEvent_t start, stop;
+};
+
+}  // namespace
+
+struct gance_engine {
+    gance_engine_config cfg{};
+    int res_log2 = 0;
+    int num_rows = 0;  // W
+    std::vector<ConvLayerHost> convs;
+    std::vector<RgbLayerHost> rgbs;
+
+    // device weight pool
+    float* pool = nullptr;
+    size_t pool_floats = 0;
+    // offsets into pool
+    size_t map_w[kMappingLayers]{}, map_b[kMappingLayers]{};
+    size_t avg_off = 0, const_off = 0, A_off = 0, bias1_off = 0, w2_off = 0;
+    std::vector<size_t> conv_w, conv_bias, conv_noise;
+    std::vector<float> conv_ns;
+    std::vector<int> conv_s_off, conv_d_off;
+    std::vector<size_t> rgb_w, rgb_bias;
+    std::vector<int> rgb_s_off;
+    int ctot = 0, dtot = 0;
+    int* blk_row = nullptr;
+    gance::DemodLayer* demod_layers = nullptr;
+
+    // workspace
+    float *dlat = nullptr, *map_a = nullptr, *map_b_buf = nullptr, *z_in = nullptr;
+    float *styles = nullptr, *demod = nullptr;
+    float *xbuf[2] = {nullptr, nullptr};
+    float* tbuf = nullptr;
+    float* ybuf[2] = {nullptr, nullptr};
+    uint8_t* u8buf = nullptr;  // staging for the host-buffer entry points
+    size_t x_floats = 0, t_floats = 0, y_floats = 0;
+
+    // profiling / debug
+    std::vector<StepRecord> steps;
+    int steps_used = 0;
+    int debug_stop_after = 0;
+    int last_act_buf = 0, last_act_c = 0, last_act_side = 0;
+    hipStream_t last_stream = nullptr;
+};
+
+namespace {
+
+void free_engine(gance_engine* e) {
+    if (!e) return;
+    for (auto& s : e->steps) {
+        hipEventDestroy(s.start);
+        hipEventDestroy(s.stop);
+    }
+    hipFree(e->pool);
+    hipFree(e->blk_row);
+    hipFree(e->demod_layers);
+    hipFree(e->dlat);
+    hipFree(e->map_a);
+    hipFree(e->map_b_buf);
+    hipFree(e->z_in);
+    hipFree(e->styles);
+    hipFree(e->demod);
+    hipFree(e->xbuf[0]);
+    hipFree(e->xbuf[1]);
+    hipFree(e->tbuf);
+    hipFree(e->ybuf[0]);
+    hipFree(e->ybuf[1]);
+    hipFree(e->u8buf);
+    delete e;
+}
+
+// Profiling bracket around one launch.
+struct StepScope {
+    gance_engine* e;
+    hipStream_t stream;
+    StepRecord* rec = nullptr;
+    StepScope(gance_engine* engine, hipStream_t s, const char* name, double flops, double bytes)
+        : e(engine), stream(s) {
+        if (!(e->cfg.flags & GANCE_FLAG_PROFILE_STEPS)) return;
+        if (e->steps_used == (int)e->steps.size()) {
+            StepRecord r{};
+            hipEventCreate(&r.start);
+            hipEventCreate(&r.stop);
+            e->steps.push_back(r);
+        }
+        rec = &e->steps[e->steps_used++];
+        std::snprintf(rec->name, sizeof(rec->name), "%s", name);
+        rec->flops = flops;
+        rec->bytes = bytes;
+        hipEventRecord(rec->start, stream);
+    }
+    ~StepScope() {
+        if (rec) hipEventRecord(rec->stop, stream);
+    }
+};
+
+int run_conv_class(gance_engine* e, const ConvLayerHost& c, int conv_index, const ClassPlan& p,
+                   const float* x, long long x_b_stride, int H, int W, float* out,
+                   long long out_b_stride, long long out_c_stride, int out_row_stride,
+                   long long slab_stride, int epilogue, int B, hipStream_t stream,
+                   const char* name) {
+    gance::ConvArgs a{};
+    a.x = x;
+    a.w = e->pool + e->conv_w[conv_index];
+    a.s = e->styles + e->conv_s_off[conv_index];
+    a.d = e->demod + e->conv_d_off[conv_index];
+    const bool has_noise = e->conv_ns[conv_index] != 0.0f;
+    a.noise = has_noise ? e->pool + e->conv_noise[conv_index] : nullptr;
+    a.bias = e->pool + e->conv_bias[conv_index];
+    a.out = out;
+    a.B = B;
+    a.Cin = c.cin;
+    a.Cout = c.cout;
+    a.H = H;
+    a.W = W;
+    a.OH = p.OH;
+    a.OW = p.OW;
+    a.s_stride = e->ctot;
+    a.d_stride = e->dtot;
+    a.noise_strength = e->conv_ns[conv_index];
+    a.tiles_x = p.tiles_x;
+    a.tiles_y = p.tiles_y;
+    a.m_tiles = p.m_tiles;
+    a.nsplit = p.nsplit;
+    a.chunks_per_split = p.chunks_per_split;
+    a.epilogue = epilogue;
+    a.ntaps = p.ntaps;
+    for (int t = 0; t < p.ntaps; ++t) {
+        a.tap_dy[t] = p.dy[t];
+        a.tap_dx[t] = p.dx[t];
+        a.tap_w[t] = p.tw[t];
+    }
+    a.out_b_stride = out_b_stride;
+    a.out_c_stride = out_c_stride;
+    a.slab_stride = slab_stride;
+    a.x_b_stride = x_b_stride;
+    a.out_row_stride = out_row_stride;
+    const double flops = 2.0 * p.ntaps * (double)c.cin * c.cout * H * W * B;
+    const double bytes = 4.0 * ((double)B * c.cin * H * W + (double)p.plane_floats * p.nsplit +
+                                9.0 * c.cin * c.cout);
+    StepScope scope(e, stream, name, flops, bytes);
+    GANCE_HIP_CHECK(gance::launch_modconv(p.tile_id, a, p.total_blocks, stream));
+    return GANCE_OK;
+}
+
+int synthesize_from_dlat(gance_engine* e, const float* d_dlat, int B, uint8_t* d_u8, float* d_f32,
+                         hipStream_t stream) {
+    char name[64];
+    {
+        StepScope scope(e, stream, "styles", 2.0 * B * kDlatent * e->ctot,
+                        4.0 * ((double)kDlatent * e->ctot + (double)B * e->ctot));
+        GANCE_HIP_CHECK(gance::launch_styles(d_dlat, e->pool + e->A_off, e->pool + e->bias1_off,
+                                             e->blk_row, e->styles, B, e->num_rows, e->ctot,
+                                             stream));
+    }
+    {
+        StepScope scope(e, stream, "demod", 0.0, 0.0);
+        GANCE_HIP_CHECK(gance::launch_demod(e->styles, e->pool + e->w2_off, e->demod_layers,
+                                            (int)e->convs.size(), e->demod, B, e->ctot, e->dtot,
+                                            stream));
+    }
+
+    int cur = 0;   // xbuf index holding the current activation
+    int ycur = 0;  // ybuf index holding the current skip image
+    bool have_y = false;
+    const int num_convs = (int)e->convs.size();
+    const int limit = e->debug_stop_after > 0 ? std::min(e->debug_stop_after, num_convs) : num_convs;
+    const float* x_in = e->pool + e->const_off;
+    long long x_b_stride = 0;  // the const input is shared by the batch
+
+    for (int li = 0; li < limit; ++li) {
+        const ConvLayerHost& c = e->convs[li];
+        const int res = 1 << c.res_log2;
+        const LayerPlan lp = plan_layer(c, B);
+        float* x_out = e->xbuf[(li == 0) ? 0 : 1 - cur];
+        const bool has_noise = e->conv_ns[li] != 0.0f;
+        const float* noise = has_noise ? e->pool + e->conv_noise[li] : nullptr;
+        const float* bias = e->pool + e->conv_bias[li];
+        if (!c.up) {
+            const ClassPlan& p = lp.cls[0];
+            std::snprintf(name, sizeof(name), "conv%d_%dx%d_%d->%d", c.layer_idx, res, res, c.cin,
+                          c.cout);
+            if (p.nsplit == 1) {
+                int rc = run_conv_class(e, c, li, p, x_in, x_b_stride, res, res, x_out,
+                                        (long long)c.cout * res * res, (long long)res * res, res,
+                                        0, gance::kEpilogueFull, B, stream, name);
+                if (rc) return rc;
+            } else {
+                int rc = run_conv_class(e, c, li, p, x_in, x_b_stride, res, res, e->tbuf,
+                                        (long long)c.cout * res * res, (long long)res * res, res,
+                                        (long long)p.plane_floats, gance::kEpilogueRaw, B, stream,
+                                        name);
+                if (rc) return rc;
+                std::snprintf(name, sizeof(name), "finish%d_%dx%d", c.layer_idx, res, res);
+                StepScope scope(e, stream, name, 0.0,
+                                4.0 * (double)p.plane_floats * (p.nsplit + 1));
+                GANCE_HIP_CHECK(gance::launch_splitk_finish(
+                    e->tbuf, (long long)p.plane_floats, p.nsplit, noise, e->conv_ns[li], bias,
+                    x_out, B, c.cout, res, res, stream));
+            }
+        } else {
+            const int H = res / 2, W = res / 2;
+            gance::FirArgs f{};
+            size_t off = 0;
+            const float* planes[4];
+            long long slabs[4];
+            for (int cls = 0; cls < 4; ++cls) {
+                const ClassPlan& p = lp.cls[cls];
+                float* plane = e->tbuf + off;
+                planes[cls] = plane;
+                slabs[cls] = (long long)p.plane_floats;
+                off += p.plane_floats * p.nsplit;
+                std::snprintf(name, sizeof(name), "convT%d_%dx%d_%d->%d_c%d", c.layer_idx, res, res,
+                              c.cin, c.cout, cls);
+                int rc = run_conv_class(e, c, li, p, x_in, x_b_stride, H, W, plane,
+                                        (long long)c.cout * p.OH * p.OW, (long long)p.OH * p.OW,
+                                        p.OW, (long long)p.plane_floats, gance::kEpilogueRaw, B,
+                                        stream, name);
+                if (rc) return rc;
+            }
+            f.t_ee = planes[0];
+            f.t_eo = planes[1];
+            f.t_oe = planes[2];
+            f.t_oo = planes[3];
+            f.slab_ee = slabs[0];
+            f.slab_eo = slabs[1];
+            f.slab_oe = slabs[2];
+            f.slab_oo = slabs[3];
+            f.noise = noise;
+            f.bias = bias;
+            f.out = x_out;
+            f.noise_strength = e->conv_ns[li];
+            f.B = B;
+            f.C = c.cout;
+            f.H = H;
+            f.W = W;
+            f.nsplit = lp.nsplit;
+            std::snprintf(name, sizeof(name), "fir%d_%dx%d", c.layer_idx, res, res);
+            StepScope scope(e, stream, name, 0.0,
+                            4.0 * ((double)off + (double)B * c.cout * res * res));
+            GANCE_HIP_CHECK(gance::launch_fir_epilogue(f, stream));
+        }
+        if (li > 0) cur = 1 - cur;
+        x_in = e->xbuf[cur];
+        x_b_stride = (long long)c.cout * res * res;
+        e->last_act_buf = cur;
+        e->last_act_c = c.cout;
+        e->last_act_side = res;
+
+        // ToRGB after the 4x4 conv and after every Conv1
+        if (!c.up) {
+            int ri = c.res_log2 - 2;
+            const RgbLayerHost& r = e->rgbs[ri];
+            gance::ToRgbArgs t{};
+            t.x = x_in;
+            t.w = e->pool + e->rgb_w[ri];
+            t.s = e->styles + e->rgb_s_off[ri];
+            t.bias = e->pool + e->rgb_bias[ri];
+            t.y_prev = have_y ? e->ybuf[ycur] : nullptr;
+            t.y = e->ybuf[have_y ? 1 - ycur : ycur];
+            const bool last = (c.res_log2 == e->res_log2);
+            t.u8 = last ? d_u8 : nullptr;
+            t.B = B;
+            t.Cin = r.cin;
+            t.R = res;
+            t.s_stride = e->ctot;
+            std::snprintf(name, sizeof(name), "torgb_%dx%d", res, res);
+            StepScope scope(e, stream, name, 2.0 * 3 * (double)r.cin * res * res * B,
+                            4.0 * (double)B * res * res * (r.cin + 3 + 0.75) + 3.0 * B * res * res);
+            GANCE_HIP_CHECK(gance::launch_torgb(t, stream));
+            if (have_y) ycur = 1 - ycur;
+            have_y = true;
+        }
+    }
+    if (d_f32 != nullptr && limit == num_convs) {
+        const size_t bytes = (size_t)B * 3 * e->cfg.resolution * e->cfg.resolution * sizeof(float);
+        GANCE_HIP_CHECK(hipMemcpyAsync(d_f32, e->ybuf[ycur], bytes, hipMemcpyDeviceToDevice, stream));
+    }
+    e->last_stream = stream;
+    return GANCE_OK;
+}
+
+int check_call(gance_engine* e, const void* in, int batch) {
+    if (e == nullptr) return fail(GANCE_ERR_INVALID_ARGUMENT, "engine is NULL");
+    if (in == nullptr) return fail(GANCE_ERR_INVALID_ARGUMENT, "input pointer is NULL");
+    if (batch < 1 || batch > e->cfg.max_batch)
+        return fail(GANCE_ERR_INVALID_ARGUMENT,
+                    "batch " + std::to_string(batch) + " outside [1, max_batch=" +
+                        std::to_string(e->cfg.max_batch) + "]");
+    return GANCE_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* gance_last_error(void) { return g_last_error.c_str(); }
+int gance_abi_version(void) { return GANCE_ABI_VERSION; }
+
+uint64_t gance_weight_blob_floats(int32_t resolution) {
+    const int l = ilog2_exact(resolution);
+    if (l < 3 || l > 10) return 0;
+    return blob_floats(l);
+}
+
+int gance_engine_create(const gance_engine_config* config, const float* host_weights,
+                        uint64_t num_floats, gance_engine** out_engine) {
+    if (config == nullptr || host_weights == nullptr || out_engine == nullptr)
+        return fail(GANCE_ERR_INVALID_ARGUMENT, "NULL argument to gance_engine_create");
+    *out_engine = nullptr;
+    const int res_log2 = ilog2_exact(config->resolution);
+    if (res_log2 < 3 || res_log2 > 10)
+        return fail(GANCE_ERR_INVALID_ARGUMENT, "resolution must be a power of two in [8, 1024]");
+    if (config->max_batch < 1 || config->max_batch > 64)
+        return fail(GANCE_ERR_INVALID_ARGUMENT, "max_batch must be in [1, 64]");
+    if (num_floats != blob_floats(res_log2))
+        return fail(GANCE_ERR_BAD_WEIGHTS,
+                    "weight blob has " + std::to_string(num_floats) + " floats, expected " +
+                        std::to_string(blob_floats(res_log2)));
+    int device_count = 0;
+    if (hipGetDeviceCount(&device_count) != hipSuccess || device_count < 1)
+        return fail(GANCE_ERR_NO_DEVICE, "no HIP device visible; libgance_hip has no CPU path");
+    if (config->device < 0 || config->device >= device_count)
+        return fail(GANCE_ERR_INVALID_ARGUMENT, "device ordinal out of range");
+    GANCE_HIP_CHECK(hipSetDevice(config->device));
+
+    gance_engine* e = new gance_engine();
+    e->cfg = *config;
+    e->res_log2 = res_log2;
+    e->num_rows = res_log2 * 2 - 2;
+    build_spec(res_log2, &e->convs, &e->rgbs);
+    const int nconv = (int)e->convs.size();
+    const int nrgb = (int)e->rgbs.size();
+
+    // ---- style / demod column layout ----
+    e->conv_s_off.resize(nconv);
+    e->conv_d_off.resize(nconv);
+    e->rgb_s_off.resize(nrgb);
+    int ctot = 0, dtot = 0;
+    for (int i = 0; i < nconv; ++i) {
+        e->conv_s_off[i] = ctot;
+        ctot += e->convs[i].cin;
+        e->conv_d_off[i] = dtot;
+        dtot += e->convs[i].cout;
+    }
+    for (int i = 0; i < nrgb; ++i) {
+        e->rgb_s_off[i] = ctot;
+        ctot += e->rgbs[i].cin;
+    }
+    e->ctot = ctot;
+    e->dtot = dtot;
+
+    // ---- build the processed weight pool on the host ----
+    std::vector<float> pool;
+    auto reserve = [&](size_t n) {
+        const size_t off = pool.size();
+        pool.resize(off + ((n + 3) & ~(size_t)3), 0.f);  // keep every array 16-B aligned
+        return off;
+    };
+    const float* src = host_weights;
+    // mapping
+    const float map_coef = (float)(1.0 / std::sqrt((double)kDlatent) * kMappingLrmul);
+    for (int i = 0; i < kMappingLayers; ++i) {
+        e->map_w[i] = reserve((size_t)kDlatent * kDlatent);
+        for (size_t k = 0; k < (size_t)kDlatent * kDlatent; ++k) pool[e->map_w[i] + k] = src[k] * map_coef;
+        src += (size_t)kDlatent * kDlatent;
+        e->map_b[i] = reserve(kDlatent);
+        for (int k = 0; k < kDlatent; ++k) pool[e->map_b[i] + k] = src[k] * kMappingLrmul;
+        src += kDlatent;
+    }
+    e->avg_off = reserve(kDlatent);
+    std::memcpy(&pool[e->avg_off], src, kDlatent * sizeof(float));
+    src += kDlatent;
+    e->const_off = reserve((size_t)nf(1) * 16);
+    std::memcpy(&pool[e->const_off], src, (size_t)nf(1) * 16 * sizeof(float));
+    src += (size_t)nf(1) * 16;
+
+    e->A_off = reserve((size_t)kDlatent * ctot);
+    e->bias1_off = reserve(ctot);
+    size_t w2_total = 0;
+    for (const auto& c : e->convs) w2_total += (size_t)c.cin * c.cout;
+    e->w2_off = reserve(w2_total);
+    const float mod_coef = (float)(1.0 / std::sqrt((double)kDlatent));
+    std::vector<gance::DemodLayer> demod_layers(nconv);
+    e->conv_w.resize(nconv);
+    e->conv_bias.resize(nconv);
+    e->conv_noise.resize(nconv);
+    e->conv_ns.resize(nconv);
+    size_t w2_cursor = 0;
+    for (int i = 0; i < nconv; ++i) {
+        const ConvLayerHost& c = e->convs[i];
+        const size_t wn = (size_t)9 * c.cin * c.cout;
+        const float coef = (float)(1.0 / std::sqrt(9.0 * c.cin));
+        e->conv_w[i] = reserve(wn);
+        float* w = &pool[e->conv_w[i]];
+        for (size_t k = 0; k < wn; ++k) w[k] = src[k] * coef;
+        src += wn;
+        float* w2 = &pool[e->w2_off + w2_cursor];
+        for (int tap = 0; tap < 9; ++tap)
+            for (size_t k = 0; k < (size_t)c.cin * c.cout; ++k) {
+                const float v = w[(size_t)tap * c.cin * c.cout + k];
+                w2[k] += v * v;
+            }
+        demod_layers[i] = {(long long)w2_cursor, e->conv_s_off[i], e->conv_d_off[i], c.cin, c.cout};
+        w2_cursor += (size_t)c.cin * c.cout;
+        // mod_weight [512][cin] -> A[k][s_off + ci]
+        for (int k = 0; k < kDlatent; ++k)
+            for (int ci = 0; ci < c.cin; ++ci)
+                pool[e->A_off + (size_t)k * ctot + e->conv_s_off[i] + ci] =
+                    src[(size_t)k * c.cin + ci] * mod_coef;
+        src += (size_t)kDlatent * c.cin;
+        for (int ci = 0; ci < c.cin; ++ci)
+            pool[e->bias1_off + e->conv_s_off[i] + ci] = src[ci] + 1.0f;
+        src += c.cin;
+        e->conv_ns[i] = src[0];
+        src += 1;
+        e->conv_bias[i] = reserve(c.cout);
+        std::memcpy(&pool[e->conv_bias[i]], src, c.cout * sizeof(float));
+        src += c.cout;
+    }
+    e->rgb_w.resize(nrgb);
+    e->rgb_bias.resize(nrgb);
+    for (int i = 0; i < nrgb; ++i) {
+        const RgbLayerHost& r = e->rgbs[i];
+        const float coef = (float)(1.0 / std::sqrt((double)r.cin));
+        e->rgb_w[i] = reserve((size_t)r.cin * 3);
+        for (int k = 0; k < r.cin * 3; ++k) pool[e->rgb_w[i] + k] = src[k] * coef;
+        src += (size_t)r.cin * 3;
+        for (int k = 0; k < kDlatent; ++k)
+            for (int ci = 0; ci < r.cin; ++ci)
+                pool[e->A_off + (size_t)k * ctot + e->rgb_s_off[i] + ci] =
+                    src[(size_t)k * r.cin + ci] * mod_coef;
+        src += (size_t)kDlatent * r.cin;
+        for (int ci = 0; ci < r.cin; ++ci)
+            pool[e->bias1_off + e->rgb_s_off[i] + ci] = src[ci] + 1.0f;
+        src += r.cin;
+        e->rgb_bias[i] = reserve(3);
+        std::memcpy(&pool[e->rgb_bias[i]], src, 3 * sizeof(float));
+        src += 3;
+    }
+    for (int i = 0; i < nconv; ++i) {
+        const size_t n = (size_t)1 << (2 * e->convs[i].res_log2);
+        e->conv_noise[i] = reserve(n);
+        std::memcpy(&pool[e->conv_noise[i]], src, n * sizeof(float));
+        src += n;
+    }
+    if ((uint64_t)(src - host_weights) != num_floats) {
+        delete e;
+        return fail(GANCE_ERR_BAD_WEIGHTS, "internal: blob walk does not match blob size");
+    }
+
+    // dlatent row of every 32-column style block
+    std::vector<int> blk_row(ctot / 32);
+    for (int i = 0; i < nconv; ++i)
+        for (int cb = e->conv_s_off[i] / 32; cb < (e->conv_s_off[i] + e->convs[i].cin) / 32; ++cb)
+            blk_row[cb] = e->convs[i].layer_idx;
+    for (int i = 0; i < nrgb; ++i)
+        for (int cb = e->rgb_s_off[i] / 32; cb < (e->rgb_s_off[i] + e->rgbs[i].cin) / 32; ++cb)
+            blk_row[cb] = e->rgbs[i].row;
+
+    // ---- workspace sizes ----
+    const int Bmax = config->max_batch;
+    size_t x_per_frame = 0;
+    for (const auto& c : e->convs)
+        x_per_frame = std::max(x_per_frame, (size_t)c.cout << (2 * c.res_log2));
+    e->x_floats = x_per_frame * Bmax;
+    size_t t_max = 4;
+    for (const auto& c : e->convs)
+        for (int B = 1; B <= Bmax; ++B) t_max = std::max(t_max, plan_layer(c, B).t_floats);
+    e->t_floats = t_max;
+    e->y_floats = (size_t)3 * config->resolution * config->resolution * Bmax;
+
+#define GANCE_CREATE_CHECK(expr)                                                            \
+    do {                                                                                    \
+        hipError_t gance_err_ = (expr);                                                     \
+        if (gance_err_ != hipSuccess) {                                                     \
+            free_engine(e);                                                                 \
+            return fail(gance_err_ == hipErrorOutOfMemory ? GANCE_ERR_OUT_OF_MEMORY         \
+                                                          : GANCE_ERR_HIP,                  \
+                        std::string(#expr) + ": " + hipGetErrorString(gance_err_));         \
+        }                                                                                   \
+    } while (0)
+
+    e->pool_floats = pool.size();
+    GANCE_CREATE_CHECK(hipMalloc((void**)&e->pool, pool.size() * sizeof(float)));
+    GANCE_CREATE_CHECK(hipMemcpy(e->pool, pool.data(), pool.size() * sizeof(float), hipMemcpyHostToDevice));
+    GANCE_CREATE_CHECK(hipMalloc((void**)&e->blk_row, blk_row.size() * sizeof(int)));
+    GANCE_CREATE_CHECK(hipMemcpy(e->blk_row, blk_row.data(), blk_row.size() * sizeof(int), hipMemcpyHostToDevice));
+    GANCE_CREATE_CHECK(hipMalloc((void**)&e->demod_layers, demod_layers.size() * sizeof(gance::DemodLayer)));
+    GANCE_CREATE_CHECK(hipMemcpy(e->demod_layers, demod_layers.data(),
+                                 demod_layers.size() * sizeof(gance::DemodLayer), hipMemcpyHostToDevice));
+    GANCE_CREATE_CHECK(hipMalloc((void**)&e->dlat, (size_t)Bmax * e->num_rows * kDlatent * sizeof(float)));
+    GANCE_CREATE_CHECK(hipMalloc((void**)&e->map_a, (size_t)Bmax * kDlatent * sizeof(float)));
+    GANCE_CREATE_CHECK(hipMalloc((void**)&e->map_b_buf, (size_t)Bmax * kDlatent * sizeof(float)));
+    GANCE_CREATE_CHECK(hipMalloc((void**)&e->z_in, (size_t)Bmax * kDlatent * sizeof(float)));
+    GANCE_CREATE_CHECK(hipMalloc((void**)&e->styles, (size_t)Bmax * ctot * sizeof(float)));
+    GANCE_CREATE_CHECK(hipMalloc((void**)&e->demod, (size_t)Bmax * dtot * sizeof(float)));
+    GANCE_CREATE_CHECK(hipMalloc((void**)&e->xbuf[0], e->x_floats * sizeof(float)));
+    GANCE_CREATE_CHECK(hipMalloc((void**)&e->xbuf[1], e->x_floats * sizeof(float)));
+    GANCE_CREATE_CHECK(hipMalloc((void**)&e->tbuf, e->t_floats * sizeof(float)));
+    GANCE_CREATE_CHECK(hipMalloc((void**)&e->ybuf[0], e->y_floats * sizeof(float)));
+    GANCE_CREATE_CHECK(hipMalloc((void**)&e->ybuf[1], e->y_floats * sizeof(float)));
+    GANCE_CREATE_CHECK(hipMalloc((void**)&e->u8buf, e->y_floats));
+#undef GANCE_CREATE_CHECK
+    *out_engine = e;
+    return GANCE_OK;
+}
+
+void gance_engine_destroy(gance_engine* engine) { free_engine(engine); }
+
+int32_t gance_engine_vector_length(const gance_engine* engine) { return engine ? kDlatent : 0; }
+int32_t gance_engine_num_layers(const gance_engine* engine) { return engine ? engine->num_rows : 0; }
+int32_t gance_engine_resolution(const gance_engine* engine) { return engine ? engine->cfg.resolution : 0; }
+int32_t gance_engine_max_batch(const gance_engine* engine) { return engine ? engine->cfg.max_batch : 0; }
+
+int gance_synthesize_w(gance_engine* engine, const float* d_dlatents, int32_t batch,
+                       uint8_t* d_out_u8, float* d_out_f32, void* stream) {
+    if (int rc = check_call(engine, d_dlatents, batch)) return rc;
+    GANCE_HIP_CHECK(hipSetDevice(engine->cfg.device));
+    engine->steps_used = 0;
+    return synthesize_from_dlat(engine, d_dlatents, batch, d_out_u8, d_out_f32, (hipStream_t)stream);
+}
+
+int gance_synthesize_z(gance_engine* engine, const float* d_z, int32_t batch, float truncation_psi,
+                       uint8_t* d_out_u8, float* d_out_f32, void* stream_) {
+    if (int rc = check_call(engine, d_z, batch)) return rc;
+    GANCE_HIP_CHECK(hipSetDevice(engine->cfg.device));
+    hipStream_t stream = (hipStream_t)stream_;
+    engine->steps_used = 0;
+    const float* in = d_z;
+    float* bufs[2] = {engine->map_a, engine->map_b_buf};
+    for (int i = 0; i < kMappingLayers; ++i) {
+        StepScope scope(engine, stream, "mapping_dense", 2.0 * batch * kDlatent * kDlatent,
+                        4.0 * kDlatent * kDlatent);
+        GANCE_HIP_CHECK(gance::launch_mapping_dense(in, engine->pool + engine->map_w[i],
+                                                    engine->pool + engine->map_b[i], bufs[i & 1],
+                                                    batch, i == 0, stream));
+        in = bufs[i & 1];
+    }
+    {
+        StepScope scope(engine, stream, "truncate", 0.0, 0.0);
+        GANCE_HIP_CHECK(gance::launch_broadcast_truncate(in, engine->pool + engine->avg_off,
+                                                         truncation_psi, engine->dlat, batch,
+                                                         engine->num_rows, stream));
+    }
+    return synthesize_from_dlat(engine, engine->dlat, batch, d_out_u8, d_out_f32, stream);
+}
+
+static int host_call(gance_engine* e, const float* h_in, size_t in_floats, int batch, bool is_z,
+                     float psi, uint8_t* h_u8, float* h_f32) {
+    if (int rc = check_call(e, h_in, batch)) return rc;
+    GANCE_HIP_CHECK(hipSetDevice(e->cfg.device));
+    const size_t px = (size_t)e->cfg.resolution * e->cfg.resolution * 3;
+    float* d_in = is_z ? e->z_in : e->dlat;
+    GANCE_HIP_CHECK(hipMemcpy(d_in, h_in, in_floats * sizeof(float), hipMemcpyHostToDevice));
+    int rc = is_z ? gance_synthesize_z(e, d_in, batch, psi, e->u8buf, nullptr, nullptr)
+                  : gance_synthesize_w(e, d_in, batch, e->u8buf, nullptr, nullptr);
+    if (rc) return rc;
+    GANCE_HIP_CHECK(hipDeviceSynchronize());
+    if (e->debug_stop_after > 0) return GANCE_OK;
+    if (h_u8) GANCE_HIP_CHECK(hipMemcpy(h_u8, e->u8buf, px * batch, hipMemcpyDeviceToHost));
+    if (h_f32) {
+        // the final skip image is in whichever ybuf the last ToRGB wrote
+        const int n_rgb = (int)e->rgbs.size();
+        const int ycur = (n_rgb - 1) & 1;
+        GANCE_HIP_CHECK(hipMemcpy(h_f32, e->ybuf[ycur], px * batch * sizeof(float), hipMemcpyDeviceToHost));
+    }
+    return GANCE_OK;
+}
+
+int gance_synthesize_w_host(gance_engine* engine, const float* h_dlatents, int32_t batch,
+                            uint8_t* h_out_u8, float* h_out_f32) {
+    if (engine == nullptr) return fail(GANCE_ERR_INVALID_ARGUMENT, "engine is NULL");
+    return host_call(engine, h_dlatents, (size_t)batch * engine->num_rows * kDlatent, batch, false,
+                     0.f, h_out_u8, h_out_f32);
+}
+
+int gance_synthesize_z_host(gance_engine* engine, const float* h_z, int32_t batch,
+                            float truncation_psi, uint8_t* h_out_u8, float* h_out_f32) {
+    if (engine == nullptr) return fail(GANCE_ERR_INVALID_ARGUMENT, "engine is NULL");
+    return host_call(engine, h_z, (size_t)batch * kDlatent, batch, true, truncation_psi, h_out_u8,
+                     h_out_f32);
+}
+
+int32_t gance_engine_step_count(const gance_engine* engine) { return engine ? engine->steps_used : 0; }
+
+int gance_engine_step_info(gance_engine* engine, int32_t index, char* name64, float* ms,
+                           double* flops, double* bytes) {
+    if (engine == nullptr || index < 0 || index >= engine->steps_used)
+        return fail(GANCE_ERR_INVALID_ARGUMENT, "step index out of range");
+    StepRecord& r = engine->steps[index];
+    GANCE_HIP_CHECK(hipEventSynchronize(r.stop));
+    float elapsed = 0.f;
+    GANCE_HIP_CHECK(hipEventElapsedTime(&elapsed, r.start, r.stop));
+    if (name64) std::snprintf(name64, 64, "%s", r.name);
+    if (ms) *ms = elapsed;
+    if (flops) *flops = r.flops;
+    if (bytes) *bytes = r.bytes;
+    return GANCE_OK;
+}
+
+int gance_engine_debug_stop_after(gance_engine* engine, int32_t num_conv_layers) {
+    if (engine == nullptr) return fail(GANCE_ERR_INVALID_ARGUMENT, "engine is NULL");
+    engine->debug_stop_after = num_conv_layers;
+    return GANCE_OK;
+}
+
+int gance_engine_debug_read_activation(gance_engine* engine, int32_t batch, float* h_out,
+                                       uint64_t max_floats, int32_t* out_channels,
+                                       int32_t* out_side) {
+    if (engine == nullptr || h_out == nullptr)
+        return fail(GANCE_ERR_INVALID_ARGUMENT, "NULL argument");
+    const size_t n = (size_t)batch * engine->last_act_c * engine->last_act_side * engine->last_act_side;
+    if (n == 0 || n > max_floats) return fail(GANCE_ERR_INVALID_ARGUMENT, "activation does not fit");
+    GANCE_HIP_CHECK(hipDeviceSynchronize());
+    GANCE_HIP_CHECK(hipMemcpy(h_out, engine->xbuf[engine->last_act_buf], n * sizeof(float), hipMemcpyDeviceToHost));
+    if (out_channels) *out_channels = engine->last_act_c;
+    if (out_side) *out_side = engine->last_act_side;
+    return GANCE_OK;
+}
+
+}  // extern "C"

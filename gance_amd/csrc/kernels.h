@@ -1,0 +1,107 @@
+// Internal declarations shared by the HIP translation units of libgance_hip.so.
+#ifndef GANCE_KERNELS_H
+#define GANCE_KERNELS_H
+
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+namespace gance {
+
+constexpr int kMaxTaps = 9;
+constexpr int kEpilogueRaw = 0;   // out = acc * d            (split-K slabs, transposed-conv planes)
+constexpr int kEpilogueFull = 1;  // out = lrelu(acc * d + noise * strength + bias) * sqrt(2)
+
+// One launch of the implicit-GEMM modulated convolution (conv_mfma.hip).
+struct ConvArgs {
+    const float* x;      // [B][Cin][H][W]
+    const float* w;      // [9][Cin][Cout]  (tap = ky*3+kx, scaled by the runtime coefficient)
+    const float* s;      // style: s[b * s_stride + ci]
+    const float* d;      // demodulation: d[b * d_stride + co]
+    const float* noise;  // [OH][OW] or nullptr (full epilogue only)
+    const float* bias;   // [Cout]           (full epilogue only)
+    float* out;          // out[split*slab_stride + b*out_b_stride + co*out_c_stride + oy*out_row_stride + ox]
+    int B, Cin, Cout, H, W;  // input tensor
+    int OH, OW;              // output grid of this launch
+    int s_stride, d_stride;
+    float noise_strength;
+    int tiles_x, tiles_y, m_tiles;
+    int nsplit, chunks_per_split;
+    int epilogue;
+    int ntaps;
+    int tap_dy[kMaxTaps], tap_dx[kMaxTaps], tap_w[kMaxTaps];
+    long long out_b_stride, out_c_stride, slab_stride;
+    long long x_b_stride;  // Cin*H*W, or 0 when every sample reads the same tensor (4x4 const)
+    int out_row_stride;
+};
+
+struct ConvTileInfo {
+    int BM, TB, TH, TW, KC;
+};
+constexpr int kNumConvTiles = 6;
+extern const ConvTileInfo kConvTiles[kNumConvTiles];
+
+hipError_t launch_modconv(int tile_id, const ConvArgs& args, int total_blocks, hipStream_t stream);
+
+// ---- aux_kernels.hip ----
+
+// Mapping network: one dense 512->512 layer with lrelu*sqrt2 (G_mapping DenseN).
+//   out[b][j] = lrelu(sum_k in[b][k] * w[k][j] + bias[j]) * sqrt2 ; w, bias already runtime-scaled.
+// If `normalize` the input row is first multiplied by rsqrt(mean(in^2) + 1e-8) (first layer).
+hipError_t launch_mapping_dense(const float* in, const float* w, const float* bias, float* out,
+                                int B, int normalize, hipStream_t stream);
+// dlat[b][row][k] = avg[k] + psi * (w[b][k] - avg[k]) for row < num_rows (broadcast + truncation).
+hipError_t launch_broadcast_truncate(const float* w, const float* avg, float psi, float* dlat,
+                                     int B, int num_rows, hipStream_t stream);
+
+// Styles of every modulated conv at once. Column block `cb` (32 columns) reads dlatent row
+// blk_row[cb]:  s[b][col] = sum_k dlat[b][blk_row][k] * A[k][col] + mod_bias_plus_one[col].
+hipError_t launch_styles(const float* dlat, const float* A, const float* bias1, const int* blk_row,
+                         float* s, int B, int num_rows, int ctot, hipStream_t stream);
+
+struct DemodLayer {
+    long long w2_off;  // offset into w2 pool: W2[ci][co] = sum_tap w^2
+    int s_off;         // column offset of this layer's styles
+    int d_off;         // column offset of this layer's demod coefficients
+    int cin, cout;
+};
+// d[b][d_off + co] = rsqrt(sum_ci s[b][s_off+ci]^2 * W2[ci][co] + 1e-8)
+hipError_t launch_demod(const float* s, const float* w2_pool, const DemodLayer* layers,
+                        int num_layers, float* d, int B, int ctot, int dtot, hipStream_t stream);
+
+// Conv0_up second half: 4x4 FIR ([1,3,3,1] x [1,3,3,1] / 16, pad 1/1) over the (2H+1)^2
+// intermediate held as four parity planes (x nsplit slabs), + noise, bias, lrelu*sqrt2.
+struct FirArgs {
+    const float* t_ee;  // [nsplit][B][C][H+1][W+1]
+    const float* t_eo;  // [nsplit][B][C][H+1][W]
+    const float* t_oe;  // [nsplit][B][C][H][W+1]
+    const float* t_oo;  // [nsplit][B][C][H][W]
+    long long slab_ee, slab_eo, slab_oe, slab_oo;
+    const float* noise;  // [2H][2W] or nullptr
+    const float* bias;   // [C]
+    float* out;          // [B][C][2H][2W]
+    float noise_strength;
+    int B, C, H, W, nsplit;
+};
+hipError_t launch_fir_epilogue(const FirArgs& args, hipStream_t stream);
+
+// Split-K finish for stride-1 convs: out = lrelu(sum_slabs + noise*strength + bias) * sqrt2.
+hipError_t launch_splitk_finish(const float* slabs, long long slab_stride, int nsplit,
+                                const float* noise, float noise_strength, const float* bias,
+                                float* out, int B, int C, int H, int W, hipStream_t stream);
+
+// ToRGB (modulated 1x1, no demod) + bias + FIR-upsampled skip image; optional uint8 NHWC output.
+struct ToRgbArgs {
+    const float* x;       // [B][Cin][R][R]
+    const float* w;       // [Cin][3], runtime-scaled
+    const float* s;       // s[b*s_stride + ci]
+    const float* bias;    // [3]
+    const float* y_prev;  // [B][3][R/2][R/2] or nullptr
+    float* y;             // [B][3][R][R]
+    uint8_t* u8;          // [B][R][R][3] or nullptr
+    int B, Cin, R, s_stride;
+};
+hipError_t launch_torgb(const ToRgbArgs& args, hipStream_t stream);
+
+}  // namespace gance
+#endif

@@ -1,0 +1,317 @@
+"""
+ctypes binding of libgance_hip.so (C ABI in include/gance_hip.h).
+
+This is the ONLY route from Python to the synthesis / audio kernels. If the shared library has not
+been built (`python -c "import __graft_entry__ as g; g.build()"` or `make -C gance_amd/csrc`) or no
+MI355X is visible, calls raise: there is no CPU fallback in the product path.
+"""
+
+import ctypes
+from pathlib import Path
+from typing import Dict, List, NamedTuple, Optional
+
+import numpy as np
+
+from gance_amd.stylegan2 import spec as sg2_spec
+
+LIBRARY_NAME = "libgance_hip.so"
+LIBRARY_PATH = Path(__file__).resolve().parent / LIBRARY_NAME
+
+GANCE_OK = 0
+GANCE_FLAG_PROFILE_STEPS = 1
+
+STATUS_NAMES = {
+    1: "GANCE_ERR_INVALID_ARGUMENT",
+    2: "GANCE_ERR_BAD_WEIGHTS",
+    3: "GANCE_ERR_HIP",
+    4: "GANCE_ERR_OUT_OF_MEMORY",
+    5: "GANCE_ERR_NO_DEVICE",
+}
+
+
+class GanceHipError(RuntimeError):
+    """A libgance_hip call returned a non-zero status."""
+
+    def __init__(self, status: int, message: str) -> None:
+        super().__init__(f"{STATUS_NAMES.get(status, status)}: {message}")
+        self.status = status
+
+
+class EngineConfig(ctypes.Structure):
+    """`gance_engine_config` of include/gance_hip.h."""
+
+    _fields_ = [
+        ("resolution", ctypes.c_int32),
+        ("max_batch", ctypes.c_int32),
+        ("device", ctypes.c_int32),
+        ("flags", ctypes.c_int32),
+    ]
+
+
+_F32P = ctypes.POINTER(ctypes.c_float)
+_U8P = ctypes.POINTER(ctypes.c_uint8)
+
+# name -> (restype, argtypes); every symbol include/gance_hip.h declares.
+SIGNATURES = {
+    "gance_last_error": (ctypes.c_char_p, []),
+    "gance_abi_version": (ctypes.c_int, []),
+    "gance_engine_create": (
+        ctypes.c_int,
+        [ctypes.POINTER(EngineConfig), _F32P, ctypes.c_uint64, ctypes.POINTER(ctypes.c_void_p)],
+    ),
+    "gance_engine_destroy": (None, [ctypes.c_void_p]),
+    "gance_engine_vector_length": (ctypes.c_int32, [ctypes.c_void_p]),
+    "gance_engine_num_layers": (ctypes.c_int32, [ctypes.c_void_p]),
+    "gance_engine_resolution": (ctypes.c_int32, [ctypes.c_void_p]),
+    "gance_engine_max_batch": (ctypes.c_int32, [ctypes.c_void_p]),
+    "gance_weight_blob_floats": (ctypes.c_uint64, [ctypes.c_int32]),
+    "gance_synthesize_w": (
+        ctypes.c_int,
+        [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p],
+    ),
+    "gance_synthesize_z": (
+        ctypes.c_int,
+        [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_float, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p],
+    ),
+    "gance_synthesize_w_host": (ctypes.c_int, [ctypes.c_void_p, _F32P, ctypes.c_int32, _U8P, _F32P]),
+    "gance_synthesize_z_host": (
+        ctypes.c_int,
+        [ctypes.c_void_p, _F32P, ctypes.c_int32, ctypes.c_float, _U8P, _F32P],
+    ),
+    "gance_engine_step_count": (ctypes.c_int32, [ctypes.c_void_p]),
+    "gance_engine_step_info": (
+        ctypes.c_int,
+        [
+            ctypes.c_void_p,
+            ctypes.c_int32,
+            ctypes.c_char_p,
+            ctypes.POINTER(ctypes.c_float),
+            ctypes.POINTER(ctypes.c_double),
+            ctypes.POINTER(ctypes.c_double),
+        ],
+    ),
+    "gance_engine_debug_stop_after": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32]),
+    "gance_engine_debug_read_activation": (
+        ctypes.c_int,
+        [
+            ctypes.c_void_p,
+            ctypes.c_int32,
+            _F32P,
+            ctypes.c_uint64,
+            ctypes.POINTER(ctypes.c_int32),
+            ctypes.POINTER(ctypes.c_int32),
+        ],
+    ),
+}
+
+_LIB: Optional[ctypes.CDLL] = None
+
+
+def load_library() -> ctypes.CDLL:
+    """
+    dlopen the in-tree library and declare every prototype.
+    :raises RuntimeError: if the library has not been built. Never falls back to another backend.
+    """
+    global _LIB  # pylint: disable=global-statement
+    if _LIB is not None:
+        return _LIB
+    if not LIBRARY_PATH.exists():
+        raise RuntimeError(
+            f"{LIBRARY_PATH} is missing: build the HIP extension first "
+            "(`make -C gance_amd/csrc` or `__graft_entry__.build()`). "
+            "gance_amd has no CPU fallback."
+        )
+    lib = ctypes.CDLL(str(LIBRARY_PATH))
+    for name, (restype, argtypes) in SIGNATURES.items():
+        function = getattr(lib, name)  # AttributeError if the .so does not export it
+        function.restype = restype
+        function.argtypes = argtypes
+    _LIB = lib
+    return lib
+
+
+def _check(lib: ctypes.CDLL, status: int) -> None:
+    if status != GANCE_OK:
+        raise GanceHipError(status, lib.gance_last_error().decode("utf-8", "replace"))
+
+
+def _f32(array: np.ndarray) -> np.ndarray:
+    return np.ascontiguousarray(array, dtype=np.float32)
+
+
+class StepInfo(NamedTuple):
+    """One kernel launch of the last synthesize call (GANCE_FLAG_PROFILE_STEPS)."""
+
+    name: str
+    ms: float
+    flops: float
+    bytes: float
+
+
+class Engine:
+    """
+    One StyleGAN2 generator resident in HBM. Thin owner of a `gance_engine*`.
+    Replaces the TF session + unpickled `Network` the reference keeps per worker process
+    (gance/network_interface/network_functions.py:93-111).
+    """
+
+    def __init__(
+        self,
+        variables: Dict[str, np.ndarray],
+        resolution: int,
+        max_batch: int = 1,
+        device: int = 0,
+        profile: bool = False,
+    ) -> None:
+        self._lib = load_library()
+        self._handle = ctypes.c_void_p()
+        spec = sg2_spec.make_spec(resolution)
+        blob = sg2_spec.pack_variables(variables, spec)
+        config = EngineConfig(resolution, max_batch, device, GANCE_FLAG_PROFILE_STEPS if profile else 0)
+        _check(
+            self._lib,
+            self._lib.gance_engine_create(
+                ctypes.byref(config),
+                blob.ctypes.data_as(_F32P),
+                ctypes.c_uint64(blob.size),
+                ctypes.byref(self._handle),
+            ),
+        )
+        self.resolution = resolution
+        self.max_batch = max_batch
+        self.device = device
+        self.vector_length = int(self._lib.gance_engine_vector_length(self._handle))
+        self.num_layers = int(self._lib.gance_engine_num_layers(self._handle))
+
+    def close(self) -> None:
+        """Free the engine's HBM. Idempotent."""
+        if self._handle:
+            self._lib.gance_engine_destroy(self._handle)
+            self._handle = ctypes.c_void_p()
+
+    def __del__(self) -> None:
+        try:
+            self.close()
+        except Exception:  # pylint: disable=broad-except
+            pass
+
+    def _require_open(self) -> None:
+        if not self._handle:
+            raise ValueError("Engine has been closed")
+
+    # ---- host-buffer calls (numpy in, numpy out) ----
+
+    def synthesize_w(self, dlatents: np.ndarray, want_float: bool = False):
+        """dlatents [B, W, 512] -> uint8 [B, R, R, 3] (and float32 [B, 3, R, R] if want_float)."""
+        self._require_open()
+        dl = _f32(dlatents)
+        if dl.ndim != 3 or dl.shape[1] != self.num_layers or dl.shape[2] != self.vector_length:
+            raise ValueError(f"dlatents must be [B, {self.num_layers}, {self.vector_length}], got {dl.shape}")
+        batch = dl.shape[0]
+        out = np.empty((batch, self.resolution, self.resolution, 3), dtype=np.uint8)
+        fout = np.empty((batch, 3, self.resolution, self.resolution), dtype=np.float32) if want_float else None
+        _check(
+            self._lib,
+            self._lib.gance_synthesize_w_host(
+                self._handle,
+                dl.ctypes.data_as(_F32P),
+                batch,
+                out.ctypes.data_as(_U8P),
+                fout.ctypes.data_as(_F32P) if fout is not None else None,
+            ),
+        )
+        return (out, fout) if want_float else out
+
+    def synthesize_z(self, z: np.ndarray, truncation_psi: float = 1.2, want_float: bool = False):
+        """z [B, 512] -> uint8 [B, R, R, 3] (and float32 [B, 3, R, R] if want_float)."""
+        self._require_open()
+        zz = _f32(z)
+        if zz.ndim != 2 or zz.shape[1] != self.vector_length:
+            raise ValueError(f"z must be [B, {self.vector_length}], got {zz.shape}")
+        batch = zz.shape[0]
+        out = np.empty((batch, self.resolution, self.resolution, 3), dtype=np.uint8)
+        fout = np.empty((batch, 3, self.resolution, self.resolution), dtype=np.float32) if want_float else None
+        _check(
+            self._lib,
+            self._lib.gance_synthesize_z_host(
+                self._handle,
+                zz.ctypes.data_as(_F32P),
+                batch,
+                ctypes.c_float(truncation_psi),
+                out.ctypes.data_as(_U8P),
+                fout.ctypes.data_as(_F32P) if fout is not None else None,
+            ),
+        )
+        return (out, fout) if want_float else out
+
+    # ---- device-pointer calls (torch tensors or raw pointers; asynchronous on `stream`) ----
+
+    def synthesize_w_device(self, d_dlatents: int, batch: int, d_out_u8: int, d_out_f32: int = 0, stream: int = 0) -> None:
+        """Raw device pointers (ints). Asynchronous on `stream`."""
+        self._require_open()
+        _check(
+            self._lib,
+            self._lib.gance_synthesize_w(self._handle, d_dlatents, batch, d_out_u8 or None, d_out_f32 or None, stream or None),
+        )
+
+    def synthesize_z_device(
+        self, d_z: int, batch: int, truncation_psi: float, d_out_u8: int, d_out_f32: int = 0, stream: int = 0
+    ) -> None:
+        """Raw device pointers (ints). Asynchronous on `stream`."""
+        self._require_open()
+        _check(
+            self._lib,
+            self._lib.gance_synthesize_z(
+                self._handle, d_z, batch, ctypes.c_float(truncation_psi), d_out_u8 or None, d_out_f32 or None, stream or None
+            ),
+        )
+
+    # ---- profiling / debugging ----
+
+    def steps(self) -> List[StepInfo]:
+        """Per-launch timings of the last call (engine created with profile=True)."""
+        self._require_open()
+        count = int(self._lib.gance_engine_step_count(self._handle))
+        result = []
+        name = ctypes.create_string_buffer(64)
+        ms = ctypes.c_float()
+        flops = ctypes.c_double()
+        nbytes = ctypes.c_double()
+        for index in range(count):
+            _check(
+                self._lib,
+                self._lib.gance_engine_step_info(
+                    self._handle, index, name, ctypes.byref(ms), ctypes.byref(flops), ctypes.byref(nbytes)
+                ),
+            )
+            result.append(StepInfo(name.value.decode(), float(ms.value), float(flops.value), float(nbytes.value)))
+        return result
+
+    def debug_activation_after(self, dlatents: np.ndarray, num_conv_layers: int) -> np.ndarray:
+        """Run only the first `num_conv_layers` conv layers and return x [B, C, res, res]."""
+        self._require_open()
+        dl = _f32(dlatents)
+        batch = dl.shape[0]
+        _check(self._lib, self._lib.gance_engine_debug_stop_after(self._handle, num_conv_layers))
+        try:
+            _check(
+                self._lib,
+                self._lib.gance_synthesize_w_host(self._handle, dl.ctypes.data_as(_F32P), batch, None, None),
+            )
+            capacity = batch * 512 * self.resolution * self.resolution
+            channels = ctypes.c_int32()
+            side = ctypes.c_int32()
+            spec = sg2_spec.make_spec(self.resolution)
+            conv = spec.convs[num_conv_layers - 1]
+            count = batch * conv.cout * (2 ** conv.res_log2) ** 2
+            out = np.empty(count, dtype=np.float32)
+            _check(
+                self._lib,
+                self._lib.gance_engine_debug_read_activation(
+                    self._handle, batch, out.ctypes.data_as(_F32P), ctypes.c_uint64(min(capacity, count)),
+                    ctypes.byref(channels), ctypes.byref(side),
+                ),
+            )
+            return out.reshape(batch, channels.value, side.value, side.value)
+        finally:
+            self._lib.gance_engine_debug_stop_after(self._handle, 0)

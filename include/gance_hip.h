@@ -1,0 +1,128 @@
+/*
+ * gance_hip.h -- C ABI of libgance_hip.so, the MI355X (gfx950) implementation of GANce's hot path
+ *                audio -> latent -> StyleGAN2 frame synthesis.
+ *
+ * Plain pointers and sizes only; no torch / numpy types. Device pointers are HIP device pointers
+ * (e.g. torch.Tensor.data_ptr() of a cuda tensor); `stream` is a hipStream_t passed as void*
+ * (NULL = the null stream). All functions return GANCE_OK (0) or a negative-free status code
+ * below; gance_last_error() returns a thread-local description of the last failure.
+ *
+ * Each entry point cites the reference interface it replaces (paths relative to the GANce tree).
+ */
+#ifndef GANCE_HIP_H
+#define GANCE_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GANCE_ABI_VERSION 1
+
+enum gance_status {
+    GANCE_OK = 0,
+    GANCE_ERR_INVALID_ARGUMENT = 1, /* NULL pointer, bad size, batch > max_batch ...            */
+    GANCE_ERR_BAD_WEIGHTS = 2,      /* weight blob length does not match the configuration      */
+    GANCE_ERR_HIP = 3,              /* a HIP runtime call failed (see gance_last_error)         */
+    GANCE_ERR_OUT_OF_MEMORY = 4,    /* hipMalloc failed                                         */
+    GANCE_ERR_NO_DEVICE = 5         /* no gfx950 device visible: there is NO CPU fallback       */
+};
+
+const char* gance_last_error(void);
+int gance_abi_version(void);
+
+/* ------------------------------------------------------------------------------------------ */
+/* Latent -> frame: StyleGAN2 config-f generator engine                                        */
+/* ------------------------------------------------------------------------------------------ */
+
+typedef struct gance_engine gance_engine; /* opaque; owns weights + workspace in HBM */
+
+typedef struct gance_engine_config {
+    int32_t resolution; /* output side, power of two in [8, 1024]; 1024 = FFHQ config-f        */
+    int32_t max_batch;  /* workspace is sized for this many frames per call (>= 1)             */
+    int32_t device;     /* HIP device ordinal                                                  */
+    int32_t flags;      /* GANCE_FLAG_*                                                        */
+} gance_engine_config;
+
+#define GANCE_FLAG_PROFILE_STEPS 1 /* record a hipEvent pair around every kernel launch        */
+
+/*
+ * Load a network. Replaces load_network_network + wrap_loaded_network
+ * (gance/network_interface/network_functions.py:93-111,114-192): the reference unpickles a TF1
+ * Network and opens a session; here the caller hands the raw variables as one float32 blob in
+ * the order documented in gance_amd/stylegan2/spec.py::variable_shapes (TF variable order:
+ * mapping dense 0..7 {weight,bias}, dlatent_avg, const, per conv layer {weight HWIO, mod_weight,
+ * mod_bias, noise_strength, bias}, per ToRGB {weight, mod_weight, mod_bias, bias}, noise buffers).
+ * The engine applies the equalised-LR runtime coefficients and re-lays the weights out for its
+ * kernels. `host_weights` is host memory and is not retained.
+ */
+int gance_engine_create(const gance_engine_config* config, const float* host_weights,
+                        uint64_t num_floats, gance_engine** out_engine);
+
+/* Replaces the worker's stop_function (network_functions.py:303-321): frees HBM. NULL is a no-op. */
+void gance_engine_destroy(gance_engine* engine);
+
+/* network.input_shape[1] (network_functions.py:191): length of a z / w vector (512). */
+int32_t gance_engine_vector_length(const gance_engine* engine);
+/* Number of dlatent rows W the matrix path expects (18 at 1024, 14 at 256). */
+int32_t gance_engine_num_layers(const gance_engine* engine);
+int32_t gance_engine_resolution(const gance_engine* engine);
+int32_t gance_engine_max_batch(const gance_engine* engine);
+/* Number of floats gance_engine_create expects for `resolution` (0 if unsupported). */
+uint64_t gance_weight_blob_floats(int32_t resolution);
+
+/*
+ * Matrix path. Replaces create_image_matrix (network_functions.py:160-169):
+ *   G.components.synthesis.run(dlatents[1,W,512], randomize_noise=False,
+ *                              output_transform=convert_images_to_uint8(nchw_to_nhwc=True))
+ * batched: d_dlatents is [batch][W][512] float32 on the device. d_out_u8 receives
+ * [batch][R][R][3] uint8 (RGB, NHWC) and may be NULL; d_out_f32 (optional, may be NULL) receives
+ * the pre-quantisation image [batch][3][R][R] float32 for tolerance checks.
+ */
+int gance_synthesize_w(gance_engine* engine, const float* d_dlatents, int32_t batch,
+                       uint8_t* d_out_u8, float* d_out_f32, void* stream);
+
+/*
+ * Vector path. Replaces create_image_vector (network_functions.py:144-158):
+ *   G.run(z[1,512], None, truncation_psi=1.2, output_transform=...)
+ * = normalise z, 8-layer mapping, broadcast to W rows, w' = avg + psi*(w - avg) on every row,
+ * synthesis. d_z is [batch][512] float32 on the device. Stored noise buffers are used.
+ */
+int gance_synthesize_z(gance_engine* engine, const float* d_z, int32_t batch,
+                       float truncation_psi, uint8_t* d_out_u8, float* d_out_f32, void* stream);
+
+/*
+ * Host-buffer forms of the two calls above for the reference's one-frame-at-a-time boundary
+ * (ImageFunction.__call__, network_functions.py:51-63): H2D copy, synthesis, D2H copy,
+ * synchronous. h_out_u8 is [batch][R][R][3]; h_out_f32 may be NULL.
+ */
+int gance_synthesize_w_host(gance_engine* engine, const float* h_dlatents, int32_t batch,
+                            uint8_t* h_out_u8, float* h_out_f32);
+int gance_synthesize_z_host(gance_engine* engine, const float* h_z, int32_t batch,
+                            float truncation_psi, uint8_t* h_out_u8, float* h_out_f32);
+
+/*
+ * Profiling / debugging (no reference counterpart).
+ * With GANCE_FLAG_PROFILE_STEPS every launch of the last synthesize call is bracketed by
+ * hipEvents on the call's stream. gance_engine_step_count returns the number of launches,
+ * gance_engine_step_info fills name (<=63 chars + NUL), elapsed milliseconds and the
+ * algorithmic FLOPs and bytes of launch `index` of the LAST call (synchronises the stream).
+ */
+int32_t gance_engine_step_count(const gance_engine* engine);
+int gance_engine_step_info(gance_engine* engine, int32_t index, char* name64, float* ms,
+                           double* flops, double* bytes);
+/*
+ * Debug: run only the first `num_steps` conv layers of the next synthesize_w calls (<=0 = all)
+ * and copy the current activation tensor [batch][C][res][res] to the host.
+ */
+int gance_engine_debug_stop_after(gance_engine* engine, int32_t num_conv_layers);
+int gance_engine_debug_read_activation(gance_engine* engine, int32_t batch, float* h_out,
+                                       uint64_t max_floats, int32_t* out_channels,
+                                       int32_t* out_side);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GANCE_HIP_H */
