@@ -1,0 +1,208 @@
+"""
+Benchmark of the hot path on MI355X: synthesized frames/sec at 1024x1024 config-f.
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+
+Workload = BASELINE.json configs[1]: FFHQ config-f 1024x1024, random-init weights (seed 0),
+batched random-z synthesis. One step = one batch of `--batch` z vectors (already resident in HBM)
+-> mapping -> truncation (psi 1.2) -> synthesis -> uint8 NHWC frames in HBM, through the C ABI of
+libgance_hip.so. With N > 1 every rank runs its own batches (frames shard embarrassingly, weak
+scaling) and the finished frames are gathered into rank 0 over RCCL, in frame order, overlapped
+with the next step.
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
+  roofline     -- the dominant kernel (modulated conv on the fp32 matrix cores) timed with HIP
+                  events on the launch stream during the timed region
+  cpu_baseline -- the CPU oracle (oracle/stylegan2_ref.py, torch fp32, all host cores) on a
+                  bounded sample of the same workload; rank 0, N = 1 only. Baseline, not target.
+"""
+
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+REPO_ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(REPO_ROOT))
+
+from gance_amd import frame_sharding, hip_lib  # noqa: E402
+from gance_amd.stylegan2 import spec as sg2_spec  # noqa: E402
+
+FP32_MFMA_PEAK_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
+HBM_PEAK_GBS = 8000.0
+ALGORITHMIC_GFLOP_PER_FRAME_1024 = 148.5
+
+
+def cpu_baseline(resolution: int, variables, budget_seconds: float = 15.0) -> dict:
+    """Time the CPU oracle (checker infrastructure, used here only as the reported baseline)."""
+    from oracle import stylegan2_ref  # pylint: disable=import-outside-toplevel
+
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    spec = sg2_spec.make_spec(resolution)
+    rng = np.random.RandomState(1)
+    dlatents = rng.randn(1, spec.num_layers, 512).astype(np.float32)
+    stylegan2_ref.synthesize_w(dlatents, variables, resolution, dtype=torch.float32)  # warm-up
+    frames = 0
+    start = time.perf_counter()
+    while True:
+        image = stylegan2_ref.synthesize_w(dlatents, variables, resolution, dtype=torch.float32)
+        stylegan2_ref.convert_images_to_uint8(image)
+        frames += 1
+        elapsed = time.perf_counter() - start
+        if elapsed > budget_seconds or frames >= 10:
+            break
+    return {
+        "value": round(frames / elapsed, 4),
+        "unit": "frames/s",
+        "cores": cores,
+        "kind": "port",
+        "sample": f"{frames} frames of the same {resolution}x{resolution} config-f network, batch 1, torch fp32 CPU oracle, dlatent (synthesis-only) input",
+    }
+
+
+def main() -> int:
+    parser = argparse.ArgumentParser()
+    parser.add_argument("--gpus", type=int, default=1)
+    parser.add_argument("--steps", type=int, default=20)
+    parser.add_argument("--warmup", type=int, default=3)
+    parser.add_argument("--batch", type=int, default=8, help="frames per step per GPU")
+    parser.add_argument("--resolution", type=int, default=1024)
+    parser.add_argument("--no-cpu-baseline", action="store_true")
+    args = parser.parse_args()
+
+    world_size = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world_size != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world_size}: launch with torch.distributed.run")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X; there is no CPU fallback in the product path")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world_size > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=device)
+
+    resolution, batch = args.resolution, args.batch
+    variables = sg2_spec.make_random_variables(resolution, seed=0)
+    engine = hip_lib.Engine(variables, resolution, max_batch=batch, device=local_rank, profile=True)
+
+    # inputs resident in HBM before the timed region: rank 0 draws every rank's z and scatters them
+    all_z = None
+    if rank == 0:
+        all_z = torch.from_numpy(np.random.RandomState(1).randn(world_size * batch, 512).astype(np.float32))
+    z = frame_sharding.scatter_latents(all_z, world_size * batch, device).contiguous()
+    frames = [torch.empty((batch, resolution, resolution, 3), dtype=torch.uint8, device=device) for _ in range(2)]
+    gathered = None
+    if world_size > 1 and rank == 0:
+        gathered = [torch.empty((world_size * batch, resolution, resolution, 3), dtype=torch.uint8, device=device) for _ in range(2)]
+    stream = torch.cuda.current_stream(device)
+    pending = [None, None]
+
+    def step(index: int) -> None:
+        slot = index & 1
+        if pending[slot] is not None:
+            pending[slot].wait()
+            pending[slot] = None
+        engine.synthesize_z_device(z.data_ptr(), batch, 1.2, frames[slot].data_ptr(), 0, stream.cuda_stream)
+        if world_size > 1:
+            _, work = frame_sharding.gather_frames(
+                frames[slot], world_size * batch, async_op=True, out=gathered[slot] if rank == 0 else None
+            )
+            pending[slot] = work
+
+    def drain() -> None:
+        for slot in (0, 1):
+            if pending[slot] is not None:
+                pending[slot].wait()
+                pending[slot] = None
+
+    def fence() -> None:
+        drain()
+        torch.cuda.synchronize(device)
+        if world_size > 1:
+            dist.barrier()
+        torch.cuda.synchronize(device)
+
+    for index in range(args.warmup):
+        step(index)
+    fence()
+    start = time.perf_counter()
+    for index in range(args.steps):
+        step(index)
+    fence()
+    elapsed = time.perf_counter() - start
+    if world_size > 1:
+        elapsed_t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(elapsed_t, op=dist.ReduceOp.MAX)
+        elapsed = float(elapsed_t.item())
+
+    # per-launch HIP-event timings of the last timed step (events sit on the launch stream)
+    steps_info = engine.steps()
+    conv_steps = [s for s in steps_info if s.flops > 0 and s.name.startswith("conv")]
+    conv_ms = sum(s.ms for s in conv_steps)
+    conv_flops = sum(s.flops for s in conv_steps)
+    dominant = max(conv_steps, key=lambda s: s.ms)
+    total_ms = sum(s.ms for s in steps_info)
+
+    if rank == 0:
+        frames_total = world_size * batch * args.steps
+        fps = frames_total / elapsed
+        result = {
+            "metric": "synthesized frames/sec at 1024x1024 config-f",
+            "value": round(fps, 3),
+            "unit": "frames/s",
+            "n_gpus": world_size,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(1e3 * elapsed / args.steps, 4),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic (random-init weights seed 0, RandomState(1) z vectors)",
+            "config": {
+                "workload": "BASELINE.json configs[1]: FFHQ config-f %dx%d random-init, batched random-z synthesis (mapping + truncation psi=1.2 + synthesis + uint8 NHWC), frames resident in HBM" % (resolution, resolution),
+                "frames_per_step_per_gpu": batch,
+                "parallelism": f"frame-sharded x{world_size}" + (" + RCCL gather to rank 0" if world_size > 1 else ""),
+            },
+            "roofline": {
+                "bound": "mfma",
+                "kernel": "modconv_mfma_kernel (%s)" % dominant.name,
+                "achieved": round(dominant.flops / (dominant.ms * 1e-3) / 1e12, 3),
+                "peak": FP32_MFMA_PEAK_TFLOPS,
+                "unit": "TFLOP/s",
+                "frac": round(dominant.flops / (dominant.ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4),
+                "traffic": None,
+                "all_conv_launches": {
+                    "achieved": round(conv_flops / (conv_ms * 1e-3) / 1e12, 3),
+                    "frac": round(conv_flops / (conv_ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4),
+                    "share_of_step_time": round(conv_ms / total_ms, 4),
+                },
+                "whole_path_frac": round(
+                    (fps / world_size) * ALGORITHMIC_GFLOP_PER_FRAME_1024 * (resolution / 1024) ** 2 / 1e3 / FP32_MFMA_PEAK_TFLOPS, 4
+                ),
+            },
+        }
+        if world_size == 1 and not args.no_cpu_baseline:
+            result["cpu_baseline"] = cpu_baseline(resolution, variables)
+        print(json.dumps(result), flush=True)
+
+    engine.close()
+    if world_size > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

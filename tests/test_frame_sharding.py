@@ -1,0 +1,79 @@
+"""
+CPU tests of the multi-GPU path with the gloo backend, world_size 2 (and 3 for ragged shards):
+scatter of per-frame latent chunks from rank 0, gather of the ordered frame stream to rank 0.
+"""
+
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from gance_amd import frame_sharding
+
+
+def test_shard_bounds_cover_all_frames_once() -> None:
+    for num_frames in (0, 1, 7, 8, 1800):
+        for world_size in (1, 2, 3, 8):
+            seen = []
+            for rank in range(world_size):
+                start, end = frame_sharding.shard_bounds(num_frames, world_size, rank)
+                assert 0 <= start <= end <= num_frames
+                seen.extend(range(start, end))
+            assert seen == list(range(num_frames))
+    with pytest.raises(ValueError):
+        frame_sharding.shard_bounds(10, 2, 2)
+
+
+def _free_port() -> int:
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        return sock.getsockname()[1]
+
+
+def _worker(rank: int, world_size: int, port: int, num_frames: int) -> None:
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world_size)
+    try:
+        device = torch.device("cpu")
+        all_latents = None
+        if rank == 0:
+            all_latents = torch.arange(num_frames * 2 * 4, dtype=torch.float32).reshape(num_frames, 2, 4)
+        local = frame_sharding.scatter_latents(all_latents, num_frames, device)
+        start, end = frame_sharding.shard_bounds(num_frames, world_size, rank)
+        expected = torch.arange(num_frames * 8, dtype=torch.float32).reshape(num_frames, 2, 4)[start:end]
+        assert torch.equal(local, expected), (rank, local, expected)
+
+        # "synthesize": frame f is a 2x2x3 image filled with f (mod 256)
+        frames = torch.stack(
+            [torch.full((2, 2, 3), f % 256, dtype=torch.uint8) for f in range(start, end)]
+        ) if end > start else torch.empty((0, 2, 2, 3), dtype=torch.uint8)
+        gathered, work = frame_sharding.gather_frames(frames, num_frames, async_op=True)
+        work.wait()
+        if rank == 0:
+            assert gathered.shape == (num_frames, 2, 2, 3)
+            assert gathered[:, 0, 0, 0].tolist() == [f % 256 for f in range(num_frames)]
+        else:
+            assert gathered is None
+        gathered_sync, work_sync = frame_sharding.gather_frames(frames, num_frames)
+        assert work_sync is None
+        if rank == 0:
+            assert torch.equal(gathered_sync, gathered)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world_size,num_frames", [(2, 8), (2, 7), (3, 10)])
+def test_scatter_then_gather_keeps_frame_order(world_size: int, num_frames: int) -> None:
+    mp.spawn(_worker, args=(world_size, _free_port(), num_frames), nprocs=world_size, join=True)
+
+
+def test_single_process_is_a_passthrough() -> None:
+    latents = torch.randn(5, 18, 512)
+    assert torch.equal(frame_sharding.scatter_latents(latents, 5, torch.device("cpu")), latents)
+    frames = torch.zeros((5, 4, 4, 3), dtype=torch.uint8)
+    out, work = frame_sharding.gather_frames(frames, 5)
+    assert work is None and out.shape == (5, 4, 4, 3)
