@@ -41,11 +41,23 @@ HBM_PEAK_GBS = 8000.0
 ALGORITHMIC_GFLOP_PER_FRAME_1024 = 148.5
 
 
+def usable_cores() -> int:
+    """Cores this process may actually use: affinity mask capped by the cgroup CPU quota."""
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = Path("/sys/fs/cgroup/cpu.max").read_text().split()
+        if quota != "max":
+            cores = min(cores, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, cores)
+
+
 def cpu_baseline(resolution: int, variables, budget_seconds: float = 15.0) -> dict:
     """Time the CPU oracle (checker infrastructure, used here only as the reported baseline)."""
     from oracle import stylegan2_ref  # pylint: disable=import-outside-toplevel
 
-    cores = os.cpu_count() or 1
+    cores = usable_cores()
     torch.set_num_threads(cores)
     spec = sg2_spec.make_spec(resolution)
     rng = np.random.RandomState(1)
@@ -77,6 +89,7 @@ def main() -> int:
     parser.add_argument("--batch", type=int, default=8, help="frames per step per GPU")
     parser.add_argument("--resolution", type=int, default=1024)
     parser.add_argument("--no-cpu-baseline", action="store_true")
+    parser.add_argument("--print-steps", action="store_true", help="per-launch table on stderr")
     args = parser.parse_args()
 
     world_size = int(os.environ.get("WORLD_SIZE", "1"))
@@ -153,6 +166,12 @@ def main() -> int:
     conv_flops = sum(s.flops for s in conv_steps)
     dominant = max(conv_steps, key=lambda s: s.ms)
     total_ms = sum(s.ms for s in steps_info)
+    if args.print_steps and rank == 0:
+        for info in steps_info:
+            tflops = info.flops / (info.ms * 1e-3) / 1e12 if info.ms > 0 else 0.0
+            gbs = info.bytes / (info.ms * 1e-3) / 1e9 if info.ms > 0 else 0.0
+            print(f"  {info.name:34s} {info.ms * 1e3:9.1f} us {tflops:8.2f} TFLOP/s {gbs:9.1f} GB/s", file=sys.stderr)
+        print(f"  sum of launches {total_ms:.3f} ms", file=sys.stderr)
 
     if rank == 0:
         frames_total = world_size * batch * args.steps

@@ -188,95 +188,96 @@ hipError_t launch_demod(const float* s, const float* w2_pool, const DemodLayer* 
 // ------------------------------------------------------------------------------------------
 // FIR half of Conv0_up + noise + bias + leaky ReLU
 // ------------------------------------------------------------------------------------------
-// T (the (2H+1)x(2W+1) transposed-conv result) lives as four parity planes. One thread makes the
-// 2x2 output quad (2Y..2Y+1, 2X..2X+1):
+// T (the (2H+1)x(2W+1) transposed-conv result) lives as four parity planes, each zero-bordered
+// [unit = split*B + b][C][H+3][W+8] with T[2y'+py][2x'+px] at [y'+1][x'+4]; cells a class does
+// not own are never written and stay zero, so no load needs a bounds test.
 //   out[oy][ox] = sum_{a,b} k[a] k[b] T[oy+a-1][ox+b-1],  k = [1,3,3,1]/4, T = 0 outside.
+// One thread makes a 2 x 8 output strip (rows 2Y, 2Y+1; columns 2X .. 2X+7, X % 4 == 0) from
+// 5 T rows x (5 even + 6 odd columns): 10 aligned float4 loads + 15 dword loads per 16 outputs.
+
+struct __attribute__((packed, aligned(4))) float4u {
+    float x, y, z, w;
+};
 
 __global__ __launch_bounds__(256) void fir_epilogue_kernel(const FirArgs p) {
+    const int W4 = p.W >> 2;
     const size_t q = (size_t)blockIdx.x * 256 + threadIdx.x;
-    const size_t total = (size_t)p.B * p.C * p.H * p.W;
+    const size_t total = (size_t)p.B * p.C * p.H * W4;
     if (q >= total) return;
-    const int X = (int)(q % p.W);
-    const int Y = (int)((q / p.W) % p.H);
-    const size_t bc = q / ((size_t)p.W * p.H);
+    const int X = (int)(q % W4) * 4;
+    const int Y = (int)((q / W4) % p.H);
+    const size_t bc = q / ((size_t)W4 * p.H);
     const int c = (int)(bc % p.C);
-    const int H = p.H, W = p.W;
+    const int b = (int)(bc / p.C);
+    const int TPW = p.W + 8;
+    const size_t plane = (size_t)(p.H + 3) * TPW;
 
-    // summed-over-slabs loads with zero outside each plane
-    auto ld = [&](const float* base, long long slab, int rows, int cols, int yy, int xx) -> float {
-        if (yy < 0 || yy >= rows || xx < 0 || xx >= cols) return 0.f;
-        const float* ptr = base + (bc * rows + yy) * (size_t)cols + xx;
-        float v = 0.f;
-        for (int sp = 0; sp < p.nsplit; ++sp) v += ptr[(size_t)sp * slab];
-        return v;
-    };
-    // horizontal pass of one T row: te = even columns X, X+1 ; to = odd columns X-1, X, X+1
-    auto hpass = [&](float te0, float te1, float to_m1, float to0, float to1, float& h0,
-                     float& h1) {
-        h0 = 0.25f * to_m1 + 0.75f * te0 + 0.75f * to0 + 0.25f * te1;
-        h1 = 0.25f * te0 + 0.75f * to0 + 0.75f * te1 + 0.25f * to1;
-    };
-    float e0h0, e0h1, e1h0, e1h1;          // even T rows Y, Y+1
-    float om1h0, om1h1, o0h0, o0h1, o1h0, o1h1;  // odd T rows Y-1, Y, Y+1
-    {
-        const float a0 = ld(p.t_ee, p.slab_ee, H + 1, W + 1, Y, X);
-        const float a1 = ld(p.t_ee, p.slab_ee, H + 1, W + 1, Y, X + 1);
-        const float bm = ld(p.t_eo, p.slab_eo, H + 1, W, Y, X - 1);
-        const float b0 = ld(p.t_eo, p.slab_eo, H + 1, W, Y, X);
-        const float b1 = ld(p.t_eo, p.slab_eo, H + 1, W, Y, X + 1);
-        hpass(a0, a1, bm, b0, b1, e0h0, e0h1);
+    // horizontal pass of one T row held as even columns e[0..4] = Te[X..X+4] and odd columns
+    // o[0..5] = To[X-1..X+4]: h[2i] = out col 2(X+i), h[2i+1] = out col 2(X+i)+1
+    float hrow[5][8];  // T rows: O[Y-1], E[Y], O[Y], E[Y+1], O[Y+1]
+#pragma unroll
+    for (int r = 0; r < 5; ++r) {
+        const bool odd_row = (r & 1) == 0;        // rows 0,2,4 are odd T rows
+        const int yy = Y + (r >> 1) + (odd_row ? 0 : 1);  // padded row: O[Y-1]->Y, E[Y]->Y+1, O[Y]->Y+1, E[Y+1]->Y+2, O[Y+1]->Y+2
+        const float* te = (odd_row ? p.t + 2 * p.cls_stride : p.t) + c * plane + (size_t)yy * TPW + X + 4;
+        const float* to = te + p.cls_stride;  // class + 1 = odd columns of the same row parity
+        float e[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+        float o[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        for (int sp = 0; sp < p.nsplit; ++sp) {
+            const size_t u = (size_t)(sp * p.B + b) * p.unit_stride;
+            const float4 e4 = *reinterpret_cast<const float4*>(te + u);
+            const float4 o4 = *reinterpret_cast<const float4*>(to + u);
+            e[0] += e4.x; e[1] += e4.y; e[2] += e4.z; e[3] += e4.w;
+            e[4] += te[u + 4];
+            o[0] += to[u - 1];
+            o[1] += o4.x; o[2] += o4.y; o[3] += o4.z; o[4] += o4.w;
+            o[5] += to[u + 4];
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            hrow[r][2 * i] = 0.25f * o[i] + 0.75f * e[i] + 0.75f * o[i + 1] + 0.25f * e[i + 1];
+            hrow[r][2 * i + 1] = 0.25f * e[i] + 0.75f * o[i + 1] + 0.75f * e[i + 1] + 0.25f * o[i + 2];
+        }
     }
-    {
-        const float a0 = ld(p.t_ee, p.slab_ee, H + 1, W + 1, Y + 1, X);
-        const float a1 = ld(p.t_ee, p.slab_ee, H + 1, W + 1, Y + 1, X + 1);
-        const float bm = ld(p.t_eo, p.slab_eo, H + 1, W, Y + 1, X - 1);
-        const float b0 = ld(p.t_eo, p.slab_eo, H + 1, W, Y + 1, X);
-        const float b1 = ld(p.t_eo, p.slab_eo, H + 1, W, Y + 1, X + 1);
-        hpass(a0, a1, bm, b0, b1, e1h0, e1h1);
-    }
-#define GANCE_ODD_ROW(yy, h0, h1)                                            \
-    {                                                                        \
-        const float a0 = ld(p.t_oe, p.slab_oe, H, W + 1, (yy), X);           \
-        const float a1 = ld(p.t_oe, p.slab_oe, H, W + 1, (yy), X + 1);       \
-        const float bm = ld(p.t_oo, p.slab_oo, H, W, (yy), X - 1);           \
-        const float b0 = ld(p.t_oo, p.slab_oo, H, W, (yy), X);               \
-        const float b1 = ld(p.t_oo, p.slab_oo, H, W, (yy), X + 1);           \
-        hpass(a0, a1, bm, b0, b1, h0, h1);                                   \
-    }
-    GANCE_ODD_ROW(Y - 1, om1h0, om1h1)
-    GANCE_ODD_ROW(Y, o0h0, o0h1)
-    GANCE_ODD_ROW(Y + 1, o1h0, o1h1)
-#undef GANCE_ODD_ROW
-
-    float r00 = 0.25f * om1h0 + 0.75f * e0h0 + 0.75f * o0h0 + 0.25f * e1h0;  // (2Y,   2X)
-    float r01 = 0.25f * om1h1 + 0.75f * e0h1 + 0.75f * o0h1 + 0.25f * e1h1;  // (2Y,   2X+1)
-    float r10 = 0.25f * e0h0 + 0.75f * o0h0 + 0.75f * e1h0 + 0.25f * o1h0;   // (2Y+1, 2X)
-    float r11 = 0.25f * e0h1 + 0.75f * o0h1 + 0.75f * e1h1 + 0.25f * o1h1;   // (2Y+1, 2X+1)
-
-    const int OW = 2 * W;
-    const size_t o0 = (size_t)(2 * Y) * OW + 2 * X;
-    if (p.noise != nullptr) {
-        const float ns = p.noise_strength;
-        r00 += p.noise[o0] * ns;
-        r01 += p.noise[o0 + 1] * ns;
-        r10 += p.noise[o0 + OW] * ns;
-        r11 += p.noise[o0 + OW + 1] * ns;
-    }
+    const int OW = 2 * p.W;
     const float bs = p.bias[c];
-    float* op = p.out + bc * (size_t)(4 * H * W) + o0;
-    *reinterpret_cast<float2*>(op) = make_float2(lrelu_gain(r00 + bs), lrelu_gain(r01 + bs));
-    *reinterpret_cast<float2*>(op + OW) = make_float2(lrelu_gain(r10 + bs), lrelu_gain(r11 + bs));
+    float r0[8], r1[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        r0[i] = 0.25f * hrow[0][i] + 0.75f * hrow[1][i] + 0.75f * hrow[2][i] + 0.25f * hrow[3][i];
+        r1[i] = 0.25f * hrow[1][i] + 0.75f * hrow[2][i] + 0.75f * hrow[3][i] + 0.25f * hrow[4][i];
+    }
+    if (p.noise != nullptr) {
+        const float* nz = p.noise + (size_t)(2 * Y) * OW + 2 * X;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            r0[i] += nz[i] * p.noise_strength;
+            r1[i] += nz[OW + i] * p.noise_strength;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        r0[i] = lrelu_gain(r0[i] + bs);
+        r1[i] = lrelu_gain(r1[i] + bs);
+    }
+    // zero-bordered activation [B][C][2H+2][2W+4], interior at [y+1][x+1]
+    const int OWp = OW + 4;
+    float* op = p.out + (bc * (size_t)(2 * p.H + 2) + (2 * Y + 1)) * OWp + 2 * X + 1;
+    *reinterpret_cast<float4u*>(op) = float4u{r0[0], r0[1], r0[2], r0[3]};
+    *reinterpret_cast<float4u*>(op + 4) = float4u{r0[4], r0[5], r0[6], r0[7]};
+    *reinterpret_cast<float4u*>(op + OWp) = float4u{r1[0], r1[1], r1[2], r1[3]};
+    *reinterpret_cast<float4u*>(op + OWp + 4) = float4u{r1[4], r1[5], r1[6], r1[7]};
 }
 
 hipError_t launch_fir_epilogue(const FirArgs& args, hipStream_t stream) {
-    const size_t total = (size_t)args.B * args.C * args.H * args.W;
+    const size_t total = (size_t)args.B * args.C * args.H * (args.W / 4);
     hipLaunchKernelGGL(fir_epilogue_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
                        stream, args);
     return hipGetLastError();
 }
 
 // ------------------------------------------------------------------------------------------
-// Split-K finish
+// Split-K finish (small layers only): slabs [nsplit][B][C][H][W] -> zero-bordered activation
 // ------------------------------------------------------------------------------------------
 
 __global__ __launch_bounds__(256) void splitk_finish_kernel(const float* __restrict__ slabs,
@@ -284,35 +285,27 @@ __global__ __launch_bounds__(256) void splitk_finish_kernel(const float* __restr
                                                             const float* __restrict__ noise,
                                                             float noise_strength,
                                                             const float* __restrict__ bias,
-                                                            float* __restrict__ out, int C,
-                                                            int HW, size_t total4) {
-    const size_t i4 = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (i4 >= total4) return;
-    const size_t i = i4 * 4;
-    float4 v = *reinterpret_cast<const float4*>(slabs + i);
-    for (int sp = 1; sp < nsplit; ++sp) {
-        const float4 u = *reinterpret_cast<const float4*>(slabs + (size_t)sp * slab_stride + i);
-        v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
-    }
-    const int pix = (int)(i % HW);
-    const int c = (int)((i / HW) % C);
-    if (noise != nullptr) {
-        const float4 nz = *reinterpret_cast<const float4*>(noise + pix);
-        v.x += nz.x * noise_strength; v.y += nz.y * noise_strength;
-        v.z += nz.z * noise_strength; v.w += nz.w * noise_strength;
-    }
-    const float bs = bias[c];
-    *reinterpret_cast<float4*>(out + i) = make_float4(lrelu_gain(v.x + bs), lrelu_gain(v.y + bs),
-                                                      lrelu_gain(v.z + bs), lrelu_gain(v.w + bs));
+                                                            float* __restrict__ out, int C, int H,
+                                                            int W, size_t total) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    float v = slabs[i];
+    for (int sp = 1; sp < nsplit; ++sp) v += slabs[(size_t)sp * slab_stride + i];
+    const int x = (int)(i % W);
+    const int y = (int)((i / W) % H);
+    const size_t bc = i / ((size_t)W * H);
+    const int c = (int)(bc % C);
+    if (noise != nullptr) v += noise[(size_t)y * W + x] * noise_strength;
+    out[(bc * (H + 2) + y + 1) * (size_t)(W + 4) + x + 1] = lrelu_gain(v + bias[c]);
 }
 
 hipError_t launch_splitk_finish(const float* slabs, long long slab_stride, int nsplit,
                                 const float* noise, float noise_strength, const float* bias,
                                 float* out, int B, int C, int H, int W, hipStream_t stream) {
-    const size_t total4 = (size_t)B * C * H * W / 4;
-    hipLaunchKernelGGL(splitk_finish_kernel, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0,
-                       stream, slabs, slab_stride, nsplit, noise, noise_strength, bias, out, C,
-                       H * W, total4);
+    const size_t total = (size_t)B * C * H * W;
+    hipLaunchKernelGGL(splitk_finish_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+                       stream, slabs, slab_stride, nsplit, noise, noise_strength, bias, out, C, H,
+                       W, total);
     return hipGetLastError();
 }
 
@@ -320,6 +313,7 @@ hipError_t launch_splitk_finish(const float* slabs, long long slab_stride, int n
 // ToRGB + skip upsample (+ uint8 NHWC)
 // ------------------------------------------------------------------------------------------
 // y[b,c,p] = sum_ci x[b,ci,p] * (s[b,ci] * w[ci,c]) + bias[c] + upsample_2d(y_prev)[b,c,p]
+// x is the zero-bordered activation [B][Cin][R+2][R+4]; y is dense [B][3][R][R].
 // upsample_2d = zero-insert x2, pad (2,1), FIR [1,3,3,1]x[1,3,3,1]/16: per axis
 //   even o=2Y:  1/4 y[Y-1] + 3/4 y[Y] ;  odd o=2Y+1:  3/4 y[Y] + 1/4 y[Y+1]   (zero outside).
 // uint8: tf.saturate_cast(x * 127.5 + 128): separate multiply and add, clamp, truncate.
@@ -335,16 +329,19 @@ __global__ __launch_bounds__(256) void torgb_kernel(const ToRgbArgs p) {
     const size_t npix = (size_t)R * R;
     const size_t p4 = ((size_t)blockIdx.x * 256 + tid) * 4;
     if (p4 >= npix) return;
+    const int oy = (int)(p4 / R);
+    const int ox0 = (int)(p4 % R);
+    const size_t xplane = (size_t)(R + 2) * (R + 4);
 
     float acc[3][4];
 #pragma unroll
     for (int c = 0; c < 3; ++c)
 #pragma unroll
         for (int k = 0; k < 4; ++k) acc[c][k] = 0.f;
-    const float* xp = p.x + (size_t)b * p.Cin * npix + p4;
+    const float* xp = p.x + (size_t)b * p.Cin * xplane + (size_t)(oy + 1) * (R + 4) + ox0 + 1;
 #pragma unroll 4
     for (int ci = 0; ci < p.Cin; ++ci) {
-        const float4 v = *reinterpret_cast<const float4*>(xp + (size_t)ci * npix);
+        const float4u v = *reinterpret_cast<const float4u*>(xp + (size_t)ci * xplane);
         const float c0 = coef[ci * 3 + 0], c1 = coef[ci * 3 + 1], c2 = coef[ci * 3 + 2];
         acc[0][0] = fmaf(v.x, c0, acc[0][0]); acc[0][1] = fmaf(v.y, c0, acc[0][1]);
         acc[0][2] = fmaf(v.z, c0, acc[0][2]); acc[0][3] = fmaf(v.w, c0, acc[0][3]);
@@ -354,8 +351,6 @@ __global__ __launch_bounds__(256) void torgb_kernel(const ToRgbArgs p) {
         acc[2][2] = fmaf(v.z, c2, acc[2][2]); acc[2][3] = fmaf(v.w, c2, acc[2][3]);
     }
 
-    const int oy = (int)(p4 / R);
-    const int ox0 = (int)(p4 % R);
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
         const float bs = p.bias[c];

@@ -6,22 +6,25 @@
 // (SURVEY.md §8 a18).
 //
 // Formulation (not the reference's): weights are shared by the whole batch,
-//     out[b,co,p] = d[b,co] * sum_{tap,ci} w[tap,ci,co] * ( s[b,ci] * x[b,ci,p+tap] )
-// i.e. GEMM  D[M = co][N = pixel] = A[M][K] * B[K][N],  K = taps x Cin, with the style scale s
-// applied while the input patch is staged into LDS and the demodulation d applied in the
-// epilogue. M = output channel is on the accumulator ROWS so that one accumulator register of a
-// wave is 32 consecutive pixels of one channel plane: every global store is a full 128-B segment.
+//     out[b,co,p] = d[b,co] * sum_{tap,ci} ( w[tap,ci,co] * s[b,ci] ) * x[b,ci,p+tap]
+// i.e. GEMM  D[M = co][N = pixel] = A[M][K] * B[K][N],  K = taps x Cin. The style scale s is
+// applied to the operand fragment in registers and the demodulation d in the epilogue. M = output
+// channel is on the accumulator ROWS so that one accumulator register of a wave is 32 consecutive
+// pixels of one channel plane: every global store is a full 128-B segment.
 //
-// The same kernel computes the stride-2 transposed convolution of the Conv0_up layers, one launch
-// per output-parity class (even/even: 4 taps, even/odd and odd/even: 2 taps, odd/odd: 1 tap): a
-// class is a small stride-1 convolution from the H x W input grid to one parity plane of the
-// (2H+1) x (2W+1) intermediate, so no multiply touches an inserted zero.
+// UP = true is the stride-2 transposed convolution of the Conv0_up layers: one block computes, for
+// a tile of INPUT-grid positions (y', x'), all four output-parity classes T[2y'+py][2x'+px]
+// (even/even 4 taps, even/odd and odd/even 2 taps, odd/odd 1 tap = the 9 filter taps, each used
+// exactly once), so no multiply touches an inserted zero and the input patch is staged once.
 //
-// Block = 256 threads = 4 waves. Per K-chunk of KC input channels the block stages
-//   Wl[tap][KC][BM]              (float4 global loads, co contiguous)
-//   Pl[TB][KC][TH+2][TW+2]       (the haloed input patch, scaled by s, zero outside the image)
-// into LDS and every wave runs taps x KC/2 MFMA steps on its MT x NT grid of 32x32 accumulators.
-// Operand fetches are conflict-free ds_read_b32: 32 consecutive co for A, 32 consecutive x for B.
+// Data layout in HBM: activations are zero-bordered  [B][C][H+2][W+4]  (interior at [y+1][x+1]),
+// so a tile's haloed patch is a set of 16-B aligned row segments that need no bounds logic and
+// can be copied by LDS-DMA. Weights are pre-arranged per (m tile, K chunk) as the exact LDS image
+// [tap][KC][BM], so their staging is a linear copy.
+//
+// Pipeline: 2 LDS buffers; `global_load_lds_dwordx4` for chunk k+1 is in flight while the MFMAs
+// of chunk k run; one __syncthreads per chunk (hipcc drains vmcnt there). All LDS is one dynamic
+// array; no ordinary global load sits inside the K loop.
 
 #include <hip/hip_runtime.h>
 
@@ -30,31 +33,79 @@
 namespace gance {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef const __attribute__((address_space(1))) void* glb_ptr_t;
 
-template <int BM, int TB, int TH, int TW, int KC, int WM, int WN>
+// ---- static tap tables -------------------------------------------------------------------
+// regular conv: tap t = ky*3+kx reads input (y+ky-1, x+kx-1), one class.
+// transposed conv: 9 (class, dy, dx) entries in the order the weights are stored (engine.hip
+// `kUpTapWeight`): EE (0,0) (0,-1) (-1,0) (-1,-1) | EO (0,0) (-1,0) | OE (0,0) (0,-1) | OO (0,0).
+template <bool UP>
+__host__ __device__ constexpr int tap_cls(int t) {
+    if (!UP) return 0;
+    return t < 4 ? 0 : (t < 6 ? 1 : (t < 8 ? 2 : 3));
+}
+template <bool UP>
+__host__ __device__ constexpr int tap_dy(int t) {
+    if (!UP) return t / 3 - 1;
+    return (t == 2 || t == 3 || t == 5) ? -1 : 0;
+}
+template <bool UP>
+__host__ __device__ constexpr int tap_dx(int t) {
+    if (!UP) return t % 3 - 1;
+    return (t == 1 || t == 3 || t == 7) ? -1 : 0;
+}
+// index of the distinct (dy,dx) shift a tap reads (B fragments are shared between taps)
+template <bool UP>
+__host__ __device__ constexpr int tap_shift(int t) {
+    if (!UP) return t;
+    return (tap_dy<true>(t) == -1 ? 2 : 0) + (tap_dx<true>(t) == -1 ? 1 : 0);
+}
+template <bool UP>
+__host__ __device__ constexpr int shift_dy(int s) {
+    return UP ? ((s & 2) ? -1 : 0) : s / 3 - 1;
+}
+template <bool UP>
+__host__ __device__ constexpr int shift_dx(int s) {
+    return UP ? ((s & 1) ? -1 : 0) : s % 3 - 1;
+}
+
+template <int BM, int TB, int TH, int TW, int KC, int WM, int WN, bool UP>
 struct ConvTile {
     static constexpr int kBN = TB * TH * TW;
     static constexpr int kMT = BM / (32 * WM);
     static constexpr int kNT = kBN / (32 * WN);
-    static constexpr int kPH = TH + 2;
-    static constexpr int kPW = TW + 2;
+    static constexpr int kCls = UP ? 4 : 1;
+    static constexpr int kShifts = UP ? 4 : 9;
+    static constexpr int kPH = UP ? TH + 1 : TH + 2;
+    static constexpr int kPW = TW + 4;
     static constexpr int kPlane = kPH * kPW;
-    static constexpr int kWlFloats = kMaxTaps * KC * BM;
+    static constexpr int kWlFloats = 9 * KC * BM;
     static constexpr int kPlFloats = TB * KC * kPlane;
-    static constexpr size_t kLdsBytes = (size_t)(kWlFloats + kPlFloats) * sizeof(float);
+    static constexpr int kWlInstr = kWlFloats / 256;              // 1 KiB DMA pieces
+    static constexpr int kPlF4 = kPlFloats / 4;
+    static constexpr int kPlInstr = (kPlF4 + 63) / 64;
+    static constexpr int kBufFloats = kWlFloats + kPlInstr * 256;  // patch region padded to pieces
     static_assert(WM * WN == 4, "4 waves per block");
     static_assert(BM % (32 * WM) == 0 && kBN % (32 * WN) == 0, "wave tiling");
-    static_assert(KC % 2 == 0, "k pairs");
+    static_assert(KC % 2 == 0 && kWlFloats % 256 == 0 && kPlFloats % 4 == 0, "DMA pieces");
+    // dynamic LDS: 2 staging buffers + style [TB][Cin] + demod [TB][BM] + bias [BM]
+    static size_t lds_bytes(int cin) {
+        return sizeof(float) * (2 * (size_t)kBufFloats + (size_t)TB * cin + (size_t)TB * BM + BM);
+    }
 };
 
-template <int BM, int TB, int TH, int TW, int KC, int WM, int WN>
-__global__ __launch_bounds__(256) void modconv_mfma_kernel(const ConvArgs p) {
-    using T = ConvTile<BM, TB, TH, TW, KC, WM, WN>;
-    constexpr int MT = T::kMT, NT = T::kNT, PW = T::kPW, PLANE = T::kPlane;
+template <int BM, int TB, int TH, int TW, int KC, int WM, int WN, bool UP>
+__global__ __launch_bounds__(256, UP ? 2 : 3) void modconv_mfma_kernel(const ConvArgs p) {
+    using T = ConvTile<BM, TB, TH, TW, KC, WM, WN, UP>;
+    constexpr int MT = T::kMT, NT = T::kNT, PH = T::kPH, PW = T::kPW, PLANE = T::kPlane;
+    constexpr int NCLS = T::kCls;
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* Wl = smem;                 // [tap][KC][BM]
-    float* Pl = smem + T::kWlFloats;  // [TB][KC][PH][PW]
+    float* const buf0 = smem;
+    float* const s_lds = smem + 2 * T::kBufFloats;  // [TB][Cin]
+    float* const d_lds = s_lds + TB * p.Cin;        // [TB][BM]
+    float* const b_lds = d_lds + TB * BM;           // [BM]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -64,8 +115,14 @@ __global__ __launch_bounds__(256) void modconv_mfma_kernel(const ConvArgs p) {
     const int l31 = lane & 31;
     const int lh = lane >> 5;
 
-    // ---- block -> (m tile, k split, pixel tile) ----
-    int id = blockIdx.x;
+    // ---- XCD-aware block remap: blocks that share an XCD (bid % 8) get a contiguous id range,
+    // so the m tiles of one pixel tile and neighbouring pixel tiles hit the same L2 ----
+    int id;
+    {
+        const int nwg = gridDim.x, bid = blockIdx.x;
+        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+        id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    }
     const int m_tile = id % p.m_tiles;
     id /= p.m_tiles;
     const int split = id % p.nsplit;
@@ -79,9 +136,55 @@ __global__ __launch_bounds__(256) void modconv_mfma_kernel(const ConvArgs p) {
     const int b0 = tile_b * TB;
     const int y0 = tile_y * TH;
     const int x0 = tile_x * TW;
+    const int Hp = p.H + 2, Wp = p.W + 4;
 
-    // ---- per-lane B-operand base offsets (one per N tile of the wave) ----
+    // ---- one-time staging of style, demod and bias (ordinary loads, before any DMA) ----
+    for (int i = tid; i < TB * p.Cin; i += 256) {
+        const int tb = i / p.Cin, ci = i - tb * p.Cin;
+        const int b = min(b0 + tb, p.B - 1);
+        s_lds[i] = p.s[(size_t)b * p.s_stride + ci];
+    }
+    for (int i = tid; i < TB * BM; i += 256) {
+        const int tb = i / BM, m = i - tb * BM;
+        const int b = min(b0 + tb, p.B - 1);
+        d_lds[i] = p.d[(size_t)b * p.d_stride + m0 + m];
+    }
+    for (int i = tid; i < BM; i += 256) b_lds[i] = p.bias[m0 + i];
+
+    // ---- DMA descriptors that do not change with the chunk ----
+    // patch piece i of this wave: float4 index f = i*64 + lane -> (tb, c, py, q)
+    const float* wsrc_base = p.w + ((size_t)m_tile * p.total_chunks) * T::kWlFloats;
+    auto stage = [&](int chunk, float* buf) {
+        const float* wsrc = wsrc_base + (size_t)chunk * T::kWlFloats;
+        for (int i = wave; i < T::kWlInstr; i += 4) {
+            __builtin_amdgcn_global_load_lds((glb_ptr_t)(wsrc + i * 256 + lane * 4),
+                                             (lds_ptr_t)(buf + i * 256), 16, 0, 0);
+        }
+        float* pl = buf + T::kWlFloats;
+        const int ci0 = chunk * KC;
+        for (int i = wave; i < T::kPlInstr; i += 4) {
+            const int f = i * 64 + lane;
+            if (f < T::kPlF4) {
+                const int q = f % (PW / 4);
+                int r = f / (PW / 4);
+                const int py = r % PH;
+                r /= PH;
+                const int c = r % KC;
+                const int tb = r / KC;
+                const int b = min(b0 + tb, p.B - 1);
+                const int gy = min(y0 + py, Hp - 1);
+                const int gx = min(x0 + 4 * q, Wp - 4);
+                const float* src = p.x + (size_t)b * p.x_b_stride +
+                                   ((size_t)(ci0 + c) * Hp + gy) * Wp + gx;
+                __builtin_amdgcn_global_load_lds((glb_ptr_t)src, (lds_ptr_t)(pl + i * 256), 16, 0,
+                                                 0);
+            }
+        }
+    };
+
+    // ---- per-lane operand offsets ----
     int boff[NT];
+    int stb[NT];
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
         const int n = (wn * NT + j) * 32 + l31;
@@ -89,78 +192,97 @@ __global__ __launch_bounds__(256) void modconv_mfma_kernel(const ConvArgs p) {
         const int yy = (n / TW) % TH;
         const int xx = n % TW;
         boff[j] = (tb * KC + lh) * PLANE + (yy + 1) * PW + (xx + 1);
+        stb[j] = tb * p.Cin + lh;
     }
     const int aoff = lh * BM + wm * (MT * 32) + l31;
 
-    f32x16 acc[MT][NT];
+    f32x16 acc[NCLS][MT][NT];
 #pragma unroll
-    for (int i = 0; i < MT; ++i)
+    for (int c = 0; c < NCLS; ++c)
 #pragma unroll
-        for (int j = 0; j < NT; ++j)
+        for (int i = 0; i < MT; ++i)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+            for (int j = 0; j < NT; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[c][i][j][r] = 0.f;
 
     const int chunk_begin = split * p.chunks_per_split;
-    const int chunk_end = chunk_begin + p.chunks_per_split;
-    const size_t in_plane = (size_t)p.H * p.W;
+    const int nchunks = p.chunks_per_split;
 
-    for (int chunk = chunk_begin; chunk < chunk_end; ++chunk) {
-        const int ci0 = chunk * KC;
-        __syncthreads();  // the previous chunk's MFMAs have read Wl / Pl
+    stage(chunk_begin, buf0);
+    for (int k = 0; k < nchunks; ++k) {
+        __syncthreads();  // DMA of chunk k has landed (vmcnt drained); chunk k-1 fully consumed
+        float* const cur = buf0 + (k & 1) * T::kBufFloats;
+        if (k + 1 < nchunks) stage(chunk_begin + k + 1, buf0 + ((k + 1) & 1) * T::kBufFloats);
+        const float* Wl = cur + aoff;
+        const float* Pl = cur + T::kWlFloats;
+        const int ci0 = (chunk_begin + k) * KC;
 
-        // ---- stage weights: Wl[t][c][m] = w[tap_w[t]][ci0 + c][m0 + m] ----
-        for (int t = 0; t < p.ntaps; ++t) {
-            const float* wsrc = p.w + ((size_t)p.tap_w[t] * p.Cin + ci0) * p.Cout + m0;
-            for (int v = tid; v < KC * BM / 4; v += 256) {
-                const int c = v / (BM / 4);
-                const int m4 = v % (BM / 4);
-                const float4 val =
-                    *reinterpret_cast<const float4*>(wsrc + (size_t)c * p.Cout + m4 * 4);
-                *reinterpret_cast<float4*>(&Wl[(t * KC + c) * BM + m4 * 4]) = val;
+        // Flattened steps u = kk*9 + tap, fully unrolled. The operand fragments of step u+1 are
+        // read from LDS BEFORE the MFMAs of step u are issued (sched_barrier pins that order), so
+        // the matrix pipe never waits on an LDS round trip: one wave alone keeps it busy.
+        // A group = the MT weight fragments of one (kk, tap). B group = the NT patch fragments of
+        // one (kk, shift): a stride-1 conv has one shift per tap, the transposed conv re-uses its
+        // 4 shifts across the 9 taps of a kk, so its B fragments are read once per kk.
+        constexpr int U = 9 * (KC / 2);
+        constexpr int BG = UP ? 4 : 1;
+        float afrag[2][MT];
+        float bfrag[2][BG][NT];
+        float sfrag[2];
+        auto load_a = [&](int u, float (&dst)[MT], float& sdst) {
+            const int kk = u / 9, t = u % 9;
+            // the style scale is read here but multiplied in at the USE step, so that nothing
+            // between two MFMA groups depends on an LDS read issued in the same step
+            sdst = (TB == 1) ? s_lds[lh + ci0 + 2 * kk] : 1.f;
+#pragma unroll
+            for (int i = 0; i < MT; ++i) dst[i] = Wl[(t * KC + 2 * kk) * BM + i * 32];
+        };
+        auto load_b = [&](int kk, int shift, float (&dst)[NT]) {
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                dst[j] = Pl[boff[j] + (2 * kk) * PLANE + shift_dy<UP>(shift) * PW + shift_dx<UP>(shift)];
+                if (TB > 1) dst[j] *= s_lds[stb[j] + ci0 + 2 * kk];
             }
+        };
+        load_a(0, afrag[0], sfrag[0]);
+        if (UP) {
+#pragma unroll
+            for (int sh = 0; sh < 4; ++sh) load_b(0, sh, bfrag[0][sh]);
+        } else {
+            load_b(0, 0, bfrag[0][0]);
         }
-        // ---- stage the haloed input patch, scaled by the style ----
-        for (int e = tid; e < T::kPlFloats; e += 256) {
-            const int px = e % PW;
-            const int py = (e / PW) % T::kPH;
-            const int c = (e / PLANE) % KC;
-            const int tb = e / (PLANE * KC);
-            const int b = b0 + tb;
-            const int gy = y0 + py - 1;
-            const int gx = x0 + px - 1;
-            float val = 0.f;
-            if (b < p.B && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W) {
-                const int ci = ci0 + c;
-                val = p.x[(size_t)b * p.x_b_stride + (size_t)ci * in_plane + (size_t)gy * p.W + gx] *
-                      p.s[(size_t)b * p.s_stride + ci];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int kk = u / 9, t = u % 9;
+            if (u + 1 < U) {
+                load_a(u + 1, afrag[(u + 1) & 1], sfrag[(u + 1) & 1]);
+                if (UP) {
+                    if (t == 8) {
+#pragma unroll
+                        for (int sh = 0; sh < 4; ++sh) load_b(kk + 1, sh, bfrag[(kk + 1) & 1][sh]);
+                    }
+                } else {
+                    load_b((u + 1) / 9, (u + 1) % 9, bfrag[(u + 1) & 1][0]);
+                }
             }
-            Pl[e] = val;
-        }
-        __syncthreads();
-
-        // ---- taps x KC/2 MFMA steps ----
-        for (int t = 0; t < p.ntaps; ++t) {
-            const int toff = p.tap_dy[t] * PW + p.tap_dx[t];
-            const float* wl_t = Wl + t * (KC * BM) + aoff;
+            __builtin_amdgcn_sched_barrier(0);
+            const int bsel = UP ? (kk & 1) : (u & 1);
+            const int bgrp = UP ? tap_shift<UP>(t) : 0;
+            float a[MT];
 #pragma unroll
-            for (int kk = 0; kk < KC / 2; ++kk) {
-                float a[MT], bv[NT];
+            for (int i = 0; i < MT; ++i) a[i] = (TB == 1) ? afrag[u & 1][i] * sfrag[u & 1] : afrag[u & 1][i];
 #pragma unroll
-                for (int i = 0; i < MT; ++i) a[i] = wl_t[(2 * kk) * BM + i * 32];
+            for (int i = 0; i < MT; ++i)
 #pragma unroll
-                for (int j = 0; j < NT; ++j) bv[j] = Pl[boff[j] + toff + (2 * kk) * PLANE];
-#pragma unroll
-                for (int i = 0; i < MT; ++i)
-#pragma unroll
-                    for (int j = 0; j < NT; ++j)
-                        acc[i][j] =
-                            __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], bv[j], acc[i][j], 0, 0, 0);
-            }
+                for (int j = 0; j < NT; ++j)
+                    acc[tap_cls<UP>(t)][i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(
+                        a[i], bfrag[bsel][bgrp][j], acc[tap_cls<UP>(t)][i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
 
     // ---- epilogue: demodulate, (noise, bias, leaky relu), store 32 consecutive pixels per reg ----
-    float* out = p.out + (size_t)split * p.slab_stride;
+    float* const out = p.out + (size_t)split * p.slab_stride;
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
         const int n = (wn * NT + j) * 32 + l31;
@@ -168,61 +290,78 @@ __global__ __launch_bounds__(256) void modconv_mfma_kernel(const ConvArgs p) {
         const int oy = y0 + (n / TW) % TH;
         const int ox = x0 + n % TW;
         const int b = b0 + tb;
-        if (b >= p.B || oy >= p.OH || ox >= p.OW) continue;
+        const bool in_batch = b < p.B;
         float nz = 0.f;
-        if (p.epilogue == kEpilogueFull && p.noise != nullptr)
+        if (!UP && p.epilogue == kEpilogueFull && p.noise != nullptr && in_batch && oy < p.OH &&
+            ox < p.OW)
             nz = p.noise[(size_t)oy * p.OW + ox] * p.noise_strength;
-        float* out_px = out + (size_t)b * p.out_b_stride + (size_t)oy * p.out_row_stride + ox;
+        float* const out_px = out + (size_t)b * p.out_b_stride +
+                              (size_t)(oy + p.out_y_off) * p.out_row_stride + ox + p.out_x_off;
 #pragma unroll
-        for (int i = 0; i < MT; ++i) {
+        for (int c = 0; c < NCLS; ++c) {
+            // class c = (py, px): valid positions shrink by one where the parity is odd
+            const bool ok = in_batch && oy < p.OH - (UP ? (c >> 1) : 0) && ox < p.OW - (UP ? (c & 1) : 0);
+            if (!ok) continue;
+            float* const out_c = out_px + (size_t)c * p.cls_stride;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int co = m0 + wm * (MT * 32) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                float v = acc[i][j][r] * p.d[(size_t)b * p.d_stride + co];
-                if (p.epilogue == kEpilogueFull) {
-                    v += nz + p.bias[co];
-                    v = (v < 0.f ? 0.2f * v : v) * 1.4142135623730951f;
+            for (int i = 0; i < MT; ++i) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = wm * (MT * 32) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    float v = acc[c][i][j][r] * d_lds[tb * BM + m];
+                    if (!UP && p.epilogue == kEpilogueFull) {
+                        v += nz + b_lds[m];
+                        v = (v < 0.f ? 0.2f * v : v) * 1.4142135623730951f;
+                    }
+                    out_c[(size_t)(m0 + m) * p.out_c_stride] = v;
                 }
-                out_px[(size_t)co * p.out_c_stride] = v;
             }
         }
     }
 }
 
-template <int BM, int TB, int TH, int TW, int KC, int WM, int WN>
+template <int BM, int TB, int TH, int TW, int KC, int WM, int WN, bool UP>
 static hipError_t launch_one(const ConvArgs& a, int total_blocks, hipStream_t stream) {
-    using T = ConvTile<BM, TB, TH, TW, KC, WM, WN>;
-    auto kernel = modconv_mfma_kernel<BM, TB, TH, TW, KC, WM, WN>;
+    using T = ConvTile<BM, TB, TH, TW, KC, WM, WN, UP>;
+    auto kernel = modconv_mfma_kernel<BM, TB, TH, TW, KC, WM, WN, UP>;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
                                            hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           (int)T::kLdsBytes);
+                                           (int)T::lds_bytes(512));
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    hipLaunchKernelGGL(kernel, dim3(total_blocks), dim3(256), T::kLdsBytes, stream, a);
+    hipLaunchKernelGGL(kernel, dim3(total_blocks), dim3(256), T::lds_bytes(a.Cin), stream, a);
     return hipGetLastError();
 }
 
 const ConvTileInfo kConvTiles[kNumConvTiles] = {
-    // BM, TB, TH, TW, KC
-    {32, 1, 8, 64, 16},   // 0: Cout = 32  (1024^2)
-    {64, 1, 4, 64, 16},   // 1: Cout = 64  (512^2)
-    {128, 1, 4, 32, 8},   // 2: Cout >= 128, wide grids
-    {128, 1, 8, 16, 8},   // 3: 16-wide grids
-    {128, 2, 8, 8, 8},    // 4: 8-wide grids
-    {128, 8, 4, 4, 8},    // 5: 4-wide grids
+    // BM, TB, TH, TW, KC, up
+    {32, 1, 8, 64, 8, 0},   // 0: Cout = 32
+    {64, 1, 4, 64, 8, 0},   // 1: Cout = 64
+    {128, 1, 4, 32, 4, 0},  // 2: Cout >= 128, wide grids
+    {128, 1, 8, 16, 4, 0},  // 3
+    {128, 2, 8, 8, 4, 0},   // 4
+    {128, 8, 4, 4, 4, 0},   // 5
+    {32, 1, 16, 16, 8, 1},  // 6: transposed, Cout = 32
+    {64, 1, 8, 16, 8, 1},   // 7: transposed, Cout = 64
+    {128, 1, 8, 8, 4, 1},   // 8: transposed, Cout >= 128
+    {128, 1, 4, 16, 4, 1},  // 9
 };
 
 hipError_t launch_modconv(int tile_id, const ConvArgs& a, int total_blocks, hipStream_t stream) {
     switch (tile_id) {
-        case 0: return launch_one<32, 1, 8, 64, 16, 1, 4>(a, total_blocks, stream);
-        case 1: return launch_one<64, 1, 4, 64, 16, 1, 4>(a, total_blocks, stream);
-        case 2: return launch_one<128, 1, 4, 32, 8, 2, 2>(a, total_blocks, stream);
-        case 3: return launch_one<128, 1, 8, 16, 8, 2, 2>(a, total_blocks, stream);
-        case 4: return launch_one<128, 2, 8, 8, 8, 2, 2>(a, total_blocks, stream);
-        case 5: return launch_one<128, 8, 4, 4, 8, 2, 2>(a, total_blocks, stream);
+        case 0: return launch_one<32, 1, 8, 64, 8, 1, 4, false>(a, total_blocks, stream);
+        case 1: return launch_one<64, 1, 4, 64, 8, 1, 4, false>(a, total_blocks, stream);
+        case 2: return launch_one<128, 1, 4, 32, 4, 2, 2, false>(a, total_blocks, stream);
+        case 3: return launch_one<128, 1, 8, 16, 4, 2, 2, false>(a, total_blocks, stream);
+        case 4: return launch_one<128, 2, 8, 8, 4, 2, 2, false>(a, total_blocks, stream);
+        case 5: return launch_one<128, 8, 4, 4, 4, 2, 2, false>(a, total_blocks, stream);
+        case 6: return launch_one<32, 1, 16, 16, 8, 1, 4, true>(a, total_blocks, stream);
+        case 7: return launch_one<64, 1, 8, 16, 8, 2, 2, true>(a, total_blocks, stream);
+        case 8: return launch_one<128, 1, 8, 8, 4, 4, 1, true>(a, total_blocks, stream);
+        case 9: return launch_one<128, 1, 4, 16, 4, 4, 1, true>(a, total_blocks, stream);
         default: return hipErrorInvalidValue;
     }
 }

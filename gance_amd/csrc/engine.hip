@@ -87,24 +87,26 @@ int ilog2_exact(int v) {
     return (1 << l) == v ? l : -1;
 }
 
-// One launch of the conv kernel: a stride-1 conv or one parity class of a transposed conv.
-struct ClassPlan {
+// One launch of the conv kernel: a stride-1 conv, or a transposed conv with its four parity
+// classes fused (grid of (H+1) x (W+1) input-grid positions).
+struct LayerPlan {
     int tile_id;
     int OH, OW;
-    int tiles_x, tiles_y, tiles_b, m_tiles, nsplit, chunks_per_split, total_blocks;
-    int ntaps;
-    int dy[gance::kMaxTaps], dx[gance::kMaxTaps], tw[gance::kMaxTaps];
-    size_t plane_floats;  // B * Cout * OH * OW
+    int tiles_x, tiles_y, tiles_b, m_tiles, nsplit, chunks_per_split, total_chunks, total_blocks;
 };
 
 int ceil_div(int a, int b) { return (a + b - 1) / b; }
 
-int choose_tile(int cout, int OH, int OW, int B) {
-    if (cout == 32) return 0;
-    if (cout == 64) return 1;
-    int best = 2;
+int layer_bm(int cout) { return cout == 32 ? 32 : (cout == 64 ? 64 : 128); }
+int layer_kc(int cout) { return layer_bm(cout) == 128 ? 4 : 8; }
+
+int choose_tile(int cout, bool up, int OH, int OW, int B) {
+    if (cout == 32) return up ? 6 : 0;
+    if (cout == 64) return up ? 7 : 1;
+    const int first = up ? 8 : 2, last = up ? 9 : 5;
+    int best = first;
     long best_tiles = -1;
-    for (int id = 2; id < gance::kNumConvTiles; ++id) {
+    for (int id = first; id <= last; ++id) {
         const auto& t = gance::kConvTiles[id];
         const long tiles = (long)ceil_div(B, t.TB) * ceil_div(OH, t.TH) * ceil_div(OW, t.TW);
         if (best_tiles < 0 || tiles < best_tiles) {
@@ -123,79 +125,33 @@ int choose_nsplit(int base_blocks, int chunks) {
     return chunks;
 }
 
-ClassPlan plan_class(int cin, int cout, int OH, int OW, int B, int force_nsplit) {
-    ClassPlan p{};
-    p.tile_id = choose_tile(cout, OH, OW, B);
+LayerPlan plan_layer(const ConvLayerHost& c, int B) {
+    LayerPlan p{};
+    const int res = 1 << c.res_log2;
+    p.OH = p.OW = c.up ? res / 2 + 1 : res;
+    p.tile_id = choose_tile(c.cout, c.up, p.OH, p.OW, B);
     const auto& t = gance::kConvTiles[p.tile_id];
-    p.OH = OH;
-    p.OW = OW;
-    p.tiles_x = ceil_div(OW, t.TW);
-    p.tiles_y = ceil_div(OH, t.TH);
+    p.tiles_x = ceil_div(p.OW, t.TW);
+    p.tiles_y = ceil_div(p.OH, t.TH);
     p.tiles_b = ceil_div(B, t.TB);
-    p.m_tiles = cout / t.BM;
-    const int chunks = cin / t.KC;
+    p.m_tiles = c.cout / t.BM;
+    p.total_chunks = c.cin / t.KC;
     const int base = p.m_tiles * p.tiles_x * p.tiles_y * p.tiles_b;
-    p.nsplit = force_nsplit > 0 ? force_nsplit : choose_nsplit(base, chunks);
-    p.chunks_per_split = chunks / p.nsplit;
+    p.nsplit = choose_nsplit(base, p.total_chunks);
+    if (c.up) p.nsplit = std::min(p.nsplit, 8);  // the FIR pass re-reads every slab
+    while (p.total_chunks % p.nsplit) --p.nsplit;
+    p.chunks_per_split = p.total_chunks / p.nsplit;
     p.total_blocks = base * p.nsplit;
-    p.plane_floats = (size_t)B * cout * OH * OW;
     return p;
 }
 
-struct LayerPlan {
-    int num_classes;  // 1 (stride-1 conv) or 4 (transposed conv parity classes)
-    ClassPlan cls[4];
-    int nsplit;
-    size_t t_floats;  // scratch floats needed (all slabs, all classes); 0 if written directly
-};
+// zero-bordered geometry
+size_t act_plane(int res) { return (size_t)(res + 2) * (res + 4); }       // one channel
+size_t t_plane(int h) { return (size_t)(h + 3) * (h + 8); }               // one channel, one class
 
-LayerPlan plan_layer(const ConvLayerHost& c, int B) {
-    LayerPlan lp{};
-    const int res = 1 << c.res_log2;
-    if (!c.up) {
-        lp.num_classes = 1;
-        lp.cls[0] = plan_class(c.cin, c.cout, res, res, B, 0);
-        ClassPlan& p = lp.cls[0];
-        p.ntaps = 9;
-        for (int t = 0; t < 9; ++t) {
-            p.dy[t] = t / 3 - 1;
-            p.dx[t] = t % 3 - 1;
-            p.tw[t] = t;
-        }
-        lp.nsplit = p.nsplit;
-        lp.t_floats = p.nsplit > 1 ? p.plane_floats * p.nsplit : 0;
-        return lp;
-    }
-    const int H = res / 2, W = res / 2;
-    lp.num_classes = 4;
-    // row taps of a parity: even -> (dy 0, w row 2), (dy -1, w row 0); odd -> (dy 0, w row 1)
-    const int even_d[2] = {0, -1}, even_w[2] = {2, 0};
-    const int odd_d[1] = {0}, odd_w[1] = {1};
-    int nsplit = 0;
-    for (int cls = 0; cls < 4; ++cls) {
-        const int py = cls >> 1, px = cls & 1;
-        const int OH = py ? H : H + 1, OW = px ? W : W + 1;
-        lp.cls[cls] = plan_class(c.cin, c.cout, OH, OW, B, nsplit);
-        ClassPlan& p = lp.cls[cls];
-        if (cls == 0) nsplit = p.nsplit;
-        const int ny = py ? 1 : 2, nx = px ? 1 : 2;
-        const int* yd = py ? odd_d : even_d;
-        const int* yw = py ? odd_w : even_w;
-        const int* xd = px ? odd_d : even_d;
-        const int* xw = px ? odd_w : even_w;
-        p.ntaps = 0;
-        for (int a = 0; a < ny; ++a)
-            for (int b = 0; b < nx; ++b) {
-                p.dy[p.ntaps] = yd[a];
-                p.dx[p.ntaps] = xd[b];
-                p.tw[p.ntaps] = yw[a] * 3 + xw[b];
-                ++p.ntaps;
-            }
-        lp.t_floats += p.plane_floats * p.nsplit;
-    }
-    lp.nsplit = nsplit;
-    return lp;
-}
+// weight slot t of the transposed conv reads filter tap kUpTapWeight[t] (= wy*3+wx); order must
+// match conv_mfma.hip's tap tables: EE (0,0) (0,-1) (-1,0) (-1,-1) | EO (0,0) (-1,0) | OE (0,0) (0,-1) | OO
+const int kUpTapWeight[9] = {8, 6, 2, 0, 7, 1, 5, 3, 4};
 
 struct StepRecord {
     char name[64];
@@ -230,17 +186,19 @@ struct gance_engine {
     // workspace
     float *dlat = nullptr, *map_a = nullptr, *map_b_buf = nullptr, *z_in = nullptr;
     float *styles = nullptr, *demod = nullptr;
-    float *xbuf[2] = {nullptr, nullptr};
-    float* tbuf = nullptr;
+    std::vector<float*> act;      // per conv layer: zero-bordered output [Bmax][cout][res+2][res+4]
+    std::vector<float*> tplanes;  // per up layer: [4 cls][max_units][cout][H+3][W+8] (else nullptr)
+    std::vector<int> t_units;     // max_units of that layer
+    float* slabs = nullptr;       // split-K scratch of the small stride-1 convs (dense)
     float* ybuf[2] = {nullptr, nullptr};
     uint8_t* u8buf = nullptr;  // staging for the host-buffer entry points
-    size_t x_floats = 0, t_floats = 0, y_floats = 0;
+    size_t slab_floats = 0, y_floats = 0;
 
     // profiling / debug
     std::vector<StepRecord> steps;
     int steps_used = 0;
     int debug_stop_after = 0;
-    int last_act_buf = 0, last_act_c = 0, last_act_side = 0;
+    int last_act_layer = 0, last_act_c = 0, last_act_side = 0;
     hipStream_t last_stream = nullptr;
 };
 
@@ -261,9 +219,9 @@ void free_engine(gance_engine* e) {
     hipFree(e->z_in);
     hipFree(e->styles);
     hipFree(e->demod);
-    hipFree(e->xbuf[0]);
-    hipFree(e->xbuf[1]);
-    hipFree(e->tbuf);
+    for (float* ptr : e->act) hipFree(ptr);
+    for (float* ptr : e->tplanes) hipFree(ptr);
+    hipFree(e->slabs);
     hipFree(e->ybuf[0]);
     hipFree(e->ybuf[1]);
     hipFree(e->u8buf);
@@ -295,19 +253,19 @@ struct StepScope {
     }
 };
 
-int run_conv_class(gance_engine* e, const ConvLayerHost& c, int conv_index, const ClassPlan& p,
-                   const float* x, long long x_b_stride, int H, int W, float* out,
-                   long long out_b_stride, long long out_c_stride, int out_row_stride,
-                   long long slab_stride, int epilogue, int B, hipStream_t stream,
-                   const char* name) {
+int run_conv(gance_engine* e, const ConvLayerHost& c, int li, const LayerPlan& p, const float* x,
+             long long x_b_stride, int H, int W, float* out, int epilogue, int out_row_stride,
+             int out_y_off, int out_x_off, long long out_b_stride, long long out_c_stride,
+             long long slab_stride, long long cls_stride, int B, hipStream_t stream,
+             const char* name) {
     gance::ConvArgs a{};
     a.x = x;
-    a.w = e->pool + e->conv_w[conv_index];
-    a.s = e->styles + e->conv_s_off[conv_index];
-    a.d = e->demod + e->conv_d_off[conv_index];
-    const bool has_noise = e->conv_ns[conv_index] != 0.0f;
-    a.noise = has_noise ? e->pool + e->conv_noise[conv_index] : nullptr;
-    a.bias = e->pool + e->conv_bias[conv_index];
+    a.w = e->pool + e->conv_w[li];
+    a.s = e->styles + e->conv_s_off[li];
+    a.d = e->demod + e->conv_d_off[li];
+    const bool has_noise = e->conv_ns[li] != 0.0f;
+    a.noise = has_noise ? e->pool + e->conv_noise[li] : nullptr;
+    a.bias = e->pool + e->conv_bias[li];
     a.out = out;
     a.B = B;
     a.Cin = c.cin;
@@ -318,27 +276,25 @@ int run_conv_class(gance_engine* e, const ConvLayerHost& c, int conv_index, cons
     a.OW = p.OW;
     a.s_stride = e->ctot;
     a.d_stride = e->dtot;
-    a.noise_strength = e->conv_ns[conv_index];
+    a.noise_strength = e->conv_ns[li];
     a.tiles_x = p.tiles_x;
     a.tiles_y = p.tiles_y;
     a.m_tiles = p.m_tiles;
     a.nsplit = p.nsplit;
     a.chunks_per_split = p.chunks_per_split;
+    a.total_chunks = p.total_chunks;
     a.epilogue = epilogue;
-    a.ntaps = p.ntaps;
-    for (int t = 0; t < p.ntaps; ++t) {
-        a.tap_dy[t] = p.dy[t];
-        a.tap_dx[t] = p.dx[t];
-        a.tap_w[t] = p.tw[t];
-    }
+    a.out_row_stride = out_row_stride;
+    a.out_y_off = out_y_off;
+    a.out_x_off = out_x_off;
     a.out_b_stride = out_b_stride;
     a.out_c_stride = out_c_stride;
     a.slab_stride = slab_stride;
+    a.cls_stride = cls_stride;
     a.x_b_stride = x_b_stride;
-    a.out_row_stride = out_row_stride;
-    const double flops = 2.0 * p.ntaps * (double)c.cin * c.cout * H * W * B;
-    const double bytes = 4.0 * ((double)B * c.cin * H * W + (double)p.plane_floats * p.nsplit +
-                                9.0 * c.cin * c.cout);
+    const double flops = 2.0 * 9 * (double)c.cin * c.cout * H * W * B;
+    const double out_elems = (double)B * c.cout * (c.up ? 4.0 * H * W : (double)H * W) * p.nsplit;
+    const double bytes = 4.0 * ((double)B * c.cin * H * W + out_elems + 9.0 * c.cin * c.cout);
     StepScope scope(e, stream, name, flops, bytes);
     GANCE_HIP_CHECK(gance::launch_modconv(p.tile_id, a, p.total_blocks, stream));
     return GANCE_OK;
@@ -361,72 +317,59 @@ int synthesize_from_dlat(gance_engine* e, const float* d_dlat, int B, uint8_t* d
                                             stream));
     }
 
-    int cur = 0;   // xbuf index holding the current activation
     int ycur = 0;  // ybuf index holding the current skip image
     bool have_y = false;
     const int num_convs = (int)e->convs.size();
     const int limit = e->debug_stop_after > 0 ? std::min(e->debug_stop_after, num_convs) : num_convs;
-    const float* x_in = e->pool + e->const_off;
-    long long x_b_stride = 0;  // the const input is shared by the batch
+    const float* x_in = e->pool + e->const_off;  // zero-bordered [512][6][8], shared by the batch
+    long long x_b_stride = 0;
 
     for (int li = 0; li < limit; ++li) {
         const ConvLayerHost& c = e->convs[li];
         const int res = 1 << c.res_log2;
-        const LayerPlan lp = plan_layer(c, B);
-        float* x_out = e->xbuf[(li == 0) ? 0 : 1 - cur];
+        const LayerPlan p = plan_layer(c, B);
+        float* x_out = e->act[li];
+        const long long out_c = (long long)act_plane(res);
+        const long long out_b = out_c * c.cout;
         const bool has_noise = e->conv_ns[li] != 0.0f;
         const float* noise = has_noise ? e->pool + e->conv_noise[li] : nullptr;
         const float* bias = e->pool + e->conv_bias[li];
         if (!c.up) {
-            const ClassPlan& p = lp.cls[0];
             std::snprintf(name, sizeof(name), "conv%d_%dx%d_%d->%d", c.layer_idx, res, res, c.cin,
                           c.cout);
             if (p.nsplit == 1) {
-                int rc = run_conv_class(e, c, li, p, x_in, x_b_stride, res, res, x_out,
-                                        (long long)c.cout * res * res, (long long)res * res, res,
-                                        0, gance::kEpilogueFull, B, stream, name);
+                int rc = run_conv(e, c, li, p, x_in, x_b_stride, res, res, x_out,
+                                  gance::kEpilogueFull, res + 4, 1, 1, out_b, out_c, 0, 0, B, stream,
+                                  name);
                 if (rc) return rc;
             } else {
-                int rc = run_conv_class(e, c, li, p, x_in, x_b_stride, res, res, e->tbuf,
-                                        (long long)c.cout * res * res, (long long)res * res, res,
-                                        (long long)p.plane_floats, gance::kEpilogueRaw, B, stream,
-                                        name);
+                const long long dense_c = (long long)res * res;
+                const long long slab = dense_c * c.cout * B;
+                int rc = run_conv(e, c, li, p, x_in, x_b_stride, res, res, e->slabs,
+                                  gance::kEpilogueRaw, res, 0, 0, dense_c * c.cout, dense_c, slab, 0,
+                                  B, stream, name);
                 if (rc) return rc;
                 std::snprintf(name, sizeof(name), "finish%d_%dx%d", c.layer_idx, res, res);
-                StepScope scope(e, stream, name, 0.0,
-                                4.0 * (double)p.plane_floats * (p.nsplit + 1));
-                GANCE_HIP_CHECK(gance::launch_splitk_finish(
-                    e->tbuf, (long long)p.plane_floats, p.nsplit, noise, e->conv_ns[li], bias,
-                    x_out, B, c.cout, res, res, stream));
+                StepScope scope(e, stream, name, 0.0, 4.0 * (double)slab * (p.nsplit + 1));
+                GANCE_HIP_CHECK(gance::launch_splitk_finish(e->slabs, slab, p.nsplit, noise,
+                                                            e->conv_ns[li], bias, x_out, B, c.cout,
+                                                            res, res, stream));
             }
         } else {
             const int H = res / 2, W = res / 2;
+            const long long tc = (long long)t_plane(H);
+            const long long unit = tc * c.cout;
+            const long long cls_stride = unit * e->t_units[li];
+            std::snprintf(name, sizeof(name), "convT%d_%dx%d_%d->%d", c.layer_idx, res, res, c.cin,
+                          c.cout);
+            int rc = run_conv(e, c, li, p, x_in, x_b_stride, H, W, e->tplanes[li],
+                              gance::kEpilogueRaw, W + 8, 1, 4, unit, tc, unit * B, cls_stride, B,
+                              stream, name);
+            if (rc) return rc;
             gance::FirArgs f{};
-            size_t off = 0;
-            const float* planes[4];
-            long long slabs[4];
-            for (int cls = 0; cls < 4; ++cls) {
-                const ClassPlan& p = lp.cls[cls];
-                float* plane = e->tbuf + off;
-                planes[cls] = plane;
-                slabs[cls] = (long long)p.plane_floats;
-                off += p.plane_floats * p.nsplit;
-                std::snprintf(name, sizeof(name), "convT%d_%dx%d_%d->%d_c%d", c.layer_idx, res, res,
-                              c.cin, c.cout, cls);
-                int rc = run_conv_class(e, c, li, p, x_in, x_b_stride, H, W, plane,
-                                        (long long)c.cout * p.OH * p.OW, (long long)p.OH * p.OW,
-                                        p.OW, (long long)p.plane_floats, gance::kEpilogueRaw, B,
-                                        stream, name);
-                if (rc) return rc;
-            }
-            f.t_ee = planes[0];
-            f.t_eo = planes[1];
-            f.t_oe = planes[2];
-            f.t_oo = planes[3];
-            f.slab_ee = slabs[0];
-            f.slab_eo = slabs[1];
-            f.slab_oe = slabs[2];
-            f.slab_oo = slabs[3];
+            f.t = e->tplanes[li];
+            f.cls_stride = cls_stride;
+            f.unit_stride = unit;
             f.noise = noise;
             f.bias = bias;
             f.out = x_out;
@@ -435,16 +378,15 @@ int synthesize_from_dlat(gance_engine* e, const float* d_dlat, int B, uint8_t* d
             f.C = c.cout;
             f.H = H;
             f.W = W;
-            f.nsplit = lp.nsplit;
+            f.nsplit = p.nsplit;
             std::snprintf(name, sizeof(name), "fir%d_%dx%d", c.layer_idx, res, res);
             StepScope scope(e, stream, name, 0.0,
-                            4.0 * ((double)off + (double)B * c.cout * res * res));
+                            4.0 * (double)B * c.cout * res * res * (p.nsplit + 1));
             GANCE_HIP_CHECK(gance::launch_fir_epilogue(f, stream));
         }
-        if (li > 0) cur = 1 - cur;
-        x_in = e->xbuf[cur];
-        x_b_stride = (long long)c.cout * res * res;
-        e->last_act_buf = cur;
+        x_in = x_out;
+        x_b_stride = out_b;
+        e->last_act_layer = li;
         e->last_act_c = c.cout;
         e->last_act_side = res;
 
@@ -519,8 +461,12 @@ int gance_engine_create(const gance_engine_config* config, const float* host_wei
                     "weight blob has " + std::to_string(num_floats) + " floats, expected " +
                         std::to_string(blob_floats(res_log2)));
     int device_count = 0;
-    if (hipGetDeviceCount(&device_count) != hipSuccess || device_count < 1)
-        return fail(GANCE_ERR_NO_DEVICE, "no HIP device visible; libgance_hip has no CPU path");
+    const hipError_t count_err = hipGetDeviceCount(&device_count);
+    if (count_err != hipSuccess || device_count < 1)
+        return fail(GANCE_ERR_NO_DEVICE,
+                    std::string("no HIP device visible (hipGetDeviceCount: ") +
+                        hipGetErrorString(count_err) + ", count " + std::to_string(device_count) +
+                        "); libgance_hip has no CPU path");
     if (config->device < 0 || config->device >= device_count)
         return fail(GANCE_ERR_INVALID_ARGUMENT, "device ordinal out of range");
     GANCE_HIP_CHECK(hipSetDevice(config->device));
@@ -572,8 +518,12 @@ int gance_engine_create(const gance_engine_config* config, const float* host_wei
     e->avg_off = reserve(kDlatent);
     std::memcpy(&pool[e->avg_off], src, kDlatent * sizeof(float));
     src += kDlatent;
-    e->const_off = reserve((size_t)nf(1) * 16);
-    std::memcpy(&pool[e->const_off], src, (size_t)nf(1) * 16 * sizeof(float));
+    e->const_off = reserve((size_t)nf(1) * act_plane(4));  // zero-bordered [512][6][8]
+    for (int ch = 0; ch < nf(1); ++ch)
+        for (int y = 0; y < 4; ++y)
+            for (int x = 0; x < 4; ++x)
+                pool[e->const_off + (size_t)ch * act_plane(4) + (size_t)(y + 1) * 8 + x + 1] =
+                    src[(size_t)ch * 16 + y * 4 + x];
     src += (size_t)nf(1) * 16;
 
     e->A_off = reserve((size_t)kDlatent * ctot);
@@ -593,15 +543,27 @@ int gance_engine_create(const gance_engine_config* config, const float* host_wei
         const size_t wn = (size_t)9 * c.cin * c.cout;
         const float coef = (float)(1.0 / std::sqrt(9.0 * c.cin));
         e->conv_w[i] = reserve(wn);
-        float* w = &pool[e->conv_w[i]];
-        for (size_t k = 0; k < wn; ++k) w[k] = src[k] * coef;
+        {
+            // scaled HWIO weights, re-laid-out as the kernel's LDS image:
+            // [m tile][K chunk][tap slot][KC][BM], slot t of an up layer = filter tap kUpTapWeight[t]
+            const int BM = layer_bm(c.cout), KC = layer_kc(c.cout);
+            const int m_tiles = c.cout / BM, chunks = c.cin / KC;
+            float* w = &pool[e->conv_w[i]];
+            float* w2 = &pool[e->w2_off + w2_cursor];
+            for (int mt = 0; mt < m_tiles; ++mt)
+                for (int ch = 0; ch < chunks; ++ch)
+                    for (int t = 0; t < 9; ++t) {
+                        const int tap = c.up ? kUpTapWeight[t] : t;
+                        for (int kc = 0; kc < KC; ++kc)
+                            for (int m = 0; m < BM; ++m) {
+                                const int ci = ch * KC + kc, co = mt * BM + m;
+                                const float v = src[((size_t)tap * c.cin + ci) * c.cout + co] * coef;
+                                w[((((size_t)mt * chunks + ch) * 9 + t) * KC + kc) * BM + m] = v;
+                                w2[(size_t)ci * c.cout + co] += v * v;
+                            }
+                    }
+        }
         src += wn;
-        float* w2 = &pool[e->w2_off + w2_cursor];
-        for (int tap = 0; tap < 9; ++tap)
-            for (size_t k = 0; k < (size_t)c.cin * c.cout; ++k) {
-                const float v = w[(size_t)tap * c.cin * c.cout + k];
-                w2[k] += v * v;
-            }
         demod_layers[i] = {(long long)w2_cursor, e->conv_s_off[i], e->conv_d_off[i], c.cin, c.cout};
         w2_cursor += (size_t)c.cin * c.cout;
         // mod_weight [512][cin] -> A[k][s_off + ci]
@@ -661,14 +623,20 @@ int gance_engine_create(const gance_engine_config* config, const float* host_wei
 
     // ---- workspace sizes ----
     const int Bmax = config->max_batch;
-    size_t x_per_frame = 0;
-    for (const auto& c : e->convs)
-        x_per_frame = std::max(x_per_frame, (size_t)c.cout << (2 * c.res_log2));
-    e->x_floats = x_per_frame * Bmax;
-    size_t t_max = 4;
-    for (const auto& c : e->convs)
-        for (int B = 1; B <= Bmax; ++B) t_max = std::max(t_max, plan_layer(c, B).t_floats);
-    e->t_floats = t_max;
+    e->act.assign(nconv, nullptr);
+    e->tplanes.assign(nconv, nullptr);
+    e->t_units.assign(nconv, 0);
+    size_t slab_max = 4;
+    for (int i = 0; i < nconv; ++i) {
+        const ConvLayerHost& c = e->convs[i];
+        for (int B = 1; B <= Bmax; ++B) {
+            const LayerPlan p = plan_layer(c, B);
+            if (c.up) e->t_units[i] = std::max(e->t_units[i], p.nsplit * B);
+            else if (p.nsplit > 1)
+                slab_max = std::max(slab_max, (size_t)p.nsplit * B * c.cout << (2 * c.res_log2));
+        }
+    }
+    e->slab_floats = slab_max;
     e->y_floats = (size_t)3 * config->resolution * config->resolution * Bmax;
 
 #define GANCE_CREATE_CHECK(expr)                                                            \
@@ -696,9 +664,20 @@ int gance_engine_create(const gance_engine_config* config, const float* host_wei
     GANCE_CREATE_CHECK(hipMalloc((void**)&e->z_in, (size_t)Bmax * kDlatent * sizeof(float)));
     GANCE_CREATE_CHECK(hipMalloc((void**)&e->styles, (size_t)Bmax * ctot * sizeof(float)));
     GANCE_CREATE_CHECK(hipMalloc((void**)&e->demod, (size_t)Bmax * dtot * sizeof(float)));
-    GANCE_CREATE_CHECK(hipMalloc((void**)&e->xbuf[0], e->x_floats * sizeof(float)));
-    GANCE_CREATE_CHECK(hipMalloc((void**)&e->xbuf[1], e->x_floats * sizeof(float)));
-    GANCE_CREATE_CHECK(hipMalloc((void**)&e->tbuf, e->t_floats * sizeof(float)));
+    for (int i = 0; i < nconv; ++i) {
+        // every layer owns its zero-bordered output (and parity planes): kernels only ever write
+        // interiors, so the borders are zeroed exactly once, here
+        const ConvLayerHost& c = e->convs[i];
+        const size_t act_bytes = (size_t)Bmax * c.cout * act_plane(1 << c.res_log2) * sizeof(float);
+        GANCE_CREATE_CHECK(hipMalloc((void**)&e->act[i], act_bytes));
+        GANCE_CREATE_CHECK(hipMemset(e->act[i], 0, act_bytes));
+        if (c.up) {
+            const size_t t_bytes = (size_t)4 * e->t_units[i] * c.cout * t_plane((1 << c.res_log2) / 2) * sizeof(float);
+            GANCE_CREATE_CHECK(hipMalloc((void**)&e->tplanes[i], t_bytes));
+            GANCE_CREATE_CHECK(hipMemset(e->tplanes[i], 0, t_bytes));
+        }
+    }
+    GANCE_CREATE_CHECK(hipMalloc((void**)&e->slabs, e->slab_floats * sizeof(float)));
     GANCE_CREATE_CHECK(hipMalloc((void**)&e->ybuf[0], e->y_floats * sizeof(float)));
     GANCE_CREATE_CHECK(hipMalloc((void**)&e->ybuf[1], e->y_floats * sizeof(float)));
     GANCE_CREATE_CHECK(hipMalloc((void**)&e->u8buf, e->y_floats));
@@ -811,12 +790,20 @@ int gance_engine_debug_read_activation(gance_engine* engine, int32_t batch, floa
                                        int32_t* out_side) {
     if (engine == nullptr || h_out == nullptr)
         return fail(GANCE_ERR_INVALID_ARGUMENT, "NULL argument");
-    const size_t n = (size_t)batch * engine->last_act_c * engine->last_act_side * engine->last_act_side;
+    const int C = engine->last_act_c, R = engine->last_act_side;
+    const size_t n = (size_t)batch * C * R * R;
     if (n == 0 || n > max_floats) return fail(GANCE_ERR_INVALID_ARGUMENT, "activation does not fit");
     GANCE_HIP_CHECK(hipDeviceSynchronize());
-    GANCE_HIP_CHECK(hipMemcpy(h_out, engine->xbuf[engine->last_act_buf], n * sizeof(float), hipMemcpyDeviceToHost));
-    if (out_channels) *out_channels = engine->last_act_c;
-    if (out_side) *out_side = engine->last_act_side;
+    const size_t padded = (size_t)batch * C * act_plane(R);
+    std::vector<float> tmp(padded);
+    GANCE_HIP_CHECK(hipMemcpy(tmp.data(), engine->act[engine->last_act_layer], padded * sizeof(float),
+                              hipMemcpyDeviceToHost));
+    for (size_t bc = 0; bc < (size_t)batch * C; ++bc)
+        for (int y = 0; y < R; ++y)
+            std::memcpy(h_out + (bc * R + y) * R, &tmp[bc * act_plane(R) + (size_t)(y + 1) * (R + 4) + 1],
+                        R * sizeof(float));
+    if (out_channels) *out_channels = C;
+    if (out_side) *out_side = R;
     return GANCE_OK;
 }
 

@@ -13,32 +13,33 @@ constexpr int kEpilogueRaw = 0;   // out = acc * d            (split-K slabs, tr
 constexpr int kEpilogueFull = 1;  // out = lrelu(acc * d + noise * strength + bias) * sqrt(2)
 
 // One launch of the implicit-GEMM modulated convolution (conv_mfma.hip).
+// Activations are zero-bordered: x is [B][Cin][H+2][W+4] with the interior at [y+1][x+1].
 struct ConvArgs {
-    const float* x;      // [B][Cin][H][W]
-    const float* w;      // [9][Cin][Cout]  (tap = ky*3+kx, scaled by the runtime coefficient)
+    const float* x;
+    const float* w;      // pre-arranged [m tile][K chunk][tap slot 0..8][KC][BM], runtime-scaled
     const float* s;      // style: s[b * s_stride + ci]
     const float* d;      // demodulation: d[b * d_stride + co]
     const float* noise;  // [OH][OW] or nullptr (full epilogue only)
-    const float* bias;   // [Cout]           (full epilogue only)
-    float* out;          // out[split*slab_stride + b*out_b_stride + co*out_c_stride + oy*out_row_stride + ox]
-    int B, Cin, Cout, H, W;  // input tensor
-    int OH, OW;              // output grid of this launch
+    const float* bias;   // [Cout]
+    // out[split*slab_stride + cls*cls_stride + b*out_b_stride + co*out_c_stride
+    //     + (oy+out_y_off)*out_row_stride + ox + out_x_off]
+    float* out;
+    int B, Cin, Cout, H, W;  // input tensor (interior size)
+    int OH, OW;              // output grid: H x W for a conv, (H+1) x (W+1) positions when up
     int s_stride, d_stride;
     float noise_strength;
     int tiles_x, tiles_y, m_tiles;
-    int nsplit, chunks_per_split;
+    int nsplit, chunks_per_split, total_chunks;
     int epilogue;
-    int ntaps;
-    int tap_dy[kMaxTaps], tap_dx[kMaxTaps], tap_w[kMaxTaps];
-    long long out_b_stride, out_c_stride, slab_stride;
-    long long x_b_stride;  // Cin*H*W, or 0 when every sample reads the same tensor (4x4 const)
-    int out_row_stride;
+    int out_row_stride, out_y_off, out_x_off;
+    long long out_b_stride, out_c_stride, slab_stride, cls_stride;
+    long long x_b_stride;  // Cin*(H+2)*(W+4), or 0 when every sample reads the same tensor
 };
 
 struct ConvTileInfo {
-    int BM, TB, TH, TW, KC;
+    int BM, TB, TH, TW, KC, up;
 };
-constexpr int kNumConvTiles = 6;
+constexpr int kNumConvTiles = 10;
 extern const ConvTileInfo kConvTiles[kNumConvTiles];
 
 hipError_t launch_modconv(int tile_id, const ConvArgs& args, int total_blocks, hipStream_t stream);
@@ -70,29 +71,29 @@ hipError_t launch_demod(const float* s, const float* w2_pool, const DemodLayer* 
                         int num_layers, float* d, int B, int ctot, int dtot, hipStream_t stream);
 
 // Conv0_up second half: 4x4 FIR ([1,3,3,1] x [1,3,3,1] / 16, pad 1/1) over the (2H+1)^2
-// intermediate held as four parity planes (x nsplit slabs), + noise, bias, lrelu*sqrt2.
+// intermediate held as four zero-bordered parity planes, + noise, bias, lrelu*sqrt2.
+//   t + cls*cls_stride + (split*B + b)*unit_stride + c*(H+3)*(W+8) + (y'+1)*(W+8) + x'+4
+// cls = 2*py + px. Writes the zero-bordered activation [B][C][2H+2][2W+4].
 struct FirArgs {
-    const float* t_ee;  // [nsplit][B][C][H+1][W+1]
-    const float* t_eo;  // [nsplit][B][C][H+1][W]
-    const float* t_oe;  // [nsplit][B][C][H][W+1]
-    const float* t_oo;  // [nsplit][B][C][H][W]
-    long long slab_ee, slab_eo, slab_oe, slab_oo;
+    const float* t;
+    long long cls_stride, unit_stride;
     const float* noise;  // [2H][2W] or nullptr
     const float* bias;   // [C]
-    float* out;          // [B][C][2H][2W]
+    float* out;
     float noise_strength;
     int B, C, H, W, nsplit;
 };
 hipError_t launch_fir_epilogue(const FirArgs& args, hipStream_t stream);
 
-// Split-K finish for stride-1 convs: out = lrelu(sum_slabs + noise*strength + bias) * sqrt2.
+// Split-K finish for small stride-1 convs: dense slabs [nsplit][B][C][H][W] ->
+// zero-bordered activation, out = lrelu(sum_slabs + noise*strength + bias) * sqrt2.
 hipError_t launch_splitk_finish(const float* slabs, long long slab_stride, int nsplit,
                                 const float* noise, float noise_strength, const float* bias,
                                 float* out, int B, int C, int H, int W, hipStream_t stream);
 
 // ToRGB (modulated 1x1, no demod) + bias + FIR-upsampled skip image; optional uint8 NHWC output.
 struct ToRgbArgs {
-    const float* x;       // [B][Cin][R][R]
+    const float* x;       // zero-bordered [B][Cin][R+2][R+4]
     const float* w;       // [Cin][3], runtime-scaled
     const float* s;       // s[b*s_stride + ci]
     const float* bias;    // [3]

@@ -11,6 +11,11 @@ from pathlib import Path
 from typing import Dict, List, NamedTuple, Optional
 
 import numpy as np
+import torch  # noqa: F401  pylint: disable=unused-import
+# torch is imported BEFORE the dlopen below on purpose: the PyTorch-ROCm wheel carries its own HIP /
+# HSA runtime, and a process must end up with exactly one. Loading libgance_hip.so first would pull
+# in /opt/rocm's copy and the two runtimes then fight over the device (observed: hipGetDeviceCount
+# fails). With torch loaded first the library binds to the runtime torch already mapped.
 
 from gance_amd.stylegan2 import spec as sg2_spec
 
