@@ -1,0 +1,151 @@
+"""
+ORACLE tooling (build container only): capture golden vectors from the REFERENCE's own code.
+
+    MPLBACKEND=Agg PYTHONDONTWRITEBYTECODE=1 python oracle/make_goldens.py
+
+Imports gance.data_into_network_visualization.visualization_inputs / gance.apply_spectrogram /
+gance.vector_sources.* from /root/reference with the leaf stubs of oracle/ref_stubs.py and writes
+small .npz fixtures to tests/golden/. Inputs are regenerated from seeds by
+gance_amd.synthetic (so they need not be stored); float stages are stored as a strided sample
+plus (min, max, sum) over the full array, integer stages in full.
+"""
+
+import sys
+from pathlib import Path
+
+import numpy as np
+
+REPO_ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(REPO_ROOT))
+
+from gance_amd import synthetic  # noqa: E402
+from oracle import ref_stubs  # noqa: E402
+
+GOLDEN_DIR = REPO_ROOT / "tests" / "golden"
+
+
+def sampled(array: np.ndarray, stride: int) -> dict:
+    """Strided sample + full-array statistics of a float stage."""
+    flat = np.asarray(array).reshape(-1)
+    return {
+        "sample": flat[::stride].copy(),
+        "stats": np.array([flat.min(), flat.max(), flat.sum(dtype=np.float64), float(flat.size)], dtype=np.float64),
+    }
+
+
+def blend_case(name: str, num_frames: int, seed: int, roll: bool, num_networks: int, stride: int) -> None:
+    """One end-to-end `alpha_blend_projection_file` case with every reference intermediate."""
+    from gance import apply_spectrogram  # pylint: disable=import-outside-toplevel,import-error
+    from gance.data_into_network_visualization import visualization_inputs as vi  # pylint: disable=import-outside-toplevel,import-error
+    from gance.vector_sources import vector_reduction, vector_sources_common as vsc  # pylint: disable=import-outside-toplevel,import-error
+    from gance.vector_sources.vector_types import MatricesLabel  # pylint: disable=import-outside-toplevel,import-error
+
+    L, alpha, amp, depth = 512, 0.25, (-5, 5), 12
+    audio = synthetic.synthetic_audio(num_frames, L, seed=seed)
+    latents = synthetic.synthetic_final_latents(num_frames // 2, L, seed=seed + 4)
+
+    db = apply_spectrogram.compute_spectrogram(audio, L)
+    scaled = apply_spectrogram.reshape_spectrogram_to_vectors(db, amplitude_range=amp, vector_length=L)
+    smoothed_time = vsc.smooth_across_vectors(scaled, L, window_length=7, polyorder=3)
+    smoothed = vsc.smooth_each_vector(data=smoothed_time, vector_length=L, window_length=5, polyorder=3)
+    assert np.array_equal(smoothed, apply_spectrogram.compute_spectrogram_smooth_scale(audio, L, amp))
+    raw_rms = vector_reduction._compute_raw_rms(audio, L)  # pylint: disable=protected-access
+    rolling_layers = vector_reduction.reduce_vector_rms_rolling_average(time_series_audio_vectors=audio, vector_length=L)
+    roll_values = vector_reduction.quantize_results_layers(rolling_layers, list(np.arange(0, 3))).result.data
+    final = vi._create_spectrogram(audio, L, amp, roll)  # pylint: disable=protected-access
+    out = vi.alpha_blend_projection_file(
+        final_latents_matrices_label=MatricesLabel(latents, L, "golden"),
+        alpha=alpha,
+        fft_roll_enabled=roll,
+        fft_amplitude_range=amp,
+        blend_depth=depth,
+        time_series_audio_vectors=audio,
+        vector_length=L,
+        network_indices=list(range(num_networks)),
+    )
+    assert np.array_equal(out.a_vectors.data, final)
+    combined = out.combined.data
+    assert combined.shape == (18, num_frames * L) and combined.dtype == np.float64
+    assert all(np.array_equal(combined[0], combined[r]) for r in range(1, depth))
+    assert all(np.array_equal(combined[depth], combined[r]) for r in range(depth, 18))
+
+    arrays = {
+        "meta": np.array([num_frames, L, num_frames // 2, seed, int(roll), num_networks, stride, depth], dtype=np.int64),
+        "alpha_amp": np.array([alpha, amp[0], amp[1]], dtype=np.float64),
+        "raw_rms": np.asarray(raw_rms),
+        "rolling_average": np.asarray(rolling_layers.layers[0].data),
+        "rolling_smoothed": np.asarray(rolling_layers.result.data),
+        "roll_values": np.asarray(roll_values, dtype=np.int64),
+        "network_indices": np.asarray(out.network_indices.result.data, dtype=np.int64),
+        "network_index_smoothed": np.asarray(out.network_indices.layers[0].data),
+    }
+    for key, value in {
+        "db": db,
+        "scaled": scaled,
+        "smoothed_time": smoothed_time,
+        "smoothed": smoothed,
+        "final": final,
+        "combined_row0": combined[0],
+        "combined_row_depth": combined[depth],
+        "projected_row0": out.b_vectors.data[0],
+    }.items():
+        for suffix, array in sampled(value, stride).items():
+            arrays[f"{key}_{suffix}"] = array
+    np.savez_compressed(GOLDEN_DIR / f"{name}.npz", **arrays)
+    print(f"wrote {name}.npz  ({(GOLDEN_DIR / (name + '.npz')).stat().st_size / 1024:.0f} KiB)")
+
+
+def unit_cases() -> None:
+    """Known answers for the array helpers of vector_sources_common / vector_reduction."""
+    from gance.vector_sources import vector_reduction, vector_sources_common as vsc  # pylint: disable=import-outside-toplevel,import-error
+
+    rng = np.random.RandomState(42)
+    data = rng.randn(6 * 64)
+    rolls = rng.randint(0, 3, size=6)
+    matrices = rng.randn(18, 5 * 32).astype(np.float32)
+    ramp = rng.rand(40) * 3.0 + 1.0
+    arrays = {
+        "data": data,
+        "rolls": rolls.astype(np.int64),
+        "rotated": vsc.rotate_vectors_over_time(data, 64, rolls),
+        "smooth_across_7_3": vsc.smooth_across_vectors(data, 8, 7, 3),  # 48 vectors of 8
+        "smooth_each_5_3": vsc.smooth_each_vector(data, 64, 5, 3),
+        "smooth_each_default": vsc.smooth_each_vector(data, 64),
+        "resample_64_to_100": vsc.scale_vectors_to_length_resample(data, 64, 100),
+        "resample_255_to_512": vsc.scale_vectors_to_length_resample(rng.randn(3 * 255), 255, 512),
+        "resample_255_input": None,
+        "duplicated_x3": vsc.duplicate_to_vector_count(data, 64, 18),
+        "promoted": vsc.promote_to_matrix_duplicate(data[:64], 4),
+        "matrices": matrices,
+        "sub_vectors_matrix": vsc.sub_vectors(matrices, 32),
+        "sub_vectors_vector": vsc.sub_vectors(data, 64),
+        "demoted": vsc.demote_to_vector_select(matrices, 0),
+        "ramp": ramp,
+        "quantized_3": vector_reduction.quantize_results_layers(
+            vector_reduction.ResultLayers(result=vector_reduction.DataLabel(ramp, "ramp")), [0, 1, 2]
+        ).result.data.astype(np.int64),
+        "quantized_5": vector_reduction.quantize_results_layers(
+            vector_reduction.ResultLayers(result=vector_reduction.DataLabel(ramp, "ramp")), [0, 1, 2, 3, 4]
+        ).result.data.astype(np.int64),
+    }
+    rng2 = np.random.RandomState(42)
+    rng2.randn(6 * 64), rng2.randint(0, 3, size=6), rng2.randn(18, 5 * 32), rng2.rand(40)  # replay the stream
+    arrays["resample_255_input"] = rng2.randn(3 * 255)
+    assert np.array_equal(vsc.scale_vectors_to_length_resample(arrays["resample_255_input"], 255, 512), arrays["resample_255_to_512"])
+    np.savez_compressed(GOLDEN_DIR / "vector_helpers.npz", **arrays)
+    print("wrote vector_helpers.npz")
+
+
+def main() -> None:
+    ref_stubs.install()
+    GOLDEN_DIR.mkdir(parents=True, exist_ok=True)
+    unit_cases()
+    blend_case("blend_n60_seed0_roll_k3", 60, 0, True, 3, 13)
+    blend_case("blend_n60_seed1_noroll_k1", 60, 1, False, 1, 13)
+    blend_case("blend_n60_seed2_roll_k1", 60, 2, True, 1, 13)
+    blend_case("blend_n240_seed3_roll_k3", 240, 3, True, 3, 53)
+    blend_case("blend_n1800_seed7_roll_k3", 1800, 7, True, 3, 257)
+
+
+if __name__ == "__main__":
+    main()
