@@ -28,6 +28,11 @@ int fail(int code, const std::string& message) {
     g_last_error = message;
     return code;
 }
+}  // namespace
+namespace gance {
+int set_last_error(int code, const std::string& message) { return fail(code, message); }
+}  // namespace gance
+namespace {
 
 #define GANCE_HIP_CHECK(expr)                                                              \
     do {                                                                                   \

@@ -6,7 +6,12 @@
 #include <stddef.h>
 #include <stdint.h>
 
+#include <string>
+
 namespace gance {
+
+// records the message gance_last_error() returns (thread local) and hands `code` back
+int set_last_error(int code, const std::string& message);
 
 constexpr int kMaxTaps = 9;
 constexpr int kEpilogueRaw = 0;   // out = acc * d            (split-K slabs, transposed-conv planes)

@@ -53,6 +53,24 @@ class EngineConfig(ctypes.Structure):
     ]
 
 
+class BlendConfig(ctypes.Structure):
+    """`gance_blend_config` of include/gance_hip.h."""
+
+    _fields_ = [
+        ("num_frames", ctypes.c_int32),
+        ("vector_length", ctypes.c_int32),
+        ("num_projection_frames", ctypes.c_int32),
+        ("latent_depth", ctypes.c_int32),
+        ("blend_depth", ctypes.c_int32),
+        ("fft_roll_enabled", ctypes.c_int32),
+        ("num_networks", ctypes.c_int32),
+        ("has_amplitude_range", ctypes.c_int32),
+        ("alpha", ctypes.c_double),
+        ("amplitude_lo", ctypes.c_double),
+        ("amplitude_hi", ctypes.c_double),
+    ]
+
+
 _F32P = ctypes.POINTER(ctypes.c_float)
 _U8P = ctypes.POINTER(ctypes.c_uint8)
 
@@ -107,6 +125,25 @@ SIGNATURES = {
             ctypes.POINTER(ctypes.c_int32),
         ],
     ),
+    "gance_blend_create": (
+        ctypes.c_int,
+        [ctypes.POINTER(BlendConfig), ctypes.c_int32, ctypes.POINTER(ctypes.c_void_p)],
+    ),
+    "gance_blend_destroy": (None, [ctypes.c_void_p]),
+    "gance_blend_run": (
+        ctypes.c_int,
+        [
+            ctypes.c_void_p,
+            ctypes.c_void_p,
+            ctypes.c_uint64,
+            ctypes.c_void_p,
+            ctypes.c_void_p,
+            ctypes.c_void_p,
+            ctypes.c_int32,
+            ctypes.c_void_p,
+        ],
+    ),
+    "gance_blend_read_stage": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p, ctypes.c_uint64]),
 }
 
 _LIB: Optional[ctypes.CDLL] = None
@@ -320,3 +357,101 @@ class Engine:
             return out.reshape(batch, channels.value, side.value, side.value)
         finally:
             self._lib.gance_engine_debug_stop_after(self._handle, 0)
+
+
+# stage ids of `enum gance_blend_stage`: name -> (id, dtype, per-frame width or None for [N])
+BLEND_STAGES = {
+    "db": (0, np.float64, "bins"),
+    "scaled": (1, np.float64, "L"),
+    "smoothed_time": (2, np.float64, "L"),
+    "smoothed": (3, np.float64, "L"),
+    "rolled": (4, np.float64, "L"),
+    "final": (5, np.float64, "L"),
+    "blend_row": (6, np.float64, "L"),
+    "raw_rms": (7, np.float32, None),
+    "roll_values": (8, np.int32, None),
+    "roll_cumulative": (9, np.int32, None),
+    "network_indices": (10, np.int32, None),
+    "rolling_average": (11, np.float64, None),
+    "rolling_smoothed": (12, np.float64, None),
+    "index_smoothed": (13, np.float64, None),
+}
+
+
+class Blend:
+    """
+    Audio -> blended latents on the GPU. Thin owner of a `gance_blend*` (operator tables and
+    workspace for one (N, F, depth, alpha, ...) configuration).
+    """
+
+    def __init__(
+        self,
+        num_frames: int,
+        num_projection_frames: int,
+        alpha: float,
+        fft_roll_enabled: bool,
+        fft_amplitude_range,
+        blend_depth: int,
+        num_networks: int,
+        vector_length: int = 512,
+        latent_depth: int = 18,
+        device: int = 0,
+    ) -> None:
+        self._lib = load_library()
+        self._handle = ctypes.c_void_p()
+        has_range = fft_amplitude_range is not None
+        lo, hi = (fft_amplitude_range if has_range else (0.0, 0.0))
+        self.config = BlendConfig(
+            num_frames, vector_length, num_projection_frames, latent_depth, blend_depth,
+            int(bool(fft_roll_enabled)), num_networks, int(has_range), float(alpha), float(lo), float(hi),
+        )
+        status = self._lib.gance_blend_create(ctypes.byref(self.config), device, ctypes.byref(self._handle))
+        if status == 1 and b"Cannot duplicate" in self._lib.gance_last_error():
+            # the reference raises ValueError here (vector_sources_common.py:318-331)
+            raise ValueError(self._lib.gance_last_error().decode())
+        _check(self._lib, status)
+        self.device = device
+
+    def close(self) -> None:
+        """Free the tables and workspace. Idempotent."""
+        if self._handle:
+            self._lib.gance_blend_destroy(self._handle)
+            self._handle = ctypes.c_void_p()
+
+    def __del__(self) -> None:
+        try:
+            self.close()
+        except Exception:  # pylint: disable=broad-except
+            pass
+
+    def run_device(
+        self, d_audio: int, num_samples: int, d_latent_row0: int, d_dlatents: int = 0, d_network_indices: int = 0,
+        debug_stages: bool = False, stream: int = 0,
+    ) -> None:
+        """Raw device pointers (ints). Asynchronous on `stream`."""
+        if not self._handle:
+            raise ValueError("Blend has been closed")
+        _check(
+            self._lib,
+            self._lib.gance_blend_run(
+                self._handle, d_audio, ctypes.c_uint64(num_samples), d_latent_row0, d_dlatents or None,
+                d_network_indices or None, int(debug_stages), stream or None,
+            ),
+        )
+
+    def read_stage(self, name: str) -> np.ndarray:
+        """Copy one stage of the last run to the host (synchronises)."""
+        stage_id, dtype, width = BLEND_STAGES[name]
+        frames = self.config.num_frames
+        if width == "L":
+            shape = (frames, self.config.vector_length)
+        elif width == "bins":
+            shape = (frames, (self.config.vector_length - 2) // 2)
+        else:
+            shape = (frames,)
+        out = np.empty(shape, dtype=dtype)
+        _check(
+            self._lib,
+            self._lib.gance_blend_read_stage(self._handle, stage_id, out.ctypes.data_as(ctypes.c_void_p), ctypes.c_uint64(out.nbytes)),
+        )
+        return out

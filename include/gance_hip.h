@@ -122,6 +122,70 @@ int gance_engine_debug_read_activation(gance_engine* engine, int32_t batch, floa
                                        uint64_t max_floats, int32_t* out_channels,
                                        int32_t* out_side);
 
+/* ------------------------------------------------------------------------------------------ */
+/* Audio -> latent: spectrogram, fft-roll, alpha blend with projected latents                  */
+/* ------------------------------------------------------------------------------------------ */
+
+typedef struct gance_blend gance_blend; /* opaque; operator tables + workspace in HBM */
+
+typedef struct gance_blend_config {
+    int32_t num_frames;            /* N output frames; audio holds N * vector_length samples      */
+    int32_t vector_length;         /* L = 512                                                     */
+    int32_t num_projection_frames; /* F projected latents; N % F == 0 (divisor.py:19-24)          */
+    int32_t latent_depth;          /* rows per latent matrix (18)                                 */
+    int32_t blend_depth;           /* rows that receive the blend (--blend-depth, <= 18)          */
+    int32_t fft_roll_enabled;      /* --fft-roll-enabled                                          */
+    int32_t num_networks;          /* K = len(network_indices)                                    */
+    int32_t has_amplitude_range;   /* 0 = no min-max scaling                                      */
+    double alpha;                  /* --alpha                                                     */
+    double amplitude_lo;           /* --fft-amplitude-range                                       */
+    double amplitude_hi;
+} gance_blend_config;
+
+/*
+ * Replaces the table-free Python of alpha_blend_projection_file
+ * (gance/data_into_network_visualization/visualization_inputs.py:169-270) and everything it calls:
+ * compute_spectrogram_smooth_scale (gance/apply_spectrogram.py:85-118), reduce_vector_rms_rolling_average
+ * + quantize_results_layers (gance/vector_sources/vector_reduction.py:102-124,161-194),
+ * rotate_vectors_over_time / smooth_each_vector / duplicate_to_vector_count / promote_to_matrix_duplicate
+ * (gance/vector_sources/vector_sources_common.py:408-428,169-188,298-365).
+ * Raises (returns GANCE_ERR_INVALID_ARGUMENT) where the reference raises ValueError: N % F != 0.
+ */
+int gance_blend_create(const gance_blend_config* config, int32_t device, gance_blend** out_blend);
+void gance_blend_destroy(gance_blend* blend);
+
+/*
+ * d_audio: float32 [>= N*L] time-series audio (read_wavs_scale_for_video's output,
+ * gance/vector_sources/music.py:60-169). d_latent_row0: float32 [F][L], row 0 of every projected
+ * final latent (the only row the reference uses, visualization_inputs.py:220-231).
+ * d_dlatents (may be NULL): float32 [N][latent_depth][L], the per-frame matrices `combined` is
+ * split into by _frame_inputs (network_visualization.py:233-251), cast to the float32 the
+ * network is fed. d_network_indices (may be NULL): int32 [N]. With debug_stages != 0 every
+ * intermediate is kept for gance_blend_read_stage. Asynchronous on `stream`.
+ */
+int gance_blend_run(gance_blend* blend, const float* d_audio, uint64_t num_samples,
+                    const float* d_latent_row0, float* d_dlatents, int32_t* d_network_indices,
+                    int32_t debug_stages, void* stream);
+
+enum gance_blend_stage {
+    GANCE_STAGE_DB = 0,            /* float64 [N][255]  compute_spectrogram, transposed          */
+    GANCE_STAGE_SCALED = 1,        /* float64 [N][L]    after resample + minmax                  */
+    GANCE_STAGE_SMOOTHED_TIME = 2, /* float64 [N][L]    after smooth_across_vectors(7,3)         */
+    GANCE_STAGE_SMOOTHED = 3,      /* float64 [N][L]    compute_spectrogram_smooth_scale         */
+    GANCE_STAGE_ROLLED = 4,        /* float64 [N][L]    after rotate_vectors_over_time           */
+    GANCE_STAGE_FINAL = 5,         /* float64 [N][L]    a_vectors.data                           */
+    GANCE_STAGE_BLEND_ROW = 6,     /* float64 [N][L]    combined.data[0]                         */
+    GANCE_STAGE_RAW_RMS = 7,       /* float32 [N]                                                */
+    GANCE_STAGE_ROLL_VALUES = 8,   /* int32   [N]       quantised roll per frame                 */
+    GANCE_STAGE_ROLL_CUMULATIVE = 9, /* int32 [N]       cumsum(roll) mod L                       */
+    GANCE_STAGE_NETWORK_INDICES = 10, /* int32 [N]                                               */
+    GANCE_STAGE_ROLLING_AVERAGE = 11, /* float64 [N]    roll chain                               */
+    GANCE_STAGE_ROLLING_SMOOTHED = 12, /* float64 [N]   roll chain                               */
+    GANCE_STAGE_INDEX_SMOOTHED = 13    /* float64 [N]   network-index chain                      */
+};
+/* Synchronises the device and copies one stage of the LAST run to host memory. */
+int gance_blend_read_stage(gance_blend* blend, int32_t stage, void* h_out, uint64_t num_bytes);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,138 @@
+"""
+GPU parity tests of the audio -> latent path: gance_blend_* of libgance_hip.so (through its C ABI)
+against (a) the committed golden vectors captured from the reference's own code and (b) the CPU
+oracle on fresh seeded inputs.
+
+Bars: integer stages (roll amounts, cumulative roll, network indices) bit-exact; the float32 RMS
+bit-exact; float64 stages within 1e-7 absolute after the reference's own scaling to the
+amplitude range (observed ~1e-11; the slack covers summation-order differences between a direct
+510-point DFT and pocketfft on near-silent bins, which the dB scale amplifies).
+"""
+
+import numpy as np
+import pytest
+import torch
+
+from gance_amd import hip_lib, synthetic
+from oracle import audio_ref
+
+pytestmark = pytest.mark.gpu
+
+FLOAT_ATOL = 1e-7
+BLEND_CASES = [
+    "blend_n60_seed0_roll_k3",
+    "blend_n60_seed1_noroll_k1",
+    "blend_n60_seed2_roll_k1",
+    "blend_n240_seed3_roll_k3",
+    "blend_n1800_seed7_roll_k3",
+]
+
+
+def run_blend(audio, latents, alpha, roll, amp, depth, num_networks):
+    """Run the HIP path once with every intermediate kept; returns (blend handle, dlatents, indices)."""
+    num_frames = len(audio) // 512
+    num_projection = latents.shape[1] // 512
+    blend = hip_lib.Blend(num_frames, num_projection, alpha, roll, amp, depth, num_networks, latent_depth=latents.shape[0])
+    d_audio = torch.from_numpy(audio).cuda()
+    d_row0 = torch.from_numpy(np.ascontiguousarray(latents[0])).cuda()
+    d_dlat = torch.empty((num_frames, latents.shape[0], 512), dtype=torch.float32, device="cuda")
+    d_idx = torch.empty((num_frames,), dtype=torch.int32, device="cuda")
+    blend.run_device(
+        d_audio.data_ptr(), audio.size, d_row0.data_ptr(), d_dlat.data_ptr(), d_idx.data_ptr(), debug_stages=True,
+        stream=torch.cuda.current_stream().cuda_stream,
+    )
+    torch.cuda.synchronize()
+    return blend, d_dlat.cpu().numpy(), d_idx.cpu().numpy()
+
+
+@pytest.mark.parametrize("name", BLEND_CASES)
+def test_hip_blend_matches_reference_goldens(golden_dir, name: str) -> None:
+    golden = np.load(golden_dir / f"{name}.npz")
+    num_frames, L, num_projection, seed, roll, num_networks, stride, depth = (int(v) for v in golden["meta"])
+    alpha, amp_lo, amp_hi = (float(v) for v in golden["alpha_amp"])
+    audio = synthetic.synthetic_audio(num_frames, L, seed=seed)
+    latents = synthetic.synthetic_final_latents(num_projection, L, seed=seed + 4)
+    blend, dlatents, indices = run_blend(audio, latents, alpha, bool(roll), (amp_lo, amp_hi), depth, num_networks)
+    try:
+        # integer / float32 stages: bit-exact
+        assert np.array_equal(blend.read_stage("raw_rms"), golden["raw_rms"])
+        assert np.array_equal(indices, golden["network_indices"])
+        assert np.array_equal(blend.read_stage("network_indices"), golden["network_indices"])
+        if roll:
+            assert np.array_equal(blend.read_stage("roll_values"), golden["roll_values"])
+            assert np.array_equal(blend.read_stage("roll_cumulative"), np.cumsum(golden["roll_values"]) % L)
+            np.testing.assert_allclose(blend.read_stage("rolling_average"), golden["rolling_average"], rtol=1e-15, atol=0)
+            np.testing.assert_allclose(blend.read_stage("rolling_smoothed"), golden["rolling_smoothed"], rtol=1e-12, atol=1e-15)
+        # float64 stages against the strided samples
+        db = blend.read_stage("db").T  # reference layout is (255, N)
+        np.testing.assert_allclose(db.reshape(-1)[::stride], golden["db_sample"], rtol=0, atol=1e-6)
+        for stage, key in [("scaled", "scaled"), ("smoothed_time", "smoothed_time"), ("smoothed", "smoothed"), ("final", "final"), ("blend_row", "combined_row0")]:
+            got = blend.read_stage(stage).reshape(-1)
+            np.testing.assert_allclose(got[::stride], golden[f"{key}_sample"], rtol=0, atol=FLOAT_ATOL, err_msg=stage)
+            lo, hi, total, size = golden[f"{key}_stats"]
+            assert got.size == int(size)
+            np.testing.assert_allclose([got.min(), got.max()], [lo, hi], rtol=0, atol=FLOAT_ATOL)
+        # the latents fed to the network: rows < depth = float32(blend row), rows >= depth = projected
+        blend_row = blend.read_stage("blend_row")
+        assert dlatents.shape == (num_frames, 18, L)
+        for row in (0, depth - 1):
+            assert np.array_equal(dlatents[:, row, :], blend_row.astype(np.float32))
+        projected = np.repeat(latents[0].reshape(-1, L), num_frames // num_projection, axis=0)
+        for row in (depth, 17):
+            assert np.array_equal(dlatents[:, row, :], projected)
+        np.testing.assert_array_equal(projected.reshape(-1)[::stride], golden["projected_row0_sample"])
+    finally:
+        blend.close()
+
+
+@pytest.mark.parametrize("seed,num_frames,mult,alpha,amp,depth,roll,num_networks", [
+    (21, 96, 3, 0.4, (-1.0, 1.0), 10, True, 4),
+    (22, 64, 1, 0.9, (-5.0, 5.0), 18, True, 2),
+    (23, 77, 7, 0.1, None, 0, False, 3),
+])
+def test_hip_blend_matches_oracle_on_fresh_inputs(seed, num_frames, mult, alpha, amp, depth, roll, num_networks) -> None:
+    """Parameters and seeds no golden covers, including blend_depth 0 / 18 and no amplitude range."""
+    L = 512
+    audio = synthetic.synthetic_audio(num_frames, L, seed=seed)
+    latents = synthetic.synthetic_final_latents(num_frames // mult, L, seed=seed + 1)
+    blend, dlatents, indices = run_blend(audio, latents, alpha, roll, amp, depth, num_networks)
+    try:
+        want = audio_ref.alpha_blend_projection_file(latents, alpha, roll, amp, depth, audio, L, list(range(num_networks)))
+        stages = audio_ref.create_spectrogram_stages(audio, L, amp, roll)
+        assert np.array_equal(indices, want.network_indices)
+        if roll:
+            assert np.array_equal(blend.read_stage("roll_values"), stages.roll_values)
+            np.testing.assert_allclose(blend.read_stage("rolled").reshape(-1), stages.rolled, rtol=0, atol=FLOAT_ATOL * 50)
+        scale = 1.0 if amp is not None else 50.0  # un-scaled dB values are ~1e2 larger
+        np.testing.assert_allclose(blend.read_stage("final").reshape(-1), want.spectrogram, rtol=0, atol=FLOAT_ATOL * scale)
+        got_combined = np.transpose(dlatents, (1, 0, 2)).reshape(18, -1)
+        np.testing.assert_allclose(got_combined, want.combined.astype(np.float32), rtol=0, atol=1e-5 * scale)
+        if depth < 18:
+            assert np.array_equal(got_combined[depth:], want.projected[depth:])
+    finally:
+        blend.close()
+
+
+def test_roll_is_an_exact_rotation() -> None:
+    """Size-independent property at the benchmark size: every rolled frame is a rotation of its input."""
+    num_frames, L = 1800, 512
+    audio, latents = synthetic.benchmark_blend_inputs(num_frames, L)
+    blend, _, _ = run_blend(audio, latents, 0.25, True, (-5, 5), 12, 1)
+    try:
+        smoothed = blend.read_stage("smoothed")
+        rolled = blend.read_stage("rolled")
+        shift = blend.read_stage("roll_cumulative")
+        rolls = blend.read_stage("roll_values")
+        assert set(np.unique(rolls)) <= {0, 1, 2}
+        assert np.array_equal(shift, np.cumsum(rolls.astype(np.int64)) % L)
+        index = (np.arange(L)[None, :] + shift[:, None]) % L
+        assert np.array_equal(rolled, np.take_along_axis(smoothed, index, axis=1))  # bit-exact gather
+    finally:
+        blend.close()
+
+
+def test_blend_rejects_what_the_reference_rejects() -> None:
+    with pytest.raises(ValueError, match="Cannot duplicate"):
+        hip_lib.Blend(60, 7, 0.25, True, (-5, 5), 12, 3)  # vsc:318-331
+    with pytest.raises(hip_lib.GanceHipError):
+        hip_lib.Blend(60, 30, 0.25, True, (-5, 5), 19, 3)  # blend_depth > 18
