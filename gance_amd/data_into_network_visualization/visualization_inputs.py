@@ -1,0 +1,123 @@
+"""
+Audio -> `VisualizationInput`, on the GPU.
+
+`alpha_blend_projection_file` keeps the reference's signature, argument meaning, return type,
+dtypes and error behaviour (gance/data_into_network_visualization/visualization_inputs.py:169-270)
+but runs as six HIP kernels (gance_amd/csrc/audio.hip) instead of per-vector Python loops over
+scipy / pandas / librosa calls. `alpha_blend_projection_file_device` is the same computation left
+in HBM for the frame-sharded synthesis pipeline (no 133 MB float64 `combined` round trip).
+"""
+
+from typing import List, NamedTuple, Optional, Tuple
+
+import numpy as np
+import torch
+
+from gance_amd import hip_lib
+from gance_amd.data_into_network_visualization.visualization_common import DataLabel, ResultLayers, VisualizationInput
+from gance_amd.vector_sources import vector_sources_common
+from gance_amd.vector_sources.vector_types import ConcatenatedMatrices, ConcatenatedVectors, MatricesLabel, VectorsLabel
+
+LATENT_ROWS = 18  # hard-coded in the reference's concatenate (visualization_inputs.py:241-243)
+
+
+class DeviceBlend(NamedTuple):
+    """Blend results resident in HBM."""
+
+    dlatents: torch.Tensor  # [N, 18, L] float32: what each frame feeds the network
+    network_indices: torch.Tensor  # [N] int32
+    blend: hip_lib.Blend  # owner of the intermediates (spectrogram, blend row ...); close() when done
+
+
+def alpha_blend_projection_file_device(
+    final_latents: np.ndarray,
+    alpha: float,
+    fft_roll_enabled: bool,
+    fft_amplitude_range: Optional[Tuple[float, float]],
+    blend_depth: int,
+    time_series_audio_vectors: np.ndarray,
+    vector_length: int,
+    num_networks: int,
+    device: int = 0,
+    keep_stages: bool = False,
+) -> DeviceBlend:
+    """
+    Run the blend on `device` and leave the per-frame latent matrices there.
+    :param final_latents: (depth, F*L) float32 concatenated final latents; only row 0 is read,
+    as in the reference (visualization_inputs.py:220-231).
+    :raises ValueError: if the frame count is not a multiple of the projected-latent count.
+    """
+    if vector_length != 512:
+        raise ValueError("vector_length must be 512 (the reference's RMS hop is librosa's fixed 512)")
+    audio = np.ascontiguousarray(time_series_audio_vectors, dtype=np.float32)
+    if audio.ndim != 1:
+        audio = np.ascontiguousarray(np.mean(audio, axis=1), dtype=np.float32)  # apply_spectrogram.py:63-66
+    num_frames = int(audio.shape[0] / vector_length)
+    row0 = np.ascontiguousarray(final_latents[0], dtype=np.float32)
+    num_projection = int(row0.shape[0] / vector_length)
+    blend = hip_lib.Blend(
+        num_frames, num_projection, alpha, fft_roll_enabled, fft_amplitude_range, blend_depth, num_networks,
+        vector_length=vector_length, latent_depth=int(final_latents.shape[0]), device=device,
+    )
+    cuda = torch.device("cuda", device)
+    d_audio = torch.from_numpy(audio).to(cuda)
+    d_row0 = torch.from_numpy(row0).to(cuda)
+    dlatents = torch.empty((num_frames, int(final_latents.shape[0]), vector_length), dtype=torch.float32, device=cuda)
+    indices = torch.empty((num_frames,), dtype=torch.int32, device=cuda)
+    stream = torch.cuda.current_stream(cuda)
+    blend.run_device(
+        d_audio.data_ptr(), audio.size, d_row0.data_ptr(), dlatents.data_ptr(), indices.data_ptr(),
+        debug_stages=keep_stages, stream=stream.cuda_stream,
+    )
+    stream.synchronize()  # d_audio / d_row0 go out of scope here
+    return DeviceBlend(dlatents, indices, blend)
+
+
+def alpha_blend_projection_file(  # pylint: disable=too-many-locals
+    final_latents_matrices_label: MatricesLabel,
+    alpha: float,
+    fft_roll_enabled: bool,
+    fft_amplitude_range: Tuple[int, int],
+    blend_depth: int,
+    time_series_audio_vectors: ConcatenatedVectors,
+    vector_length: int,
+    network_indices: List[int],
+) -> VisualizationInput:
+    """
+    Drop-in for the reference function of the same name: same arguments, same NamedTuple back
+    (a_vectors = rolled spectrogram (N*L,) float64, b_vectors = projected latents (depth, N*L)
+    float32, combined (18, N*L) float64, network_indices = ResultLayers with int indices).
+    """
+    latents = np.asarray(final_latents_matrices_label.data)
+    result = alpha_blend_projection_file_device(
+        latents, alpha, fft_roll_enabled, fft_amplitude_range, blend_depth, time_series_audio_vectors,
+        vector_length, len(network_indices),
+    )
+    try:
+        spectrogram = ConcatenatedVectors(result.blend.read_stage("final").reshape(-1))
+        blend_row = result.blend.read_stage("blend_row").reshape(-1)
+        index_smoothed = result.blend.read_stage("index_smoothed")
+        indices = result.network_indices.cpu().numpy().astype(int)
+    finally:
+        result.blend.close()
+    num_vectors = int(vector_sources_common.underlying_length(spectrogram) / vector_length)
+    projected: ConcatenatedMatrices = vector_sources_common.promote_to_matrix_duplicate(
+        data=vector_sources_common.duplicate_to_vector_count(
+            data=vector_sources_common.demote_to_vector_select(latents, index_to_take=0),
+            vector_length=vector_length,
+            target_vector_count=num_vectors,
+        ),
+        target_depth=latents.shape[0],
+    )
+    combined = np.concatenate(
+        (vector_sources_common.promote_to_matrix_duplicate(ConcatenatedVectors(blend_row), blend_depth), projected[blend_depth:LATENT_ROWS])
+    )
+    return VisualizationInput(
+        a_vectors=VectorsLabel(data=spectrogram, vector_length=vector_length, label="Rolled Audio Spectrogram"),
+        b_vectors=MatricesLabel(data=projected, vector_length=vector_length, label=final_latents_matrices_label.label),
+        combined=MatricesLabel(data=combined, vector_length=vector_length, label=f"Combined w/ Alpha Blending, a={alpha}"),
+        network_indices=ResultLayers(
+            result=DataLabel(indices, "Savgol Smoothing Filter (window=3, polyorder=2) Scaled, Quantized"),
+            layers=[DataLabel(index_smoothed, "Savgol Smoothing Filter (window=3, polyorder=2)")],
+        ),
+    )

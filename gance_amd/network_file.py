@@ -1,0 +1,56 @@
+"""
+Network files of this implementation.
+
+The reference loads a TF1 StyleGAN2 pickle and takes element [2], `Gs`
+(gance/network_interface/network_functions.py:108-110). Unpickling that needs TensorFlow 1.x and
+the un-vendored dnnlib, neither of which exists here, so this implementation stores a generator as
+a plain pickle of numpy arrays under the SAME TF variable names (gance_amd/stylegan2/spec.py): a
+legacy importer only has to copy arrays by name (not built yet). The file suffix
+stays `.pkl` so `sorted_networks_in_directory` / `parse_network_paths` behave identically.
+"""
+
+import pickle
+from pathlib import Path
+from typing import Dict, NamedTuple
+
+import numpy as np
+
+from gance_amd.stylegan2 import spec as sg2_spec
+
+FORMAT = "gance_amd.stylegan2.v1"
+
+
+class NetworkFile(NamedTuple):
+    """A generator on disk."""
+
+    resolution: int
+    variables: Dict[str, np.ndarray]
+
+
+def save_network(path: Path, resolution: int, variables: Dict[str, np.ndarray]) -> None:
+    """Write a generator (raw, un-scaled TF-named variables)."""
+    spec = sg2_spec.make_spec(resolution)
+    sg2_spec.pack_variables(variables, spec)  # validates names and shapes
+    with open(str(path), "wb") as file:
+        pickle.dump({"format": FORMAT, "resolution": int(resolution), "variables": dict(variables)}, file, protocol=4)
+
+
+def load_network(path: Path) -> NetworkFile:
+    """
+    Read a generator.
+    :raises RuntimeError: if the file is not in this implementation's format (e.g. a legacy TF
+    pickle), the error class the reference's callers already handle (network_functions.py:523-529).
+    """
+    try:
+        with open(str(path), "rb") as file:
+            content = pickle.load(file)
+    except (pickle.UnpicklingError, ModuleNotFoundError, AttributeError, EOFError, ImportError) as error:
+        raise RuntimeError(f"{path} is not a gance_amd network file (legacy TF pickles need the importer): {error}") from error
+    if not isinstance(content, dict) or content.get("format") != FORMAT:
+        raise RuntimeError(f"{path} is not a gance_amd network file (format tag {FORMAT!r} missing)")
+    return NetworkFile(int(content["resolution"]), content["variables"])
+
+
+def write_random_network(path: Path, resolution: int, seed: int = 0) -> None:
+    """Random-init generator as a network file."""
+    save_network(path, resolution, sg2_spec.make_random_variables(resolution, seed=seed))
