@@ -260,13 +260,13 @@ __global__ __launch_bounds__(256) void fir_epilogue_kernel(const FirArgs p) {
         r0[i] = lrelu_gain(r0[i] + bs);
         r1[i] = lrelu_gain(r1[i] + bs);
     }
-    // zero-bordered activation [B][C][2H+2][2W+4], interior at [y+1][x+1]
-    const int OWp = OW + 4;
-    float* op = p.out + (bc * (size_t)(2 * p.H + 2) + (2 * Y + 1)) * OWp + 2 * X + 1;
-    *reinterpret_cast<float4u*>(op) = float4u{r0[0], r0[1], r0[2], r0[3]};
-    *reinterpret_cast<float4u*>(op + 4) = float4u{r0[4], r0[5], r0[6], r0[7]};
-    *reinterpret_cast<float4u*>(op + OWp) = float4u{r1[0], r1[1], r1[2], r1[3]};
-    *reinterpret_cast<float4u*>(op + OWp + 4) = float4u{r1[4], r1[5], r1[6], r1[7]};
+    // zero-bordered activation [B][C][2H+2][2W+8], interior at [y+1][x+4]: aligned 16-B stores
+    const int OWp = OW + 8;
+    float* op = p.out + (bc * (size_t)(2 * p.H + 2) + (2 * Y + 1)) * OWp + 2 * X + 4;
+    *reinterpret_cast<float4*>(op) = make_float4(r0[0], r0[1], r0[2], r0[3]);
+    *reinterpret_cast<float4*>(op + 4) = make_float4(r0[4], r0[5], r0[6], r0[7]);
+    *reinterpret_cast<float4*>(op + OWp) = make_float4(r1[0], r1[1], r1[2], r1[3]);
+    *reinterpret_cast<float4*>(op + OWp + 4) = make_float4(r1[4], r1[5], r1[6], r1[7]);
 }
 
 hipError_t launch_fir_epilogue(const FirArgs& args, hipStream_t stream) {
@@ -277,7 +277,7 @@ hipError_t launch_fir_epilogue(const FirArgs& args, hipStream_t stream) {
 }
 
 // ------------------------------------------------------------------------------------------
-// Split-K finish (small layers only): slabs [nsplit][B][C][H][W] -> zero-bordered activation
+// Split-K finish (small layers only): slabs [nsplit][B][C][H][W] -> zero-bordered activation [..][H+2][W+8]
 // ------------------------------------------------------------------------------------------
 
 __global__ __launch_bounds__(256) void splitk_finish_kernel(const float* __restrict__ slabs,
@@ -296,7 +296,7 @@ __global__ __launch_bounds__(256) void splitk_finish_kernel(const float* __restr
     const size_t bc = i / ((size_t)W * H);
     const int c = (int)(bc % C);
     if (noise != nullptr) v += noise[(size_t)y * W + x] * noise_strength;
-    out[(bc * (H + 2) + y + 1) * (size_t)(W + 4) + x + 1] = lrelu_gain(v + bias[c]);
+    out[(bc * (H + 2) + y + 1) * (size_t)(W + 8) + x + 4] = lrelu_gain(v + bias[c]);
 }
 
 hipError_t launch_splitk_finish(const float* slabs, long long slab_stride, int nsplit,
@@ -313,7 +313,7 @@ hipError_t launch_splitk_finish(const float* slabs, long long slab_stride, int n
 // ToRGB + skip upsample (+ uint8 NHWC)
 // ------------------------------------------------------------------------------------------
 // y[b,c,p] = sum_ci x[b,ci,p] * (s[b,ci] * w[ci,c]) + bias[c] + upsample_2d(y_prev)[b,c,p]
-// x is the zero-bordered activation [B][Cin][R+2][R+4]; y is dense [B][3][R][R].
+// x is the zero-bordered activation [B][Cin][R+2][R+8]; y is dense [B][3][R][R].
 // upsample_2d = zero-insert x2, pad (2,1), FIR [1,3,3,1]x[1,3,3,1]/16: per axis
 //   even o=2Y:  1/4 y[Y-1] + 3/4 y[Y] ;  odd o=2Y+1:  3/4 y[Y] + 1/4 y[Y+1]   (zero outside).
 // uint8: tf.saturate_cast(x * 127.5 + 128): separate multiply and add, clamp, truncate.
@@ -331,17 +331,17 @@ __global__ __launch_bounds__(256) void torgb_kernel(const ToRgbArgs p) {
     if (p4 >= npix) return;
     const int oy = (int)(p4 / R);
     const int ox0 = (int)(p4 % R);
-    const size_t xplane = (size_t)(R + 2) * (R + 4);
+    const size_t xplane = (size_t)(R + 2) * (R + 8);
 
     float acc[3][4];
 #pragma unroll
     for (int c = 0; c < 3; ++c)
 #pragma unroll
         for (int k = 0; k < 4; ++k) acc[c][k] = 0.f;
-    const float* xp = p.x + (size_t)b * p.Cin * xplane + (size_t)(oy + 1) * (R + 4) + ox0 + 1;
+    const float* xp = p.x + (size_t)b * p.Cin * xplane + (size_t)(oy + 1) * (R + 8) + ox0 + 4;
 #pragma unroll 4
     for (int ci = 0; ci < p.Cin; ++ci) {
-        const float4u v = *reinterpret_cast<const float4u*>(xp + (size_t)ci * xplane);
+        const float4 v = *reinterpret_cast<const float4*>(xp + (size_t)ci * xplane);
         const float c0 = coef[ci * 3 + 0], c1 = coef[ci * 3 + 1], c2 = coef[ci * 3 + 2];
         acc[0][0] = fmaf(v.x, c0, acc[0][0]); acc[0][1] = fmaf(v.y, c0, acc[0][1]);
         acc[0][2] = fmaf(v.z, c0, acc[0][2]); acc[0][3] = fmaf(v.w, c0, acc[0][3]);

@@ -13,6 +13,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -103,11 +104,20 @@ struct LayerPlan {
 int ceil_div(int a, int b) { return (a + b - 1) / b; }
 
 int layer_bm(int cout) { return cout == 32 ? 32 : (cout == 64 ? 64 : 128); }
-int layer_kc(int cout) { return layer_bm(cout) == 128 ? 4 : 8; }
+
+// K chunk (input channels per LDS stage) of the narrow layers. Tunable for experiments:
+// GANCE_TUNE_KC_CONV / GANCE_TUNE_KC_UP = 4 or 8 (read once).
+int tuned_kc(bool up) {
+    static const int conv_kc = [] { const char* v = std::getenv("GANCE_TUNE_KC_CONV"); return v && std::atoi(v) == 8 ? 8 : 4; }();
+    static const int up_kc = [] { const char* v = std::getenv("GANCE_TUNE_KC_UP"); return v && std::atoi(v) == 4 ? 4 : 8; }();
+    return up ? up_kc : conv_kc;
+}
+int layer_kc(int cout, bool up) { return layer_bm(cout) == 128 ? 4 : tuned_kc(up); }
 
 int choose_tile(int cout, bool up, int OH, int OW, int B) {
-    if (cout == 32) return up ? 6 : 0;
-    if (cout == 64) return up ? 7 : 1;
+    const bool kc4 = tuned_kc(up) == 4;
+    if (cout == 32) return up ? (kc4 ? 12 : 6) : (kc4 ? 10 : 0);
+    if (cout == 64) return up ? (kc4 ? 13 : 7) : (kc4 ? 11 : 1);
     const int first = up ? 8 : 2, last = up ? 9 : 5;
     int best = first;
     long best_tiles = -1;
@@ -151,7 +161,7 @@ LayerPlan plan_layer(const ConvLayerHost& c, int B) {
 }
 
 // zero-bordered geometry
-size_t act_plane(int res) { return (size_t)(res + 2) * (res + 4); }       // one channel
+size_t act_plane(int res) { return (size_t)(res + 2) * (res + 8); }       // one channel, interior at [y+1][x+4]
 size_t t_plane(int h) { return (size_t)(h + 3) * (h + 8); }               // one channel, one class
 
 // weight slot t of the transposed conv reads filter tap kUpTapWeight[t] (= wy*3+wx); order must
@@ -297,11 +307,42 @@ int run_conv(gance_engine* e, const ConvLayerHost& c, int li, const LayerPlan& p
     a.slab_stride = slab_stride;
     a.cls_stride = cls_stride;
     a.x_b_stride = x_b_stride;
+    static const int debug_flags = [] { const char* v = std::getenv("GANCE_DEBUG_CONV"); return v ? std::atoi(v) : 0; }();
+    a.debug_flags = debug_flags;
+    static unsigned long long* stamps = nullptr;
+    if (debug_flags & 16) {
+        if (stamps == nullptr) hipMalloc((void**)&stamps, (size_t)5 * 8 * 65536);
+        a.debug_stamps = stamps;
+    }
     const double flops = 2.0 * 9 * (double)c.cin * c.cout * H * W * B;
     const double out_elems = (double)B * c.cout * (c.up ? 4.0 * H * W : (double)H * W) * p.nsplit;
     const double bytes = 4.0 * ((double)B * c.cin * H * W + out_elems + 9.0 * c.cin * c.cout);
     StepScope scope(e, stream, name, flops, bytes);
     GANCE_HIP_CHECK(gance::launch_modconv(p.tile_id, a, p.total_blocks, stream));
+    if ((debug_flags & 16) && p.total_blocks <= 65536) {
+        // timing experiment: dump per-block phase stamps (100 MHz clock) of this launch
+        hipStreamSynchronize(stream);
+        std::vector<unsigned long long> h((size_t)5 * p.total_blocks);
+        hipMemcpy(h.data(), stamps, h.size() * 8, hipMemcpyDeviceToHost);
+        unsigned long long t_min = ~0ull, t_max = 0;
+        double pro = 0, main_ = 0, epi = 0;
+        for (int i = 0; i < p.total_blocks; ++i) {
+            t_min = std::min(t_min, h[5 * i]);
+            t_max = std::max(t_max, h[5 * i + 3]);
+            pro += (double)(h[5 * i + 1] - h[5 * i]);
+            main_ += (double)(h[5 * i + 2] - h[5 * i + 1]);
+            epi += (double)(h[5 * i + 3] - h[5 * i + 2]);
+        }
+        const double n = p.total_blocks, span = (double)(t_max - t_min) / 100.0;
+        // concurrency: sum of block lifetimes / span / 256 CUs
+        const double life = (pro + main_ + epi) / 100.0;
+        std::fprintf(stderr, "STAMPS %s blocks %d span %.1f us | per block: prologue %.2f us, main %.2f us, epilogue %.2f us | avg resident blocks/CU %.2f\n",
+                     name, p.total_blocks, span, pro / n / 100.0, main_ / n / 100.0, epi / n / 100.0, life / span / 256.0);
+        if (std::getenv("GANCE_DEBUG_DUMP") && std::strstr(name, std::getenv("GANCE_DEBUG_DUMP"))) {
+            for (int i = 0; i < p.total_blocks; ++i)
+                std::fprintf(stderr, "BLK %d %llu %llu %llu %llu %llx\n", i, h[5 * i] - t_min, h[5 * i + 1] - t_min, h[5 * i + 2] - t_min, h[5 * i + 3] - t_min, h[5 * i + 4]);
+        }
+    }
     return GANCE_OK;
 }
 
@@ -326,7 +367,7 @@ int synthesize_from_dlat(gance_engine* e, const float* d_dlat, int B, uint8_t* d
     bool have_y = false;
     const int num_convs = (int)e->convs.size();
     const int limit = e->debug_stop_after > 0 ? std::min(e->debug_stop_after, num_convs) : num_convs;
-    const float* x_in = e->pool + e->const_off;  // zero-bordered [512][6][8], shared by the batch
+    const float* x_in = e->pool + e->const_off;  // zero-bordered [512][6][12], shared by the batch
     long long x_b_stride = 0;
 
     for (int li = 0; li < limit; ++li) {
@@ -344,7 +385,7 @@ int synthesize_from_dlat(gance_engine* e, const float* d_dlat, int B, uint8_t* d
                           c.cout);
             if (p.nsplit == 1) {
                 int rc = run_conv(e, c, li, p, x_in, x_b_stride, res, res, x_out,
-                                  gance::kEpilogueFull, res + 4, 1, 1, out_b, out_c, 0, 0, B, stream,
+                                  gance::kEpilogueFull, res + 8, 1, 4, out_b, out_c, 0, 0, B, stream,
                                   name);
                 if (rc) return rc;
             } else {
@@ -523,11 +564,11 @@ int gance_engine_create(const gance_engine_config* config, const float* host_wei
     e->avg_off = reserve(kDlatent);
     std::memcpy(&pool[e->avg_off], src, kDlatent * sizeof(float));
     src += kDlatent;
-    e->const_off = reserve((size_t)nf(1) * act_plane(4));  // zero-bordered [512][6][8]
+    e->const_off = reserve((size_t)nf(1) * act_plane(4));  // zero-bordered [512][6][12]
     for (int ch = 0; ch < nf(1); ++ch)
         for (int y = 0; y < 4; ++y)
             for (int x = 0; x < 4; ++x)
-                pool[e->const_off + (size_t)ch * act_plane(4) + (size_t)(y + 1) * 8 + x + 1] =
+                pool[e->const_off + (size_t)ch * act_plane(4) + (size_t)(y + 1) * 12 + x + 4] =
                     src[(size_t)ch * 16 + y * 4 + x];
     src += (size_t)nf(1) * 16;
 
@@ -551,7 +592,7 @@ int gance_engine_create(const gance_engine_config* config, const float* host_wei
         {
             // scaled HWIO weights, re-laid-out as the kernel's LDS image:
             // [m tile][K chunk][tap slot][KC][BM], slot t of an up layer = filter tap kUpTapWeight[t]
-            const int BM = layer_bm(c.cout), KC = layer_kc(c.cout);
+            const int BM = layer_bm(c.cout), KC = layer_kc(c.cout, c.up);
             const int m_tiles = c.cout / BM, chunks = c.cin / KC;
             float* w = &pool[e->conv_w[i]];
             float* w2 = &pool[e->w2_off + w2_cursor];
@@ -805,7 +846,7 @@ int gance_engine_debug_read_activation(gance_engine* engine, int32_t batch, floa
                               hipMemcpyDeviceToHost));
     for (size_t bc = 0; bc < (size_t)batch * C; ++bc)
         for (int y = 0; y < R; ++y)
-            std::memcpy(h_out + (bc * R + y) * R, &tmp[bc * act_plane(R) + (size_t)(y + 1) * (R + 4) + 1],
+            std::memcpy(h_out + (bc * R + y) * R, &tmp[bc * act_plane(R) + (size_t)(y + 1) * (R + 8) + 4],
                         R * sizeof(float));
     if (out_channels) *out_channels = C;
     if (out_side) *out_side = R;

@@ -18,7 +18,7 @@ constexpr int kEpilogueRaw = 0;   // out = acc * d            (split-K slabs, tr
 constexpr int kEpilogueFull = 1;  // out = lrelu(acc * d + noise * strength + bias) * sqrt(2)
 
 // One launch of the implicit-GEMM modulated convolution (conv_mfma.hip).
-// Activations are zero-bordered: x is [B][Cin][H+2][W+4] with the interior at [y+1][x+1].
+// Activations are zero-bordered: x is [B][Cin][H+2][W+8] with the interior at [y+1][x+4].
 struct ConvArgs {
     const float* x;
     const float* w;      // pre-arranged [m tile][K chunk][tap slot 0..8][KC][BM], runtime-scaled
@@ -38,13 +38,15 @@ struct ConvArgs {
     int epilogue;
     int out_row_stride, out_y_off, out_x_off;
     long long out_b_stride, out_c_stride, slab_stride, cls_stride;
-    long long x_b_stride;  // Cin*(H+2)*(W+4), or 0 when every sample reads the same tensor
+    long long x_b_stride;  // Cin*(H+2)*(W+8), or 0 when every sample reads the same tensor
+    unsigned long long* debug_stamps;  // [blocks][4] s_memrealtime stamps when debug_flags & 16
+    int debug_flags;       // timing ablations only (GANCE_DEBUG_CONV): 1 no stores, 2 no DMA after chunk 0, 4 no MFMA
 };
 
 struct ConvTileInfo {
     int BM, TB, TH, TW, KC, up;
 };
-constexpr int kNumConvTiles = 10;
+constexpr int kNumConvTiles = 14;
 extern const ConvTileInfo kConvTiles[kNumConvTiles];
 
 hipError_t launch_modconv(int tile_id, const ConvArgs& args, int total_blocks, hipStream_t stream);
@@ -78,7 +80,7 @@ hipError_t launch_demod(const float* s, const float* w2_pool, const DemodLayer* 
 // Conv0_up second half: 4x4 FIR ([1,3,3,1] x [1,3,3,1] / 16, pad 1/1) over the (2H+1)^2
 // intermediate held as four zero-bordered parity planes, + noise, bias, lrelu*sqrt2.
 //   t + cls*cls_stride + (split*B + b)*unit_stride + c*(H+3)*(W+8) + (y'+1)*(W+8) + x'+4
-// cls = 2*py + px. Writes the zero-bordered activation [B][C][2H+2][2W+4].
+// cls = 2*py + px. Writes the zero-bordered activation [B][C][2H+2][2W+8].
 struct FirArgs {
     const float* t;
     long long cls_stride, unit_stride;
@@ -98,7 +100,7 @@ hipError_t launch_splitk_finish(const float* slabs, long long slab_stride, int n
 
 // ToRGB (modulated 1x1, no demod) + bias + FIR-upsampled skip image; optional uint8 NHWC output.
 struct ToRgbArgs {
-    const float* x;       // zero-bordered [B][Cin][R+2][R+4]
+    const float* x;       // zero-bordered [B][Cin][R+2][R+8]
     const float* w;       // [Cin][3], runtime-scaled
     const float* s;       // s[b*s_stride + ci]
     const float* bias;    // [3]

@@ -1,0 +1,156 @@
+"""
+Read WAV files and fit them to a video: the input stage of the path.
+
+Same names, modes, error behaviour and output contract as gance/vector_sources/music.py
+(`read_wav_file` :172-209, `read_wavs_scale_for_video` :60-169, `_scale_wav_to_sample_rate`
+:212-230). Two deliberate differences:
+
+* The integer -> [-1, 1] remap is one vectorised linear map (the same `interp1d` line,
+  slope * (x - lo) + out_lo) instead of a `multiprocessing.Pool().map` over every sample
+  (vector_sources_common.py:59-61), which is seconds of pure overhead on a 30 s file.
+* Time-stretching used `resampy.resample` (kaiser_best), a third-party dependency that is not
+  available here and whose sample values no reference test pins (parity UNPINNED;
+  only the output length is pinned, test/test_vector_source_music.py:13-24). `resample_audio`
+  below is this implementation's own band-limited (Kaiser-windowed sinc) resampler with the same
+  length rule, `int(len(x) * ratio)`; it is NOT bit-compatible with resampy. When the ratio is
+  exactly 1 (the benchmark synthesises its WAV at L * fps Hz) the samples pass through unchanged.
+"""
+
+import pickle
+from pathlib import Path
+from typing import List, NamedTuple, Optional, Union
+
+import numpy as np
+from scipy.io import wavfile
+
+from gance_amd.logger_common import LOGGER
+from gance_amd.vector_sources.vector_sources_common import pad_array
+
+WavDataType = Union["np.ndarray[np.int16]", "np.ndarray[np.float32]", "np.ndarray[np.int32]"]
+
+# integer PCM ranges the reference remaps from (music.py:191-196; its int8 branch is kept as is)
+_INTEGER_RANGES = {
+    np.dtype(np.int32): (-2147483648, 2147483647),
+    np.dtype(np.int16): (-32768, 32767),
+    np.dtype(np.int8): (0, 255),
+}
+
+_SINC_ZERO_CROSSINGS = 64
+_KAISER_BETA = 14.769656459379492
+_ROLLOFF = 0.9475937167399596
+
+
+class WavFileProperties(NamedTuple):
+    """Sample rate, samples and a name (music.py:19-33)."""
+
+    sample_rate: int
+    wav_data: WavDataType
+    name: str
+
+
+def read_wav_file(wav_path: Path, convert_to_32bit_float: bool = True) -> WavFileProperties:
+    """
+    Read a `.wav`; integer PCM is mapped linearly onto [-1, 1] float32.
+    :raises ValueError: for sample formats the reference does not convert either.
+    """
+    sample_rate, wav_data = wavfile.read(str(wav_path))
+    if convert_to_32bit_float and wav_data.dtype != np.float32:
+        if wav_data.dtype not in _INTEGER_RANGES:
+            raise ValueError(
+                f"Cannot safely convert wav data to np.float32, unknown input format: {wav_data.dtype}"
+            )
+        lo, hi = _INTEGER_RANGES[wav_data.dtype]
+        slope = (1.0 - (-1.0)) / (float(hi) - float(lo))
+        wav_data = (slope * (wav_data.astype(np.float64) - lo) + (-1.0)).astype(np.float32)
+    return WavFileProperties(sample_rate=int(sample_rate), wav_data=wav_data, name=wav_path.with_suffix("").name)
+
+
+def resample_audio(samples: np.ndarray, sr_orig: float, sr_new: float) -> np.ndarray:
+    """
+    Band-limited resampling by a Kaiser-windowed sinc (64 zero crossings, beta 14.77, roll-off
+    0.9476: the published kaiser_best design). Output length int(len(samples) * sr_new / sr_orig).
+    """
+    ratio = float(sr_new) / float(sr_orig)
+    if ratio <= 0:
+        raise ValueError("sample rates must be positive")
+    count = int(samples.shape[0] * ratio)
+    if ratio == 1.0:
+        return np.array(samples[:count], copy=True)
+    x = np.asarray(samples, dtype=np.float64)
+    scale = min(1.0, ratio) * _ROLLOFF  # cut-off relative to the lower Nyquist
+    half_width = int(np.ceil(_SINC_ZERO_CROSSINGS / scale))
+    out = np.empty(count, dtype=np.float64)
+    taps = np.arange(-half_width, half_width + 1)
+    for start in range(0, count, 16384):  # bounded working set: chunk x taps
+        positions = np.arange(start, min(count, start + 16384)) / ratio
+        centre = np.floor(positions).astype(np.int64)
+        index = centre[:, None] + taps[None, :]
+        offset = (positions[:, None] - index) * scale
+        window_arg = offset / _SINC_ZERO_CROSSINGS
+        inside = np.abs(window_arg) < 1.0
+        kaiser = np.i0(_KAISER_BETA * np.sqrt(np.clip(1.0 - window_arg * window_arg, 0.0, None))) / np.i0(_KAISER_BETA)
+        kernel = np.where(inside, np.sinc(offset) * kaiser, 0.0) * scale
+        valid = (index >= 0) & (index < len(x))
+        out[start : start + len(positions)] = np.sum(np.where(valid, x[np.clip(index, 0, len(x) - 1)], 0.0) * kernel, axis=1)
+    return out.astype(samples.dtype if np.issubdtype(samples.dtype, np.floating) else np.float32)
+
+
+def _scale_wav_to_sample_rate(wav_file: WavFileProperties, new_sample_rate: float) -> WavFileProperties:
+    """Speed the audio up or slow it down; the result keeps the INPUT sample rate (music.py:212-230)."""
+    return WavFileProperties(
+        wav_data=resample_audio(wav_file.wav_data, wav_file.sample_rate, new_sample_rate),
+        sample_rate=wav_file.sample_rate,
+        name=f"{wav_file.name}_scaled",
+    )
+
+
+def read_wavs_scale_for_video(  # pylint: disable=too-many-arguments
+    wavs: Union[List[Path], List[WavFileProperties]],
+    vector_length: int,
+    frames_per_second: Optional[float] = None,
+    target_num_vectors: Optional[int] = None,
+    cache_path: Optional[Path] = None,
+    pad_to_length: bool = True,
+) -> WavFileProperties:
+    """
+    Read several WAVs, mix each to mono, concatenate, and stretch in time so that there is one
+    `vector_length` vector per video frame (FPS mode) or exactly `target_num_vectors` vectors
+    (target mode); zero-pad to a multiple of `vector_length`.
+    :raises ValueError: both or neither mode given; differing sample rates.
+    """
+    if frames_per_second is not None and target_num_vectors is not None:
+        raise ValueError("Can't use both FPS mode and target vector count mode.")
+    if frames_per_second is None and target_num_vectors is None:
+        raise ValueError("Need to use FPS mode or target vector count mode.")
+    if cache_path is not None and cache_path.exists():
+        LOGGER.info("Cached audio found. Loading.")
+        with open(str(cache_path), "rb") as read_file:
+            cached: WavFileProperties = pickle.load(read_file)
+        return cached
+
+    input_wavs = [read_wav_file(wav) if isinstance(wav, Path) else wav for wav in wavs]
+    sample_rates = {wav.sample_rate for wav in input_wavs}
+    if len(sample_rates) != 1:
+        raise ValueError("Multiple sample rates for input audio files is unsupported.")
+    sample_rate = next(iter(sample_rates))
+    mono = np.concatenate([wav.wav_data.mean(axis=1) if wav.wav_data.ndim > 1 else wav.wav_data for wav in input_wavs])
+    name = "_".join(wav.name for wav in input_wavs) + "_mono"
+    num_samples = mono.shape[0]
+
+    if frames_per_second is not None:
+        # sr * (L * fps * duration) / samples, truncated exactly like music.py:127-132
+        scaled_sample_rate: float = int(
+            sample_rate * (vector_length * (frames_per_second * (num_samples / sample_rate))) / num_samples
+        )
+    else:
+        scaled_sample_rate = float(sample_rate) * (target_num_vectors / (num_samples / vector_length))
+
+    scaled = _scale_wav_to_sample_rate(WavFileProperties(sample_rate, mono, name), scaled_sample_rate)
+    data = scaled.wav_data
+    if pad_to_length:
+        data = pad_array(data, int(np.ceil(data.shape[0] / vector_length) * vector_length))
+    output = WavFileProperties(wav_data=data, sample_rate=sample_rate, name=f"{scaled.name}_padded")
+    if cache_path is not None:
+        with open(str(cache_path), "wb") as write_file:
+            pickle.dump(output, write_file)
+    return output

@@ -1,0 +1,83 @@
+"""
+CPU tests of the WAV input stage. Mirrors test/test_vector_source_music.py:13-24
+(output length for several stretch factors) and adds what the reference leaves unpinned.
+"""
+
+from pathlib import Path
+
+import numpy as np
+import pytest
+from scipy.io import wavfile
+
+from gance_amd import synthetic
+from gance_amd.vector_sources import music
+
+
+@pytest.mark.parametrize("multiplier", [2, 1.5, 0.3, 0.1, 10])
+def test_scaled_length_follows_the_reference_rule(multiplier: float) -> None:
+    wav = music.WavFileProperties(44100, synthetic.synthetic_audio(8, 512, seed=1), "synthetic")
+    scaled = music._scale_wav_to_sample_rate(wav, int(wav.sample_rate * multiplier))  # pylint: disable=protected-access
+    assert len(scaled.wav_data) == int(len(wav.wav_data) * int(wav.sample_rate * multiplier) / wav.sample_rate)
+    assert scaled.sample_rate == wav.sample_rate and scaled.wav_data.dtype == np.float32
+
+
+def test_resampler_preserves_a_tone_and_is_identity_at_ratio_one() -> None:
+    rate, tone = 8000, 440.0
+    t = np.arange(8000) / rate
+    x = np.sin(2 * np.pi * tone * t).astype(np.float32)
+    assert np.array_equal(music.resample_audio(x, rate, rate), x)
+    for new_rate in (12000, 5000):
+        y = music.resample_audio(x, rate, new_rate)
+        want = np.sin(2 * np.pi * tone * np.arange(len(y)) / new_rate)
+        inner = slice(200, len(y) - 200)  # away from the zero-padded ends
+        assert np.abs(y[inner] - want[inner]).max() < 2e-3
+    # a tone above the new Nyquist is removed, not aliased
+    high = np.sin(2 * np.pi * 3500.0 * t).astype(np.float32)
+    assert np.abs(music.resample_audio(high, rate, 4000)[100:-100]).max() < 5e-3
+
+
+def _write(path: Path, rate: int, data: np.ndarray) -> Path:
+    wavfile.write(str(path), rate, data)
+    return path
+
+
+def test_read_wav_file_remaps_integers_to_unit_floats(tmp_path: Path) -> None:
+    ramp16 = np.array([-32768, -16384, 0, 16383, 32767], dtype=np.int16)
+    got = music.read_wav_file(_write(tmp_path / "a.wav", 22050, ramp16))
+    assert got.sample_rate == 22050 and got.name == "a" and got.wav_data.dtype == np.float32
+    np.testing.assert_allclose(got.wav_data, np.interp(ramp16.astype(float), [-32768, 32767], [-1, 1]), atol=1e-7)
+    ramp32 = np.array([-2147483648, 0, 2147483647], dtype=np.int32)
+    np.testing.assert_allclose(music.read_wav_file(_write(tmp_path / "b.wav", 8000, ramp32)).wav_data, [-1, 0, 1], atol=1e-6)
+    floats = np.linspace(-0.5, 0.5, 7, dtype=np.float32)
+    assert np.array_equal(music.read_wav_file(_write(tmp_path / "c.wav", 8000, floats)).wav_data, floats)
+    raw = music.read_wav_file(_write(tmp_path / "d.wav", 8000, ramp16), convert_to_32bit_float=False)
+    assert raw.wav_data.dtype == np.int16
+    with pytest.raises(ValueError, match="unknown input format"):
+        music.read_wav_file(_write(tmp_path / "e.wav", 8000, np.zeros(4, dtype=np.uint8)))
+
+
+def test_scale_for_video_modes_padding_mono_and_errors(tmp_path: Path) -> None:
+    L, rate = 512, 30720
+    stereo = np.stack([np.full(rate, 8192, dtype=np.int16), np.full(rate, -8192, dtype=np.int16)], axis=1)
+    mono = (np.sin(np.arange(rate) / 20.0) * 20000).astype(np.int16)
+    paths = [_write(tmp_path / "s.wav", rate, stereo), _write(tmp_path / "m.wav", rate, mono)]
+    # 2 s at 60 fps and L * fps == rate: exactly 120 vectors, untouched samples
+    by_fps = music.read_wavs_scale_for_video(paths, L, frames_per_second=60.0)
+    assert by_fps.wav_data.shape == (120 * L,) and by_fps.sample_rate == rate and by_fps.name == "s_m_mono_scaled_padded"
+    np.testing.assert_allclose(by_fps.wav_data[:rate], 0.0, atol=2e-5)  # stereo halves cancel in the mono mix
+    by_count = music.read_wavs_scale_for_video(paths, L, target_num_vectors=90)
+    assert by_count.wav_data.shape == (90 * L,)
+    unpadded = music.read_wavs_scale_for_video(paths[1:], L, target_num_vectors=7, pad_to_length=False)
+    assert len(unpadded.wav_data) == 7 * L
+    cache = tmp_path / "cache.p"
+    first = music.read_wavs_scale_for_video(paths, L, target_num_vectors=30, cache_path=cache)
+    assert cache.exists()
+    again = music.read_wavs_scale_for_video([], L, target_num_vectors=30, cache_path=cache)  # served from the cache
+    assert np.array_equal(first.wav_data, again.wav_data)
+    with pytest.raises(ValueError, match="both FPS mode"):
+        music.read_wavs_scale_for_video(paths, L, frames_per_second=60, target_num_vectors=3)
+    with pytest.raises(ValueError, match="Need to use FPS mode"):
+        music.read_wavs_scale_for_video(paths, L)
+    other = _write(tmp_path / "o.wav", 8000, mono)
+    with pytest.raises(ValueError, match="Multiple sample rates"):
+        music.read_wavs_scale_for_video([paths[0], other], L, frames_per_second=60)
