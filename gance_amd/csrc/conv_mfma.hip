@@ -71,7 +71,7 @@ __host__ __device__ constexpr int shift_dx(int s) {
     return UP ? ((s & 1) ? -1 : 0) : s % 3 - 1;
 }
 
-template <int BM, int TB, int TH, int TW, int KC, int WM, int WN, bool UP, int NBUF>
+template <int BM, int TB, int TH, int TW, int KC, int WM, int WN, bool UP, int NBUF, bool RT = false>
 struct ConvTile {
     static constexpr int kBN = TB * TH * TW;
     static constexpr int kMT = BM / (32 * WM);
@@ -79,10 +79,12 @@ struct ConvTile {
     static constexpr int kCls = UP ? 4 : 1;
     static constexpr int kShifts = UP ? 4 : 9;
     static constexpr int kPH = UP ? TH + 1 : TH + 2;
-    static constexpr int kPW = UP ? TW + 4 : TW + 8;  // image cols x0-4 .. (no right halo when UP)
+    static constexpr int kPW = UP ? (TW + 7) / 4 * 4 : TW + 8;  // image cols x0-4 .. (no right halo when UP)
     static constexpr int kPlane = kPH * kPW;
     static constexpr int kWlFloats = 9 * KC * BM;
-    static constexpr int kPlFloats = TB * KC * kPlane;
+    // RT: per-block runtime tile geometry (8x8 main tile, 1x64 row strip, 64x1 column strip of a
+    // transposed conv); the patch region is sized for the largest, the 65 x 8 column-strip patch
+    static constexpr int kPlFloats = RT ? KC * 65 * 8 : TB * KC * kPlane;
     static constexpr int kWlInstr = (kWlFloats + 255) / 256;      // 1 KiB DMA pieces (last may be partial)
     static constexpr int kWlRegion = kWlInstr * 256;              // patch region starts piece-aligned
     static constexpr int kPlF4 = kPlFloats / 4;
@@ -93,19 +95,20 @@ struct ConvTile {
     static_assert(KC % 2 == 0 && kWlFloats % 4 == 0 && kPlFloats % 4 == 0, "DMA pieces");
     // every wave issues the same number of DMA pieces per chunk (the counted vmcnt needs that);
     // when the piece count is not a multiple of 4 the spare slots re-issue piece 0 (same bytes)
-    static constexpr int kPieces = kWlInstr + kPlInstr;
+    static constexpr int kPieces = RT ? kWlInstr : kWlInstr + kPlInstr;
     static constexpr int kPiecesPerWave = (kPieces + 3) / 4;
     static_assert(NBUF == 2 || NBUF == 3, "ring depth");
+    static_assert(!RT || (UP && TB == 1 && kBN == 64 && NBUF == 2), "runtime geometry: 64-position up tiles");
     // dynamic LDS: NBUF staging buffers + style [TB][Cin] + demod [TB][BM] + bias [BM]
     static size_t lds_bytes(int cin) {
         return sizeof(float) * (NBUF * (size_t)kBufFloats + (size_t)TB * cin + (size_t)TB * BM + BM);
     }
 };
 
-template <int BM, int TB, int TH, int TW, int KC, int WM, int WN, bool UP, int NBUF>
+template <int BM, int TB, int TH, int TW, int KC, int WM, int WN, bool UP, int NBUF, bool RT>
 __global__ __launch_bounds__(256, UP ? 2 : 4) void modconv_mfma_kernel(const ConvArgs p) {
-    using T = ConvTile<BM, TB, TH, TW, KC, WM, WN, UP, NBUF>;
-    constexpr int MT = T::kMT, NT = T::kNT, PH = T::kPH, PW = T::kPW, PLANE = T::kPlane;
+    using T = ConvTile<BM, TB, TH, TW, KC, WM, WN, UP, NBUF, RT>;
+    constexpr int MT = T::kMT, NT = T::kNT, PH = T::kPH, PW = T::kPW;
     constexpr int NCLS = T::kCls;
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -142,15 +145,47 @@ __global__ __launch_bounds__(256, UP ? 2 : 4) void modconv_mfma_kernel(const Con
     id /= p.m_tiles;
     const int split = id % p.nsplit;
     id /= p.nsplit;
-    const int tile_x = id % p.tiles_x;
-    id /= p.tiles_x;
-    const int tile_y = id % p.tiles_y;
-    const int tile_b = id / p.tiles_y;
+    // tile geometry: compile-time, or (RT) chosen per block
+    int y0, x0, tile_b;
+    int tw_log2 = 0, th_r = TH, PHr = PH, PWr = PW;
+    if (RT) {
+        const int main_tiles = p.tiles_x * p.tiles_y;
+        const int tiles_total = main_tiles + p.row_tiles + p.col_tiles;
+        const int t = id % tiles_total;
+        tile_b = id / tiles_total;
+        if (t < main_tiles) {  // TH x TW tile of the exactly-tiled H x W position grid
+            y0 = (t / p.tiles_x) * TH;
+            x0 = (t % p.tiles_x) * TW;
+            tw_log2 = 3;
+            static_assert(!RT || (TH == 8 && TW == 8), "RT main tile is 8x8");
+        } else if (t < main_tiles + p.row_tiles) {  // 1 x 64 on the position row y' = H
+            y0 = p.H;
+            x0 = (t - main_tiles) * 64;
+            tw_log2 = 6;
+            th_r = 1;
+            PHr = 2;
+            PWr = 68;
+        } else {  // 64 x 1 on the position column x' = W
+            y0 = (t - main_tiles - p.row_tiles) * 64;
+            x0 = p.W;
+            tw_log2 = 0;
+            th_r = 64;
+            PHr = 65;
+            PWr = 8;
+        }
+    } else {
+        const int tile_x = id % p.tiles_x;
+        id /= p.tiles_x;
+        const int tile_y = id % p.tiles_y;
+        tile_b = id / p.tiles_y;
+        y0 = tile_y * TH;
+        x0 = tile_x * TW;
+    }
+    const int PLANEr = PHr * PWr;
+    (void)th_r;
 
     const int m0 = m_tile * BM;
     const int b0 = tile_b * TB;
-    const int y0 = tile_y * TH;
-    const int x0 = tile_x * TW;
     const int Hp = p.H + 2, Wp = p.W + 8;
 
     // ---- LDS-DMA staging: `buffer_load_dwordx4 ... lds` (MUBUF). The FLAT-encoded
@@ -160,6 +195,30 @@ __global__ __launch_bounds__(256, UP ? 2 : 4) void modconv_mfma_kernel(const Con
         (void*)(p.w + ((size_t)m_tile * p.total_chunks) * T::kWlFloats), 0, 0x7fffffff, 0x00020000);
     const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc(
         (void*)(p.x + (size_t)min(b0, p.B - 1) * p.x_b_stride), 0, 0x7fffffff, 0x00020000);
+    // RT: the patch image is [KC][PHr][PWr/4] float4s; a wave's pieces are i = wave, wave+4, ...
+    // (at most 3); their per-lane source offsets are computed once, a chunk only adds its plane offset
+    int rt_off[3] = {0, 0, 0};
+    int rt_pieces = 0;
+    if (RT) {
+        const int f4_total = KC * PLANEr / 4;
+        rt_pieces = (f4_total + 63) / 64;
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const int i = wave + 4 * r;
+            const int f = i * 64 + lane;
+            rt_off[r] = -1;
+            if (i < rt_pieces && f < f4_total) {
+                const int q4 = PWr / 4;
+                const int q = f % q4;
+                int rr = f / q4;
+                const int py = rr % PHr;
+                const int c = rr / PHr;
+                const int gy = min(y0 + py, Hp - 1);
+                const int gx = min(x0 + 4 * q, Wp - 4);
+                rt_off[r] = ((c * Hp + gy) * Wp + gx) * 4;
+            }
+        }
+    }
     auto stage = [&](int chunk, float* buf) {
         const int wbase = chunk * T::kWlFloats;
         const int ci0 = chunk * KC;
@@ -172,7 +231,7 @@ __global__ __launch_bounds__(256, UP ? 2 : 4) void modconv_mfma_kernel(const Con
                 if (g * 256 + lane * 4 < T::kWlFloats)
                     __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, (lds_ptr_t)(buf + g * 256), 16,
                                                              (wbase + g * 256 + lane * 4) * 4, 0, 0, 0);
-            } else {
+            } else if (!RT) {
                 const int i = g - T::kWlInstr;
                 const int f = min(i * 64 + lane, T::kPlF4 - 1);  // tail lanes repeat the last float4
                 // float4 index f of the patch image [TB][KC][PH][PW/4] -> source address
@@ -191,6 +250,16 @@ __global__ __launch_bounds__(256, UP ? 2 : 4) void modconv_mfma_kernel(const Con
                                                              (int)(off * 4), 0, 0, 0);
             }
         }
+        if (RT) {
+            const int chunk_off = ci0 * Hp * Wp * 4;
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+                const int i = wave + 4 * r;
+                if (i < rt_pieces && rt_off[r] >= 0)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(x_rsrc, (lds_ptr_t)(pl + i * 256), 16,
+                                                             rt_off[r] + chunk_off, 0, 0, 0);
+            }
+        }
     };
 
     // ---- per-lane operand offsets ----
@@ -199,10 +268,10 @@ __global__ __launch_bounds__(256, UP ? 2 : 4) void modconv_mfma_kernel(const Con
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
         const int n = (wn * NT + j) * 32 + l31;
-        const int tb = n / (TH * TW);
-        const int yy = (n / TW) % TH;
-        const int xx = n % TW;
-        boff[j] = (tb * KC + lh) * PLANE + (yy + 1) * PW + (xx + 4);
+        const int tb = RT ? 0 : n / (TH * TW);
+        const int yy = RT ? (n >> tw_log2) : (n / TW) % TH;
+        const int xx = RT ? (n & ((1 << tw_log2) - 1)) : n % TW;
+        boff[j] = (tb * KC + lh) * PLANEr + (yy + 1) * PWr + (xx + 4);
         stb[j] = tb * p.Cin + lh;
     }
     const int aoff = lh * BM + wm * (MT * 32) + l31;
@@ -295,7 +364,7 @@ __global__ __launch_bounds__(256, UP ? 2 : 4) void modconv_mfma_kernel(const Con
         auto load_b = [&](int kk, int shift, float (&dst)[NT]) {
 #pragma unroll
             for (int j = 0; j < NT; ++j) {
-                dst[j] = Pl[boff[j] + (2 * kk) * PLANE + shift_dy<UP>(shift) * PW + shift_dx<UP>(shift)];
+                dst[j] = Pl[boff[j] + (2 * kk) * PLANEr + shift_dy<UP>(shift) * PWr + shift_dx<UP>(shift)];
                 if (TB > 1) dst[j] *= s_lds[stb[j] + ci0 + 2 * kk];
             }
         };
@@ -361,9 +430,9 @@ __global__ __launch_bounds__(256, UP ? 2 : 4) void modconv_mfma_kernel(const Con
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
             const int n = (wn * NT + j) * 32 + l31;
-            const int tb = n / (TH * TW);
-            const int oy = y0 + (n / TW) % TH;
-            const int ox = x0 + n % TW;
+            const int tb = RT ? 0 : n / (TH * TW);
+            const int oy = y0 + (RT ? (n >> tw_log2) : (n / TW) % TH);
+            const int ox = x0 + (RT ? (n & ((1 << tw_log2) - 1)) : n % TW);
             const int b = b0 + tb;
             const bool in_batch = b < p.B;
             if (TB > 1) load_consts(tb);
@@ -406,10 +475,10 @@ __global__ __launch_bounds__(256, UP ? 2 : 4) void modconv_mfma_kernel(const Con
     }
 }
 
-template <int BM, int TB, int TH, int TW, int KC, int WM, int WN, bool UP, int NBUF>
+template <int BM, int TB, int TH, int TW, int KC, int WM, int WN, bool UP, int NBUF, bool RT = false>
 static hipError_t launch_one(const ConvArgs& a, int total_blocks, hipStream_t stream) {
-    using T = ConvTile<BM, TB, TH, TW, KC, WM, WN, UP, NBUF>;
-    auto kernel = modconv_mfma_kernel<BM, TB, TH, TW, KC, WM, WN, UP, NBUF>;
+    using T = ConvTile<BM, TB, TH, TW, KC, WM, WN, UP, NBUF, RT>;
+    auto kernel = modconv_mfma_kernel<BM, TB, TH, TW, KC, WM, WN, UP, NBUF, RT>;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
@@ -432,8 +501,8 @@ const ConvTileInfo kConvTiles[kNumConvTiles] = {
     {128, 8, 4, 4, 4, 0},   // 5
     {32, 1, 16, 16, 8, 1},  // 6: transposed, Cout = 32
     {64, 1, 8, 16, 8, 1},   // 7: transposed, Cout = 64
-    {128, 1, 8, 8, 4, 1},   // 8: transposed, Cout >= 128
-    {128, 1, 4, 16, 4, 1},  // 9
+    {128, 1, 8, 8, 4, 1},   // 8: transposed, Cout >= 128: runtime geometry (8x8 + edge strips)
+    {128, 1, 4, 16, 4, 1},  // 9: unused
     {32, 1, 8, 64, 4, 0},   // 10: as 0 with KC = 4 (more blocks per CU)
     {64, 1, 4, 64, 4, 0},   // 11: as 1 with KC = 4
     {32, 1, 16, 16, 4, 1},  // 12: as 6 with KC = 4
@@ -441,12 +510,11 @@ const ConvTileInfo kConvTiles[kNumConvTiles] = {
 };
 
 hipError_t launch_modconv(int tile_id, const ConvArgs& a, int total_blocks, hipStream_t stream) {
-    // ring depth 2 (measured faster: depth 3 costs a block per CU); GANCE_TUNE_NBUF=3 for experiments
-    static const bool deep = [] { const char* v = std::getenv("GANCE_TUNE_NBUF"); return v && std::atoi(v) == 3; }();
-#define GANCE_CASE(id, ...)                                                                   \
-    case id:                                                                                  \
-        return deep ? launch_one<__VA_ARGS__, 3>(a, total_blocks, stream)                     \
-                    : launch_one<__VA_ARGS__, 2>(a, total_blocks, stream);
+    // ring depth 2: depth 3 (prefetch distance 2, template parameter NBUF) measured slower, it costs
+    // a resident block per CU and DMA latency is already covered
+#define GANCE_CASE(id, ...) \
+    case id:               \
+        return launch_one<__VA_ARGS__, 2>(a, total_blocks, stream);
     switch (tile_id) {
         GANCE_CASE(0, 32, 1, 8, 64, 8, 1, 4, false)
         GANCE_CASE(1, 64, 1, 4, 64, 8, 1, 4, false)
@@ -456,7 +524,7 @@ hipError_t launch_modconv(int tile_id, const ConvArgs& a, int total_blocks, hipS
         GANCE_CASE(5, 128, 8, 4, 4, 4, 2, 2, false)
         GANCE_CASE(6, 32, 1, 16, 16, 8, 1, 4, true)
         GANCE_CASE(7, 64, 1, 8, 16, 8, 2, 2, true)
-        GANCE_CASE(8, 128, 1, 8, 8, 4, 4, 1, true)
+        case 8: return launch_one<128, 1, 8, 8, 4, 4, 1, true, 2, true>(a, total_blocks, stream);
         GANCE_CASE(9, 128, 1, 4, 16, 4, 4, 1, true)
         GANCE_CASE(10, 32, 1, 8, 64, 4, 1, 4, false)
         GANCE_CASE(11, 64, 1, 4, 64, 4, 1, 4, false)

@@ -93,12 +93,15 @@ int ilog2_exact(int v) {
     return (1 << l) == v ? l : -1;
 }
 
-// One launch of the conv kernel: a stride-1 conv, or a transposed conv with its four parity
-// classes fused (grid of (H+1) x (W+1) input-grid positions).
+// One launch of the conv kernel: a stride-1 conv, or a transposed conv with its four parity classes
+// fused. Wide transposed convs (BM = 128) tile the H x W position grid exactly with 8x8 tiles and
+// cover the extra position row y' = H / column x' = W with 1x64 / 64x1 strip tiles in the SAME
+// launch (runtime tile geometry); the narrow ones tile the (H+1) x (W+1) grid directly.
 struct LayerPlan {
     int tile_id;
-    int OH, OW;
-    int tiles_x, tiles_y, tiles_b, m_tiles, nsplit, chunks_per_split, total_chunks, total_blocks;
+    int OH, OW;  // output bound for masking: H x W, or (H+1) x (W+1) positions when up
+    int tiles_x, tiles_y, tiles_b, row_tiles, col_tiles;
+    int m_tiles, nsplit, chunks_per_split, total_chunks, total_blocks;
 };
 
 int ceil_div(int a, int b) { return (a + b - 1) / b; }
@@ -106,19 +109,18 @@ int ceil_div(int a, int b) { return (a + b - 1) / b; }
 int layer_bm(int cout) { return cout == 32 ? 32 : (cout == 64 ? 64 : 128); }
 
 // K chunk (input channels per LDS stage) of the narrow layers. Tunable for experiments:
-// GANCE_TUNE_KC_CONV / GANCE_TUNE_KC_UP = 4 or 8 (read once).
+// GANCE_TUNE_KC_CONV = 4 or 8 (read once). Transposed convs use 8.
 int tuned_kc(bool up) {
     static const int conv_kc = [] { const char* v = std::getenv("GANCE_TUNE_KC_CONV"); return v && std::atoi(v) == 8 ? 8 : 4; }();
-    static const int up_kc = [] { const char* v = std::getenv("GANCE_TUNE_KC_UP"); return v && std::atoi(v) == 4 ? 4 : 8; }();
-    return up ? up_kc : conv_kc;
+    return up ? 8 : conv_kc;
 }
 int layer_kc(int cout, bool up) { return layer_bm(cout) == 128 ? 4 : tuned_kc(up); }
 
 int choose_tile(int cout, bool up, int OH, int OW, int B) {
     const bool kc4 = tuned_kc(up) == 4;
-    if (cout == 32) return up ? (kc4 ? 12 : 6) : (kc4 ? 10 : 0);
-    if (cout == 64) return up ? (kc4 ? 13 : 7) : (kc4 ? 11 : 1);
-    const int first = up ? 8 : 2, last = up ? 9 : 5;
+    if (cout == 32) return up ? 6 : (kc4 ? 10 : 0);
+    if (cout == 64) return up ? 7 : (kc4 ? 11 : 1);
+    const int first = up ? 8 : 2, last = up ? 8 : 5;
     int best = first;
     long best_tiles = -1;
     for (int id = first; id <= last; ++id) {
@@ -143,15 +145,21 @@ int choose_nsplit(int base_blocks, int chunks) {
 LayerPlan plan_layer(const ConvLayerHost& c, int B) {
     LayerPlan p{};
     const int res = 1 << c.res_log2;
+    // strips pay once the position grid has several tiles per side; below that the launch is
+    // latency-bound and extra blocks only hurt
+    const bool strips = c.up && layer_bm(c.cout) == 128 && res / 2 >= 16;
+    const int grid = c.up ? (strips ? res / 2 : res / 2 + 1) : res;  // the tiled grid
     p.OH = p.OW = c.up ? res / 2 + 1 : res;
-    p.tile_id = choose_tile(c.cout, c.up, p.OH, p.OW, B);
+    p.tile_id = choose_tile(c.cout, c.up, grid, grid, B);
     const auto& t = gance::kConvTiles[p.tile_id];
-    p.tiles_x = ceil_div(p.OW, t.TW);
-    p.tiles_y = ceil_div(p.OH, t.TH);
+    p.tiles_x = ceil_div(grid, t.TW);
+    p.tiles_y = ceil_div(grid, t.TH);
     p.tiles_b = ceil_div(B, t.TB);
+    p.row_tiles = strips ? ceil_div(res / 2 + 1, 64) : 0;
+    p.col_tiles = strips ? ceil_div(res / 2, 64) : 0;
     p.m_tiles = c.cout / t.BM;
     p.total_chunks = c.cin / t.KC;
-    const int base = p.m_tiles * p.tiles_x * p.tiles_y * p.tiles_b;
+    const int base = p.m_tiles * (p.tiles_x * p.tiles_y + p.row_tiles + p.col_tiles) * p.tiles_b;
     p.nsplit = choose_nsplit(base, p.total_chunks);
     if (c.up) p.nsplit = std::min(p.nsplit, 8);  // the FIR pass re-reads every slab
     while (p.total_chunks % p.nsplit) --p.nsplit;
@@ -294,6 +302,8 @@ int run_conv(gance_engine* e, const ConvLayerHost& c, int li, const LayerPlan& p
     a.noise_strength = e->conv_ns[li];
     a.tiles_x = p.tiles_x;
     a.tiles_y = p.tiles_y;
+    a.row_tiles = p.row_tiles;
+    a.col_tiles = p.col_tiles;
     a.m_tiles = p.m_tiles;
     a.nsplit = p.nsplit;
     a.chunks_per_split = p.chunks_per_split;

@@ -34,6 +34,9 @@ struct ConvArgs {
     int s_stride, d_stride;
     float noise_strength;
     int tiles_x, tiles_y, m_tiles;
+    // runtime-geometry launches (transposed conv, BM = 128): after the tiles_x*tiles_y main tiles
+    // come row_tiles 1x64 tiles on the position row y' = H and col_tiles 64x1 tiles on x' = W
+    int row_tiles, col_tiles;
     int nsplit, chunks_per_split, total_chunks;
     int epilogue;
     int out_row_stride, out_y_off, out_x_off;
