@@ -53,6 +53,22 @@ def usable_cores() -> int:
     return max(1, cores)
 
 
+def measured_traffic(kernel_name: str, resolution: int, batch: int):
+    """
+    HBM bytes per launch of the dominant kernel from the committed PMC pass (rocprofv3 cannot run
+    inside this process): profiles/traffic_latest.json, only if it was taken on this workload.
+    """
+    path = REPO_ROOT / "profiles" / "traffic_latest.json"
+    try:
+        record = json.loads(path.read_text())
+    except (OSError, ValueError):
+        return None
+    workload = record.get("workload", {})
+    if workload.get("resolution") != resolution or workload.get("frames_per_step_per_gpu") != batch:
+        return None
+    return record.get("hbm_bytes_per_launch")
+
+
 def cpu_baseline(resolution: int, variables, budget_seconds: float = 15.0) -> dict:
     """Time the CPU oracle (checker infrastructure, used here only as the reported baseline)."""
     from oracle import stylegan2_ref  # pylint: disable=import-outside-toplevel
@@ -201,7 +217,8 @@ def main() -> int:
                 "peak": FP32_MFMA_PEAK_TFLOPS,
                 "unit": "TFLOP/s",
                 "frac": round(dominant.flops / (dominant.ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4),
-                "traffic": None,
+                "traffic": measured_traffic(dominant.name, resolution, batch),
+                "traffic_note": "HBM bytes per launch from profiles/traffic_latest.json (2*FETCH_SIZE + WRITE_SIZE, separate --pmc passes); algorithmic bytes per launch = %d" % int(dominant.bytes),
                 "all_conv_launches": {
                     "achieved": round(conv_flops / (conv_ms * 1e-3) / 1e12, 3),
                     "frac": round(conv_flops / (conv_ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4),

@@ -408,8 +408,86 @@ __global__ __launch_bounds__(256) void torgb_kernel(const ToRgbArgs p) {
     }
 }
 
+// Small resolutions (R <= 128): the per-pixel loop over Cin = 256..512 channels is a long serial
+// chain and there are too few pixels to fill the chip, so the channel sum is split 8 ways across
+// the threads of a block (32 pixels x 8 channel slices) and reduced through LDS.
+__global__ __launch_bounds__(256) void torgb_small_kernel(const ToRgbArgs p) {
+    __shared__ float coef[512 * 3];
+    __shared__ float red[8][3][32];
+    const int tid = threadIdx.x;
+    const int b = blockIdx.y;
+    for (int i = tid; i < p.Cin * 3; i += 256)
+        coef[i] = p.s[(size_t)b * p.s_stride + i / 3] * p.w[i];
+    __syncthreads();
+    const int R = p.R;
+    const int npix = R * R;
+    const int pix = blockIdx.x * 32 + (tid & 31);
+    const int slice = tid >> 5;
+    const bool live = pix < npix;
+    const int oy = live ? pix / R : 0, ox = live ? pix % R : 0;
+    const size_t xplane = (size_t)(R + 2) * (R + 8);
+    const float* xp = p.x + (size_t)b * p.Cin * xplane + (size_t)(oy + 1) * (R + 8) + ox + 4;
+    const int per_slice = p.Cin / 8;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+    if (live) {
+#pragma unroll 4
+        for (int k = 0; k < per_slice; ++k) {
+            const int ci = slice * per_slice + k;
+            const float v = xp[(size_t)ci * xplane];
+            a0 = fmaf(v, coef[ci * 3 + 0], a0);
+            a1 = fmaf(v, coef[ci * 3 + 1], a1);
+            a2 = fmaf(v, coef[ci * 3 + 2], a2);
+        }
+    }
+    red[slice][0][tid & 31] = a0;
+    red[slice][1][tid & 31] = a1;
+    red[slice][2][tid & 31] = a2;
+    __syncthreads();
+    if (slice != 0 || !live) return;
+    float acc[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        float sum = 0.f;
+#pragma unroll
+        for (int sl = 0; sl < 8; ++sl) sum += red[sl][c][tid];
+        acc[c] = sum + p.bias[c];
+    }
+    if (p.y_prev != nullptr) {
+        const int Rh = R >> 1;
+        const int ya = (oy & 1) ? (oy >> 1) : (oy >> 1) - 1, yb = ya + 1;
+        const int xa = (ox & 1) ? (ox >> 1) : (ox >> 1) - 1, xb = xa + 1;
+        const float wya = (oy & 1) ? 0.75f : 0.25f, wyb = 1.0f - wya;
+        const float wxa = (ox & 1) ? 0.75f : 0.25f, wxb = 1.0f - wxa;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float* yp = p.y_prev + ((size_t)b * 3 + c) * Rh * Rh;
+            auto at = [&](int yy, int xx) -> float {
+                return (yy >= 0 && yy < Rh && xx >= 0 && xx < Rh) ? yp[(size_t)yy * Rh + xx] : 0.f;
+            };
+            const float top = wxa * at(ya, xa) + wxb * at(ya, xb);
+            const float bot = wxa * at(yb, xa) + wxb * at(yb, xb);
+            acc[c] += wya * top + wyb * bot;
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) p.y[((size_t)b * 3 + c) * npix + pix] = acc[c];
+    if (p.u8 != nullptr) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            float v = __fadd_rn(__fmul_rn(acc[c], 127.5f), 128.0f);
+            v = fminf(fmaxf(v, 0.f), 255.f);
+            p.u8[((size_t)b * npix + pix) * 3 + c] = (uint8_t)(int)v;
+        }
+    }
+}
+
 hipError_t launch_torgb(const ToRgbArgs& args, hipStream_t stream) {
     const size_t npix = (size_t)args.R * args.R;
+    if (args.R <= 128 && args.Cin % 8 == 0) {
+        hipLaunchKernelGGL(torgb_small_kernel, dim3((unsigned)((npix + 31) / 32), args.B), dim3(256), 0,
+                           stream, args);
+        return hipGetLastError();
+    }
     hipLaunchKernelGGL(torgb_kernel, dim3((unsigned)((npix / 4 + 255) / 256), args.B), dim3(256),
                        0, stream, args);
     return hipGetLastError();
