@@ -493,4 +493,68 @@ hipError_t launch_torgb(const ToRgbArgs& args, hipStream_t stream) {
     return hipGetLastError();
 }
 
+// ------------------------------------------------------------------------------------------
+// Post-synthesis resize: bicubic, a = -0.75, uint8 RGB NHWC
+// ------------------------------------------------------------------------------------------
+// Replaces cv2.resize(image, (side, side), interpolation=cv2.INTER_CUBIC) of
+// gance/image_sources/video_common.py:399-429. OpenCV's uint8 path uses 11-bit fixed-point
+// coefficients; this implementation DEFINES the float form of the same filter: source coordinate
+// (d + 0.5) * src/dst - 0.5, four taps per axis with the Keys kernel a = -0.75, replicated
+// border, float32 accumulation, round half up, saturate. Parity with OpenCV is unpinned (cv2 is
+// not available); the oracle is oracle/resize_ref.py.
+
+__device__ __forceinline__ void cubic_weights(float t, float (&w)[4]) {
+    const float a = -0.75f;
+    w[0] = ((a * (t + 1.f) - 5.f * a) * (t + 1.f) + 8.f * a) * (t + 1.f) - 4.f * a;
+    w[1] = ((a + 2.f) * t - (a + 3.f)) * t * t + 1.f;
+    w[2] = ((a + 2.f) * (1.f - t) - (a + 3.f)) * (1.f - t) * (1.f - t) + 1.f;
+    w[3] = 1.f - w[0] - w[1] - w[2];
+}
+
+__global__ __launch_bounds__(256) void resize_bicubic_u8_kernel(const uint8_t* __restrict__ in, int src,
+                                                                uint8_t* __restrict__ out, int dst,
+                                                                size_t total) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int ox = (int)(i % dst);
+    const int oy = (int)((i / dst) % dst);
+    const size_t b = i / ((size_t)dst * dst);
+    const float scale = (float)src / (float)dst;
+    const float fy = ((float)oy + 0.5f) * scale - 0.5f;
+    const float fx = ((float)ox + 0.5f) * scale - 0.5f;
+    const int iy = (int)floorf(fy), ix = (int)floorf(fx);
+    float wy[4], wx[4];
+    cubic_weights(fy - (float)iy, wy);
+    cubic_weights(fx - (float)ix, wx);
+    float acc[3] = {0.f, 0.f, 0.f};
+    const uint8_t* img = in + b * (size_t)src * src * 3;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int yy = min(max(iy - 1 + r, 0), src - 1);
+        float row[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int xx = min(max(ix - 1 + c, 0), src - 1);
+            const uint8_t* px = img + ((size_t)yy * src + xx) * 3;
+            row[0] += wx[c] * (float)px[0];
+            row[1] += wx[c] * (float)px[1];
+            row[2] += wx[c] * (float)px[2];
+        }
+        acc[0] += wy[r] * row[0];
+        acc[1] += wy[r] * row[1];
+        acc[2] += wy[r] * row[2];
+    }
+    uint8_t* o = out + i * 3;
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch) o[ch] = (uint8_t)(int)fminf(fmaxf(floorf(acc[ch] + 0.5f), 0.f), 255.f);
+}
+
+hipError_t launch_resize_bicubic_u8(const uint8_t* in, int batch, int src, uint8_t* out, int dst,
+                                    hipStream_t stream) {
+    const size_t total = (size_t)batch * dst * dst;
+    hipLaunchKernelGGL(resize_bicubic_u8_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream,
+                       in, src, out, dst, total);
+    return hipGetLastError();
+}
+
 }  // namespace gance

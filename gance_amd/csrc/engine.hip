@@ -863,4 +863,12 @@ int gance_engine_debug_read_activation(gance_engine* engine, int32_t batch, floa
     return GANCE_OK;
 }
 
+int gance_resize_bicubic_u8(const uint8_t* d_in, int32_t batch, int32_t src_side, uint8_t* d_out,
+                            int32_t dst_side, void* stream) {
+    if (d_in == nullptr || d_out == nullptr || batch < 1 || src_side < 1 || dst_side < 1)
+        return fail(GANCE_ERR_INVALID_ARGUMENT, "bad argument to gance_resize_bicubic_u8");
+    GANCE_HIP_CHECK(gance::launch_resize_bicubic_u8(d_in, batch, src_side, d_out, dst_side, (hipStream_t)stream));
+    return GANCE_OK;
+}
+
 }  // extern "C"

@@ -114,5 +114,9 @@ struct ToRgbArgs {
 };
 hipError_t launch_torgb(const ToRgbArgs& args, hipStream_t stream);
 
+// Bicubic (a = -0.75) resize of uint8 NHWC RGB frames [batch][src][src][3] -> [batch][dst][dst][3].
+hipError_t launch_resize_bicubic_u8(const uint8_t* in, int batch, int src, uint8_t* out, int dst,
+                                    hipStream_t stream);
+
 }  // namespace gance
 #endif

@@ -144,6 +144,10 @@ SIGNATURES = {
         ],
     ),
     "gance_blend_read_stage": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p, ctypes.c_uint64]),
+    "gance_resize_bicubic_u8": (
+        ctypes.c_int,
+        [ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p],
+    ),
 }
 
 _LIB: Optional[ctypes.CDLL] = None
@@ -455,3 +459,9 @@ class Blend:
             self._lib.gance_blend_read_stage(self._handle, stage_id, out.ctypes.data_as(ctypes.c_void_p), ctypes.c_uint64(out.nbytes)),
         )
         return out
+
+
+def resize_bicubic_u8_device(d_in: int, batch: int, src_side: int, d_out: int, dst_side: int, stream: int = 0) -> None:
+    """Bicubic (a = -0.75) resize of uint8 NHWC frames in HBM; raw device pointers; asynchronous."""
+    lib = load_library()
+    _check(lib, lib.gance_resize_bicubic_u8(d_in, batch, src_side, d_out, dst_side, stream or None))

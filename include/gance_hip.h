@@ -186,6 +186,20 @@ enum gance_blend_stage {
 /* Synchronises the device and copies one stage of the LAST run to host memory. */
 int gance_blend_read_stage(gance_blend* blend, int32_t stage, void* h_out, uint64_t num_bytes);
 
+/* ------------------------------------------------------------------------------------------ */
+/* Post-synthesis resize (next row f-2)                                                        */
+/* ------------------------------------------------------------------------------------------ */
+
+/*
+ * Replaces resize_source's cv2.resize(image, (side, side), interpolation=cv2.INTER_CUBIC)
+ * (gance/image_sources/video_common.py:399-429) for square uint8 RGB frames resident in HBM:
+ * d_in [batch][src_side][src_side][3] -> d_out [batch][dst_side][dst_side][3]. Float bicubic,
+ * a = -0.75, replicated border, round half up (OpenCV's 11-bit fixed point is not reproduced:
+ * parity unpinned). Asynchronous on `stream`.
+ */
+int gance_resize_bicubic_u8(const uint8_t* d_in, int32_t batch, int32_t src_side, uint8_t* d_out,
+                            int32_t dst_side, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

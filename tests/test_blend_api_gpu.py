@@ -1,0 +1,98 @@
+"""
+GPU tests of the post-synthesis resize kernel and of the end-to-end
+`projection_file_blend_api` harness (BASELINE.json configs[2] in miniature): WAV file + projection
+file + network files -> resized uint8 frames, against the chained oracles.
+"""
+
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+from scipy.io import wavfile
+
+from gance_amd import hip_lib, network_file, projection_file_blend, synthetic
+from gance_amd.projection import projection_file_reader as pfr
+from oracle import audio_ref, resize_ref, stylegan2_ref
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("src,dst,batch", [(64, 135, 3), (1024, 2160, 1), (256, 100, 2), (32, 32, 1)])
+def test_bicubic_resize_matches_oracle(src: int, dst: int, batch: int) -> None:
+    """Float bicubic a=-0.75: <= 1 LSB from the float64 restatement (fp32 vs fp64 rounding at .5)."""
+    images = np.random.RandomState(src + dst).randint(0, 256, (batch, src, src, 3)).astype(np.uint8)
+    d_in = torch.from_numpy(images).cuda()
+    d_out = torch.empty((batch, dst, dst, 3), dtype=torch.uint8, device="cuda")
+    hip_lib.resize_bicubic_u8_device(d_in.data_ptr(), batch, src, d_out.data_ptr(), dst, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    got = d_out.cpu().numpy()
+    want = resize_ref.resize_bicubic_u8(images, dst)
+    diff = np.abs(got.astype(int) - want.astype(int))
+    assert diff.max() <= 1 and (diff > 0).mean() < 2e-3
+    if src == dst:
+        assert np.array_equal(got, images)  # identity at scale 1
+
+
+def test_resize_keeps_flat_images_flat() -> None:
+    flat = torch.full((2, 64, 64, 3), 200, dtype=torch.uint8, device="cuda")
+    out = torch.empty((2, 150, 150, 3), dtype=torch.uint8, device="cuda")
+    hip_lib.resize_bicubic_u8_device(flat.data_ptr(), 2, 64, out.data_ptr(), 150)
+    torch.cuda.synchronize()
+    assert int(out.min()) == 200 and int(out.max()) == 200
+
+
+def test_projection_file_blend_api_end_to_end(tmp_path: Path) -> None:
+    L, num_projection, fps_in, fps_out, side, out_side = 512, 8, 15.0, 30.0, 64, 96
+    num_frames = int(num_projection * fps_out / fps_in)
+    # inputs on disk: a float32 WAV at L * fps Hz (the stretch is then the identity), a projection
+    # file, two network files
+    audio = synthetic.synthetic_audio(num_frames, L, seed=51, frames_per_second=fps_out)
+    wav_path = tmp_path / "audio.wav"
+    wavfile.write(str(wav_path), int(L * fps_out), audio)
+    latents = synthetic.synthetic_final_latents(num_projection, L, seed=52)
+    projection_path = tmp_path / "projection.npz"
+    pfr.write_projection_npz(projection_path, latents.reshape(18, num_projection, L).transpose(1, 0, 2), projection_fps=fps_in)
+    network_paths = []
+    for seed in range(2):
+        path = tmp_path / f"net_{seed}.pkl"
+        network_file.write_random_network(path, side, seed=seed)
+        network_paths.append(path)
+    out_path = tmp_path / "frames.npy"
+    projection_file_blend.projection_file_blend_api(
+        wav=[str(wav_path)], output_path=str(out_path), network_paths=network_paths, frames_to_visualize=None,
+        output_fps=fps_out, output_side_length=out_side, debug_path=None, debug_window=None, debug_side_length=None,
+        alpha=0.25, fft_roll_enabled=True, fft_amplitude_range=(-5, 5), projection_file_path=str(projection_path),
+        blend_depth=12, complexity_change_rolling_sum_window=None, complexity_change_threshold=None,
+        phash_distance=None, bbox_distance=None, track_length=None,
+    )
+    frames = np.load(out_path)
+    assert frames.shape == (num_frames, out_side, out_side, 3) and frames.dtype == np.uint8
+
+    # the same pipeline through the oracles
+    want_blend = audio_ref.alpha_blend_projection_file(latents, 0.25, True, (-5, 5), 12, audio, L, [0, 1])
+    dlatents = audio_ref.sub_vectors(want_blend.combined, L).astype(np.float32)
+    rows = int(np.log2(side)) * 2 - 2
+    for frame_index in (0, num_frames // 2, num_frames - 1):
+        variables = network_file.load_network(network_paths[int(want_blend.network_indices[frame_index])]).variables
+        image = stylegan2_ref.synthesize_w(dlatents[frame_index : frame_index + 1, :rows], variables, side)
+        native = stylegan2_ref.convert_images_to_uint8(image)
+        expected = resize_ref.resize_bicubic_u8(native, out_side)[0]
+        diff = np.abs(frames[frame_index].astype(int) - expected.astype(int))
+        assert diff.max() <= 2 and (diff > 0).mean() < 5e-3  # 1 LSB synthesis x bicubic overshoot
+
+    with pytest.raises(ValueError, match="Overlay music mask"):
+        projection_file_blend.projection_file_blend_api(
+            [str(wav_path)], None, network_paths, None, fps_out, out_side, None, None, None, 0.25, True, (-5, 5),
+            str(projection_path), 12, 3, 4, None, None, None,
+        )
+    with pytest.raises(ValueError, match="Cannot evenly divide"):
+        projection_file_blend.projection_file_blend_frames(
+            [str(wav_path)], network_paths, None, 40.0, out_side, 0.25, True, (-5, 5), str(projection_path), 12
+        )
+    incomplete = tmp_path / "incomplete.npz"
+    pfr.write_projection_npz(incomplete, latents.reshape(18, num_projection, L).transpose(1, 0, 2), projection_fps=fps_in, complete=False)
+    with pytest.raises(ValueError, match="Invalid Projection File"):
+        projection_file_blend.projection_file_blend_frames(
+            [str(wav_path)], network_paths, None, fps_out, out_side, 0.25, True, (-5, 5), str(incomplete), 12
+        )
