@@ -41,14 +41,23 @@ def load_network(path: Path) -> NetworkFile:
     :raises RuntimeError: if the file is not in this implementation's format (e.g. a legacy TF
     pickle), the error class the reference's callers already handle (network_functions.py:523-529).
     """
+    from gance_amd import legacy_import  # pylint: disable=import-outside-toplevel
+
     try:
         with open(str(path), "rb") as file:
             content = pickle.load(file)
-    except (pickle.UnpicklingError, ModuleNotFoundError, AttributeError, EOFError, ImportError) as error:
-        raise RuntimeError(f"{path} is not a gance_amd network file (legacy TF pickles need the importer): {error}") from error
-    if not isinstance(content, dict) or content.get("format") != FORMAT:
-        raise RuntimeError(f"{path} is not a gance_amd network file (format tag {FORMAT!r} missing)")
-    return NetworkFile(int(content["resolution"]), content["variables"])
+    except (pickle.UnpicklingError, ModuleNotFoundError, AttributeError, EOFError, ImportError, ValueError, IndexError) as error:
+        content = error  # not one of ours: maybe a legacy TF pickle (needs dnnlib to unpickle normally)
+    if isinstance(content, dict) and content.get("format") == FORMAT:
+        return NetworkFile(int(content["resolution"]), content["variables"])
+    try:
+        resolution, variables = legacy_import.load_legacy_network(path)
+    except Exception as error:  # pylint: disable=broad-except
+        raise RuntimeError(
+            f"{path} is neither a gance_amd network file (format tag {FORMAT!r}) nor an importable "
+            f"TF1 StyleGAN2 (G, D, Gs) pickle: {error}"
+        ) from error
+    return NetworkFile(resolution, variables)
 
 
 def write_random_network(path: Path, resolution: int, seed: int = 0) -> None:
