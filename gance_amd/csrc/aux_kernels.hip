@@ -7,6 +7,8 @@
 
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "kernels.h"
 
 namespace gance {
@@ -199,26 +201,32 @@ struct __attribute__((packed, aligned(4))) float4u {
     float x, y, z, w;
 };
 
+// RQ = position rows per thread: a thread makes 2*RQ output rows x 8 columns from 2*RQ+3 T rows
+// (the vertical FIR re-uses each horizontally filtered T row up to four times in registers).
+template <int RQ>
 __global__ __launch_bounds__(256) void fir_epilogue_kernel(const FirArgs p) {
     const int W4 = p.W >> 2;
+    const int HQ = p.H / RQ;
     const size_t q = (size_t)blockIdx.x * 256 + threadIdx.x;
-    const size_t total = (size_t)p.B * p.C * p.H * W4;
+    const size_t total = (size_t)p.B * p.C * HQ * W4;
     if (q >= total) return;
     const int X = (int)(q % W4) * 4;
-    const int Y = (int)((q / W4) % p.H);
-    const size_t bc = q / ((size_t)W4 * p.H);
+    const int Y = (int)((q / W4) % HQ) * RQ;
+    const size_t bc = q / ((size_t)W4 * HQ);
     const int c = (int)(bc % p.C);
     const int b = (int)(bc / p.C);
     const int TPW = p.W + 8;
     const size_t plane = (size_t)(p.H + 3) * TPW;
+    constexpr int NR = 2 * RQ + 3;  // T rows O[Y-1], E[Y], O[Y], E[Y+1], ..., O[Y+RQ]
 
     // horizontal pass of one T row held as even columns e[0..4] = Te[X..X+4] and odd columns
     // o[0..5] = To[X-1..X+4]: h[2i] = out col 2(X+i), h[2i+1] = out col 2(X+i)+1
-    float hrow[5][8];  // T rows: O[Y-1], E[Y], O[Y], E[Y+1], O[Y+1]
+    float hrow[NR][8];
 #pragma unroll
-    for (int r = 0; r < 5; ++r) {
-        const bool odd_row = (r & 1) == 0;        // rows 0,2,4 are odd T rows
-        const int yy = Y + (r >> 1) + (odd_row ? 0 : 1);  // padded row: O[Y-1]->Y, E[Y]->Y+1, O[Y]->Y+1, E[Y+1]->Y+2, O[Y+1]->Y+2
+    for (int r = 0; r < NR; ++r) {
+        const bool odd_row = (r & 1) == 0;  // r = 0, 2, 4, ... are odd T rows
+        // padded plane row: O[Y-1+k] -> Y+k, E[Y+k] -> Y+k+1
+        const int yy = Y + (r >> 1) + (odd_row ? 0 : 1);
         const float* te = (odd_row ? p.t + 2 * p.cls_stride : p.t) + c * plane + (size_t)yy * TPW + X + 4;
         const float* to = te + p.cls_stride;  // class + 1 = odd columns of the same row parity
         float e[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
@@ -240,39 +248,37 @@ __global__ __launch_bounds__(256) void fir_epilogue_kernel(const FirArgs p) {
         }
     }
     const int OW = 2 * p.W;
+    const int OWp = OW + 8;  // zero-bordered activation [B][C][2H+2][2W+8], interior at [y+1][x+4]
     const float bs = p.bias[c];
-    float r0[8], r1[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        r0[i] = 0.25f * hrow[0][i] + 0.75f * hrow[1][i] + 0.75f * hrow[2][i] + 0.25f * hrow[3][i];
-        r1[i] = 0.25f * hrow[1][i] + 0.75f * hrow[2][i] + 0.75f * hrow[3][i] + 0.25f * hrow[4][i];
-    }
-    if (p.noise != nullptr) {
-        const float* nz = p.noise + (size_t)(2 * Y) * OW + 2 * X;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            r0[i] += nz[i] * p.noise_strength;
-            r1[i] += nz[OW + i] * p.noise_strength;
-        }
-    }
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        r0[i] = lrelu_gain(r0[i] + bs);
-        r1[i] = lrelu_gain(r1[i] + bs);
-    }
-    // zero-bordered activation [B][C][2H+2][2W+8], interior at [y+1][x+4]: aligned 16-B stores
-    const int OWp = OW + 8;
     float* op = p.out + (bc * (size_t)(2 * p.H + 2) + (2 * Y + 1)) * OWp + 2 * X + 4;
-    *reinterpret_cast<float4*>(op) = make_float4(r0[0], r0[1], r0[2], r0[3]);
-    *reinterpret_cast<float4*>(op + 4) = make_float4(r0[4], r0[5], r0[6], r0[7]);
-    *reinterpret_cast<float4*>(op + OWp) = make_float4(r1[0], r1[1], r1[2], r1[3]);
-    *reinterpret_cast<float4*>(op + OWp + 4) = make_float4(r1[4], r1[5], r1[6], r1[7]);
+#pragma unroll
+    for (int k = 0; k < 2 * RQ; ++k) {  // output row 2Y + k uses T rows hrow[k .. k+3]
+        float r[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            r[i] = 0.25f * hrow[k][i] + 0.75f * hrow[k + 1][i] + 0.75f * hrow[k + 2][i] + 0.25f * hrow[k + 3][i];
+        if (p.noise != nullptr) {
+            const float* nz = p.noise + (size_t)(2 * Y + k) * OW + 2 * X;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) r[i] += nz[i] * p.noise_strength;
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) r[i] = lrelu_gain(r[i] + bs);
+        *reinterpret_cast<float4*>(op + (size_t)k * OWp) = make_float4(r[0], r[1], r[2], r[3]);
+        *reinterpret_cast<float4*>(op + (size_t)k * OWp + 4) = make_float4(r[4], r[5], r[6], r[7]);
+    }
 }
 
 hipError_t launch_fir_epilogue(const FirArgs& args, hipStream_t stream) {
-    const size_t total = (size_t)args.B * args.C * args.H * (args.W / 4);
-    hipLaunchKernelGGL(fir_epilogue_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
-                       stream, args);
+    // 2 position rows per thread (measured best: +7 % over 1, same as 4) when the grid still fills the chip
+    static const int forced = [] { const char* v = std::getenv("GANCE_TUNE_FIR_RQ"); return v ? std::atoi(v) : 0; }();
+    int rq = (args.H % 2 == 0 && (size_t)args.B * args.C * (args.H / 2) * (args.W / 4) >= 256 * 256 * 4) ? 2 : 1;
+    if (forced == 1 || forced == 2 || forced == 4) rq = (args.H % forced == 0) ? forced : 1;
+    const size_t total = (size_t)args.B * args.C * (args.H / rq) * (args.W / 4);
+    const dim3 grid((unsigned)((total + 255) / 256));
+    if (rq == 4) hipLaunchKernelGGL(fir_epilogue_kernel<4>, grid, dim3(256), 0, stream, args);
+    else if (rq == 2) hipLaunchKernelGGL(fir_epilogue_kernel<2>, grid, dim3(256), 0, stream, args);
+    else hipLaunchKernelGGL(fir_epilogue_kernel<1>, grid, dim3(256), 0, stream, args);
     return hipGetLastError();
 }
 
