@@ -97,6 +97,51 @@ def cpu_baseline(resolution: int, variables, budget_seconds: float = 15.0) -> di
     }
 
 
+def blend_workload(args, device) -> int:
+    """
+    BASELINE.json configs[2] on one GPU: 30 s synthetic WAV (30 720 Hz) + 900 projected latents
+    -> spectrogram, fft-roll, alpha blend (alpha 0.25, amplitude +-5, depth 12) -> 1800 frames at
+    1024^2, frames left in HBM. Timed: host audio array -> last uint8 frame in HBM.
+    """
+    from gance_amd import synthetic  # pylint: disable=import-outside-toplevel
+    from gance_amd.data_into_network_visualization import visualization_inputs  # pylint: disable=import-outside-toplevel
+
+    resolution, batch, num_frames = args.resolution, args.batch, 1800
+    variables = sg2_spec.make_random_variables(resolution, seed=0)
+    engine = hip_lib.Engine(variables, resolution, max_batch=batch, device=device.index)
+    audio, latents = synthetic.benchmark_blend_inputs(num_frames)
+    frames = torch.empty((batch, resolution, resolution, 3), dtype=torch.uint8, device=device)
+    stream = torch.cuda.current_stream(device)
+    rows = engine.num_layers
+
+    def run_once():
+        t0 = time.perf_counter()
+        blend = visualization_inputs.alpha_blend_projection_file_device(
+            latents, 0.25, True, (-5, 5), 12, audio, 512, 1, device=device.index
+        )
+        torch.cuda.synchronize(device)
+        t1 = time.perf_counter()
+        dlat = blend.dlatents[:, :rows, :].contiguous()
+        for start in range(0, num_frames, batch):
+            count = min(batch, num_frames - start)
+            engine.synthesize_w_device(dlat[start : start + count].data_ptr(), count, frames.data_ptr(), 0, stream.cuda_stream)
+        torch.cuda.synchronize(device)
+        t2 = time.perf_counter()
+        blend.blend.close()
+        return t1 - t0, t2 - t1
+
+    run_once()  # warm-up (LDS attribute setup, allocator)
+    audio_s, synth_s = run_once()
+    print(json.dumps({
+        "metric": "projection-file-blend frames/sec at 1024x1024 (config 3), host audio -> frames in HBM",
+        "value": round(num_frames / (audio_s + synth_s), 3), "unit": "frames/s", "n_gpus": 1,
+        "frames": num_frames, "audio_to_latents_ms": round(audio_s * 1e3, 3), "synthesis_ms": round(synth_s * 1e3, 3),
+        "frames_per_call": batch, "dtype": "f64 (audio) / f32 (synthesis)", "data": "synthetic",
+    }), flush=True)
+    engine.close()
+    return 0
+
+
 def main() -> int:
     parser = argparse.ArgumentParser()
     parser.add_argument("--gpus", type=int, default=1)
@@ -106,6 +151,11 @@ def main() -> int:
     parser.add_argument("--resolution", type=int, default=1024)
     parser.add_argument("--no-cpu-baseline", action="store_true")
     parser.add_argument("--print-steps", action="store_true", help="per-launch table on stderr")
+    parser.add_argument(
+        "--workload", choices=["synthesis", "blend"], default="synthesis",
+        help="synthesis = BASELINE configs[1] (the contract line); blend = configs[2]: 30 s synthetic WAV -> "
+        "FFT + fft-roll -> alpha-blended latents -> 1024 synthesis, single GPU, extra line for DESIGN.md",
+    )
     args = parser.parse_args()
 
     world_size = int(os.environ.get("WORLD_SIZE", "1"))
@@ -122,6 +172,8 @@ def main() -> int:
         dist.init_process_group(backend="nccl", device_id=device)
 
     resolution, batch = args.resolution, args.batch
+    if args.workload == "blend":
+        return blend_workload(args, device)
     variables = sg2_spec.make_random_variables(resolution, seed=0)
     engine = hip_lib.Engine(variables, resolution, max_batch=batch, device=local_rank, profile=True)
 
