@@ -204,6 +204,9 @@ __global__ __launch_bounds__(512) void db_resample_kernel(const double* __restri
         if (t0 + f < N) {
             v = 20.0 * log10(mag[(size_t)(t0 + f) * bins + k] / gmax);
             if (db_out != nullptr) db_out[(size_t)(t0 + f) * bins + k] = v;
+            // a silent window gives log10(0) = -inf (the reference then fails inside minmax_scale);
+            // fmin / fmax below drop NaNs, so record the non-finite value in the running minimum
+            if (!isfinite(v)) atomicMin(&minmax_key[0], order_key(-INFINITY));
         }
         lds[i] = v;
     }
@@ -640,6 +643,20 @@ int gance_blend_read_stage(gance_blend* b, int32_t stage, void* h_out, uint64_t 
         case GANCE_STAGE_ROLLING_AVERAGE: src = b->rolling[0]; bytes = N * 8; break;
         case GANCE_STAGE_ROLLING_SMOOTHED: src = b->smoothed[0]; bytes = N * 8; break;
         case GANCE_STAGE_INDEX_SMOOTHED: src = b->smoothed[1]; bytes = N * 8; break;
+        case GANCE_STAGE_MINMAX: {
+            if (num_bytes != 24) return audio_fail(GANCE_ERR_INVALID_ARGUMENT, "GANCE_STAGE_MINMAX holds 24 bytes");
+            unsigned long long keys[3];
+            GANCE_AUDIO_CHECK(hipSetDevice(b->device));
+            GANCE_AUDIO_CHECK(hipDeviceSynchronize());
+            GANCE_AUDIO_CHECK(hipMemcpy(keys, b->keys, sizeof(keys), hipMemcpyDeviceToHost));
+            double* out = (double*)h_out;
+            for (int i = 0; i < 3; ++i) {  // inverse of the order-preserving key transform
+                const unsigned long long k = keys[i];
+                const unsigned long long bits = (k >> 63) ? (k & 0x7fffffffffffffffull) : ~k;
+                std::memcpy(&out[i], &bits, 8);
+            }
+            return GANCE_OK;
+        }
         default: return audio_fail(GANCE_ERR_INVALID_ARGUMENT, "unknown stage");
     }
     if (num_bytes != bytes)

@@ -70,6 +70,11 @@ def alpha_blend_projection_file_device(
         debug_stages=keep_stages, stream=stream.cuda_stream,
     )
     stream.synchronize()  # d_audio / d_row0 go out of scope here
+    try:
+        blend.check_finite()
+    except ValueError:
+        blend.close()
+        raise
     return DeviceBlend(dlatents, indices, blend)
 
 

@@ -410,8 +410,11 @@ class Blend:
             int(bool(fft_roll_enabled)), num_networks, int(has_range), float(alpha), float(lo), float(hi),
         )
         status = self._lib.gance_blend_create(ctypes.byref(self.config), device, ctypes.byref(self._handle))
-        if status == 1 and b"Cannot duplicate" in self._lib.gance_last_error():
-            # the reference raises ValueError here (vector_sources_common.py:318-331)
+        if status == 1 and (
+            b"Cannot duplicate" in self._lib.gance_last_error() or b"num_frames must be >= 7" in self._lib.gance_last_error()
+        ):
+            # the reference raises ValueError in both cases (vector_sources_common.py:318-331;
+            # scipy.signal.savgol_filter: window_length must not exceed the number of frames)
             raise ValueError(self._lib.gance_last_error().decode())
         _check(self._lib, status)
         self.device = device
@@ -442,6 +445,18 @@ class Blend:
                 d_network_indices or None, int(debug_stages), stream or None,
             ),
         )
+
+    def check_finite(self) -> None:
+        """
+        The reference fails on audio with a silent 510-sample window: log10(0) = -inf reaches
+        sklearn's minmax_scale, which raises ValueError (apply_spectrogram.py:43,81). Same here:
+        inspect the global extrema of the last run (one 24-byte read-back).
+        :raises ValueError: if the spectrogram holds a non-finite value.
+        """
+        extrema = np.empty(3, dtype=np.float64)
+        _check(self._lib, self._lib.gance_blend_read_stage(self._handle, 14, extrema.ctypes.data_as(ctypes.c_void_p), ctypes.c_uint64(24)))
+        if not np.all(np.isfinite(extrema)) or extrema[0] == 0.0:
+            raise ValueError("Input contains infinity or a value too large for dtype('float64').")
 
     def read_stage(self, name: str) -> np.ndarray:
         """Copy one stage of the last run to the host (synchronises)."""

@@ -181,7 +181,8 @@ enum gance_blend_stage {
     GANCE_STAGE_NETWORK_INDICES = 10, /* int32 [N]                                               */
     GANCE_STAGE_ROLLING_AVERAGE = 11, /* float64 [N]    roll chain                               */
     GANCE_STAGE_ROLLING_SMOOTHED = 12, /* float64 [N]   roll chain                               */
-    GANCE_STAGE_INDEX_SMOOTHED = 13    /* float64 [N]   network-index chain                      */
+    GANCE_STAGE_INDEX_SMOOTHED = 13,   /* float64 [N]   network-index chain                      */
+    GANCE_STAGE_MINMAX = 14            /* float64 [3]   global max |X|, min and max of the resampled dB  */
 };
 /* Synchronises the device and copies one stage of the LAST run to host memory. */
 int gance_blend_read_stage(gance_blend* blend, int32_t stage, void* h_out, uint64_t num_bytes);

@@ -131,6 +131,19 @@ def test_roll_is_an_exact_rotation() -> None:
         blend.close()
 
 
+def test_silent_window_raises_like_the_reference() -> None:
+    """A 510-sample window of zeros gives log10(0) = -inf; sklearn's minmax_scale raises ValueError."""
+    from gance_amd.data_into_network_visualization import visualization_inputs
+
+    audio = synthetic.synthetic_audio(16, 512, seed=1)
+    audio[3 * 512 : 4 * 512] = 0.0
+    latents = synthetic.synthetic_final_latents(8, 512, seed=2)
+    with pytest.raises(ValueError, match="infinity"):
+        visualization_inputs.alpha_blend_projection_file_device(latents, 0.25, True, (-5, 5), 12, audio, 512, 1)
+    with pytest.raises(ValueError, match="num_frames must be >= 7"):
+        hip_lib.Blend(6, 3, 0.25, True, (-5, 5), 12, 1)
+
+
 def test_blend_rejects_what_the_reference_rejects() -> None:
     with pytest.raises(ValueError, match="Cannot duplicate"):
         hip_lib.Blend(60, 7, 0.25, True, (-5, 5), 12, 3)  # vsc:318-331

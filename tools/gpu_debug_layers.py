@@ -1,7 +1,7 @@
 """
 Developer script (not collected by pytest): layer-by-layer comparison of the HIP engine with the
 oracle, to localise a parity failure. Run on a GPU box:
-    python tests/gpu_debug_layers.py [resolution] [batch]
+    python tools/gpu_debug_layers.py [resolution] [batch]
 """
 
 import sys
