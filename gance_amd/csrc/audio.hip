@@ -432,6 +432,7 @@ struct gance_blend {
     gance_blend_config cfg{};
     int device = 0;
     int m = 0, bins = 0;
+    int index_w = 3;
     // tables
     double *window = nullptr, *twiddle = nullptr, *RT = nullptr;
     double *sg_time = nullptr, *sg_bins = nullptr, *sg_roll_bins = nullptr, *sg_chain_roll = nullptr,
@@ -473,6 +474,10 @@ int gance_blend_create(const gance_blend_config* config, int32_t device, gance_b
     if (c.latent_depth < 1 || c.blend_depth < 0 || c.blend_depth > c.latent_depth)
         return audio_fail(GANCE_ERR_INVALID_ARGUMENT, "blend_depth must be in [0, latent_depth]");
     if (c.num_networks < 1) return audio_fail(GANCE_ERR_INVALID_ARGUMENT, "num_networks must be >= 1");
+    if (c.index_savgol_window_length != 0 &&
+        (c.index_savgol_window_length < 3 || c.index_savgol_window_length > 7 || c.index_savgol_window_length % 2 == 0 ||
+         c.index_savgol_polyorder < 0 || c.index_savgol_polyorder > 3 || c.index_savgol_polyorder >= c.index_savgol_window_length))
+        return audio_fail(GANCE_ERR_INVALID_ARGUMENT, "index savgol: window_length odd in [3, 7], polyorder in [0, 3] and < window_length");
     int device_count = 0;
     const hipError_t count_err = hipGetDeviceCount(&device_count);
     if (count_err != hipSuccess || device_count < 1)
@@ -517,7 +522,9 @@ int gance_blend_create(const gance_blend_config* config, int32_t device, gance_b
     const std::vector<double> sg_bins = gance_audio::savgol_table(5, 3);
     const std::vector<double> sg_roll_bins = gance_audio::savgol_table(51, 2);
     const std::vector<double> sg_chain_roll = gance_audio::savgol_table(7, 3);
-    const std::vector<double> sg_chain_index = gance_audio::savgol_table(3, 2);
+    const int index_w = c.index_savgol_window_length == 0 ? 3 : c.index_savgol_window_length;
+    const int index_p = c.index_savgol_window_length == 0 ? 2 : c.index_savgol_polyorder;
+    const std::vector<double> sg_chain_index = gance_audio::savgol_table(index_w, index_p);
 
 #define GANCE_ALLOC(ptr, count, type)                                                        \
     do {                                                                                     \
@@ -543,6 +550,7 @@ int gance_blend_create(const gance_blend_config* config, int32_t device, gance_b
     GANCE_UPLOAD(b->sg_roll_bins, sg_roll_bins);
     GANCE_UPLOAD(b->sg_chain_roll, sg_chain_roll);
     GANCE_UPLOAD(b->sg_chain_index, sg_chain_index);
+    b->index_w = index_w;
     const size_t NL = (size_t)N * L;
     GANCE_ALLOC(b->mag, (size_t)N * bins, double);
     GANCE_ALLOC(b->db, (size_t)N * bins, double);
@@ -596,7 +604,7 @@ int gance_blend_run(gance_blend* b, const float* d_audio, uint64_t num_samples, 
                        L, N, b->rms);
     gance_audio::ChainArgs roll{b->rms, c.fft_roll_enabled ? N : 0, 3, b->sg_chain_roll, 7, 3, L,
                                 b->rolling[0], b->smoothed[0], b->roll_values, b->cumulative};
-    gance_audio::ChainArgs index{b->rms, N, 3, b->sg_chain_index, 3, c.num_networks, 0,
+    gance_audio::ChainArgs index{b->rms, N, 3, b->sg_chain_index, b->index_w, c.num_networks, 0,
                                  b->rolling[1], b->smoothed[1], b->net_indices, nullptr};
     hipLaunchKernelGGL(gance_audio::reduce_chain_kernel, dim3(2), dim3(64), 0, stream, roll, index);
     gance_audio::BlendArgs blend{};

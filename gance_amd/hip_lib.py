@@ -8,7 +8,7 @@ MI355X is visible, calls raise: there is no CPU fallback in the product path.
 
 import ctypes
 from pathlib import Path
-from typing import Dict, List, NamedTuple, Optional
+from typing import Dict, List, NamedTuple, Optional, Tuple
 
 import numpy as np
 import torch  # noqa: F401  pylint: disable=unused-import
@@ -68,6 +68,8 @@ class BlendConfig(ctypes.Structure):
         ("alpha", ctypes.c_double),
         ("amplitude_lo", ctypes.c_double),
         ("amplitude_hi", ctypes.c_double),
+        ("index_savgol_window_length", ctypes.c_int32),
+        ("index_savgol_polyorder", ctypes.c_int32),
     ]
 
 
@@ -147,6 +149,19 @@ SIGNATURES = {
     "gance_resize_bicubic_u8": (
         ctypes.c_int,
         [ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p],
+    ),
+    "gance_gaussian_noise": (
+        ctypes.c_int,
+        [
+            ctypes.c_void_p,
+            ctypes.c_int32,
+            ctypes.c_int32,
+            ctypes.c_double,
+            ctypes.c_double,
+            ctypes.POINTER(ctypes.c_double),
+            ctypes.c_void_p,
+            ctypes.c_void_p,
+        ],
     ),
 }
 
@@ -400,7 +415,12 @@ class Blend:
         vector_length: int = 512,
         latent_depth: int = 18,
         device: int = 0,
+        index_savgol: Tuple[int, int] = (3, 2),
     ) -> None:
+        """
+        :param index_savgol: (window_length, polyorder) of the savgol_filter in front of the
+        network-index quantisation: (3, 2) for projection-file-blend, (7, 3) for noise-blend.
+        """
         self._lib = load_library()
         self._handle = ctypes.c_void_p()
         has_range = fft_amplitude_range is not None
@@ -408,6 +428,7 @@ class Blend:
         self.config = BlendConfig(
             num_frames, vector_length, num_projection_frames, latent_depth, blend_depth,
             int(bool(fft_roll_enabled)), num_networks, int(has_range), float(alpha), float(lo), float(hi),
+            int(index_savgol[0]), int(index_savgol[1]),
         )
         status = self._lib.gance_blend_create(ctypes.byref(self.config), device, ctypes.byref(self._handle))
         if status == 1 and (
@@ -480,3 +501,33 @@ def resize_bicubic_u8_device(d_in: int, batch: int, src_side: int, d_out: int, d
     """Bicubic (a = -0.75) resize of uint8 NHWC frames in HBM; raw device pointers; asynchronous."""
     lib = load_library()
     _check(lib, lib.gance_resize_bicubic_u8(d_in, batch, src_side, d_out, dst_side, stream or None))
+
+
+def gaussian_noise_device(  # pylint: disable=too-many-arguments
+    d_randn: int,
+    num_vectors: int,
+    vector_length: int,
+    sigma_across: float,
+    sigma_within: float,
+    feature_range: Optional[Tuple[float, float]],
+    d_out: int,
+    stream: int = 0,
+) -> None:
+    """
+    Gaussian-filtered ("wrap"), RMS-normalised and optionally min-max scaled noise field from
+    float32 standard-normal draws already in HBM (raw device pointers, [N][L]); returns once
+    `stream` has drained.
+    :raises ValueError: for a feature range sklearn's minmax_scale rejects.
+    """
+    lib = load_library()
+    bounds = None
+    if feature_range is not None:
+        if not feature_range[0] < feature_range[1]:
+            raise ValueError(f"Minimum of desired feature range must be smaller than maximum. Got {feature_range}.")
+        bounds = (ctypes.c_double * 2)(float(feature_range[0]), float(feature_range[1]))
+    _check(
+        lib,
+        lib.gance_gaussian_noise(
+            d_randn, num_vectors, vector_length, float(sigma_across), float(sigma_within), bounds, d_out, stream or None
+        ),
+    )

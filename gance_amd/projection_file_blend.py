@@ -22,7 +22,7 @@ import torch.distributed as dist
 from gance_amd import divisor, frame_sharding, hip_lib
 from gance_amd.data_into_network_visualization import visualization_inputs
 from gance_amd.logger_common import LOGGER
-from gance_amd.network_interface.network_functions import DEFAULT_MAX_BATCH, MultiNetwork
+from gance_amd.network_interface.network_functions import DEFAULT_MAX_BATCH, TRUNCATION_PSI, MultiNetwork
 from gance_amd.projection import projection_file_reader
 from gance_amd.vector_sources import music
 from gance_amd.vector_sources.vector_sources_common import underlying_length
@@ -39,6 +39,9 @@ def synthesize_device_frames(  # pylint: disable=too-many-locals
     dlatents [n, W18, L] float32 and network_indices [n] int32 on the GPU -> uint8 frame batches
     [<=batch, S, S, 3] on the GPU, in frame order. Rows beyond what a network takes (a 256^2
     generator reads 14 of the 18 rows) are dropped, like feeding `combined[:W]`.
+    A 2-D `dlatents` [n, L] holds z vectors and takes the network's vector entry (mapping +
+    truncation psi 1.2 + synthesis, network_functions.py:144-158), as `is_vector` data does in
+    the reference's `create_image_generic`.
     """
     indices = network_indices.cpu().numpy()
     stream = torch.cuda.current_stream(dlatents.device).cuda_stream
@@ -50,10 +53,14 @@ def synthesize_device_frames(  # pylint: disable=too-many-locals
             network = networks._network_at(int(network_index))  # pylint: disable=protected-access
             engine = network.engine
             members = torch.from_numpy(np.nonzero(chunk == network_index)[0] + start).to(dlatents.device)
-            selected = dlatents.index_select(0, members)[:, : engine.num_layers, :].contiguous()
             side = engine.resolution
             images = torch.empty((len(members), side, side, 3), dtype=torch.uint8, device=dlatents.device)
-            engine.synthesize_w_device(selected.data_ptr(), len(members), images.data_ptr(), 0, stream)
+            if dlatents.dim() == 2:
+                selected = dlatents.index_select(0, members).contiguous()
+                engine.synthesize_z_device(selected.data_ptr(), len(members), TRUNCATION_PSI, images.data_ptr(), 0, stream)
+            else:
+                selected = dlatents.index_select(0, members)[:, : engine.num_layers, :].contiguous()
+                engine.synthesize_w_device(selected.data_ptr(), len(members), images.data_ptr(), 0, stream)
             if frames is None:
                 frames = torch.empty((stop - start, side, side, 3), dtype=torch.uint8, device=dlatents.device)
             frames.index_copy_(0, members - start, images)
@@ -67,6 +74,32 @@ def synthesize_device_frames(  # pylint: disable=too-many-locals
             )
             frames = resized
         yield frames
+
+
+def shard_synthesize_gather(  # pylint: disable=too-many-arguments
+    dlatents: Optional[torch.Tensor],
+    indices: Optional[torch.Tensor],
+    num_frames: int,
+    networks: MultiNetwork,
+    output_side_length: int,
+    device: torch.device,
+) -> Optional[np.ndarray]:
+    """
+    Rank 0 holds the per-frame network inputs (and `num_frames`); every rank synthesises its
+    contiguous share and rank 0 gets the frames back in order (None elsewhere).
+    """
+    world_size = dist.get_world_size() if dist.is_initialized() else 1
+    if world_size > 1:
+        count = [num_frames]
+        dist.broadcast_object_list(count, src=0)
+        num_frames = count[0]
+        dlatents = frame_sharding.scatter_latents(dlatents, num_frames, device)
+        indices = frame_sharding.scatter_latents(indices, num_frames, device)
+    batches = list(synthesize_device_frames(dlatents, indices, networks, output_side_length))
+    local = torch.cat(batches) if batches else torch.empty((0, output_side_length, output_side_length, 3), dtype=torch.uint8, device=device)
+    frames, _ = frame_sharding.gather_frames(local, num_frames)
+    torch.cuda.synchronize(device)
+    return frames.cpu().numpy() if frames is not None else None
 
 
 def projection_file_blend_frames(  # pylint: disable=too-many-arguments,too-many-locals
@@ -86,7 +119,6 @@ def projection_file_blend_frames(  # pylint: disable=too-many-arguments,too-many
     0; None on other ranks when running distributed).
     """
     rank = dist.get_rank() if dist.is_initialized() else 0
-    world_size = dist.get_world_size() if dist.is_initialized() else 1
     device = torch.device("cuda", torch.cuda.current_device())
     networks = MultiNetwork(network_paths=network_paths, load=True)
     try:
@@ -119,17 +151,7 @@ def projection_file_blend_frames(  # pylint: disable=too-many-arguments,too-many
             if frames_to_visualize is not None:
                 dlatents, indices = dlatents[:frames_to_visualize], indices[:frames_to_visualize]
             num_frames = int(dlatents.shape[0])
-        if world_size > 1:
-            count = [num_frames]
-            dist.broadcast_object_list(count, src=0)
-            num_frames = count[0]
-            dlatents = frame_sharding.scatter_latents(dlatents, num_frames, device)
-            indices = frame_sharding.scatter_latents(indices, num_frames, device)
-        batches = list(synthesize_device_frames(dlatents, indices, networks, output_side_length))
-        local = torch.cat(batches) if batches else torch.empty((0, output_side_length, output_side_length, 3), dtype=torch.uint8, device=device)
-        frames, _ = frame_sharding.gather_frames(local, num_frames)
-        torch.cuda.synchronize(device)
-        return frames.cpu().numpy() if frames is not None else None
+        return shard_synthesize_gather(dlatents, indices, num_frames, networks, output_side_length, device)
     finally:
         networks.unload()
 

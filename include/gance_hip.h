@@ -19,7 +19,7 @@
 extern "C" {
 #endif
 
-#define GANCE_ABI_VERSION 1
+#define GANCE_ABI_VERSION 2
 
 enum gance_status {
     GANCE_OK = 0,
@@ -140,6 +140,12 @@ typedef struct gance_blend_config {
     double alpha;                  /* --alpha                                                     */
     double amplitude_lo;           /* --fft-amplitude-range                                       */
     double amplitude_hi;
+    /* savgol_filter applied to the rolling RMS before it is quantised to network indices:
+     * 0, 0 = (3, 2), what alpha_blend_projection_file passes (visualization_inputs.py:244-252);
+     * noise-blend leaves reduce_vector_rms_rolling_average at its defaults (7, 3)
+     * (visualization_inputs.py:146-151, vector_reduction.py:102-108). */
+    int32_t index_savgol_window_length;
+    int32_t index_savgol_polyorder;
 } gance_blend_config;
 
 /*
@@ -200,6 +206,20 @@ int gance_blend_read_stage(gance_blend* blend, int32_t stage, void* h_out, uint6
  */
 int gance_resize_bicubic_u8(const uint8_t* d_in, int32_t batch, int32_t src_side, uint8_t* d_out,
                             int32_t dst_side, void* stream);
+
+/* ---- smoothed-noise vector source (noise-blend) ------------------------------------------------
+ * Replaces gaussian_data (gance/vector_sources/primatives.py:49-74) after its MT19937 draw, and the
+ * minmax_scale(noise, (-4, 4)) of alpha_blend_vectors_max_rms_power_audio
+ * (gance/data_into_network_visualization/visualization_inputs.py:135-142).
+ * d_randn  [num_vectors][vector_length] float32 standard-normal draws (device; the caller's
+ *          np.random.RandomState(1234).randn(...).astype(float32), primatives.py:66-68)
+ * sigma_across / sigma_within   scipy.ndimage.gaussian_filter sigmas over vectors / inside a
+ *          vector (mode "wrap", truncate 4.0); 0 skips the axis, as scipy does
+ * feature_range  NULL, or {lo, hi}: min-max scale the RMS-normalised field to [lo, hi]
+ * d_out    [num_vectors][vector_length] float32 (device, != d_randn)
+ * Runs on `stream` of the current device and returns after the stream has drained. */
+int gance_gaussian_noise(const float* d_randn, int32_t num_vectors, int32_t vector_length, double sigma_across,
+                         double sigma_within, const double* feature_range, float* d_out, void* stream);
 
 #ifdef __cplusplus
 }

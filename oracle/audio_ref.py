@@ -18,6 +18,7 @@ from typing import List, NamedTuple, Optional, Tuple
 
 import numpy as np
 import pandas as pd
+from scipy.ndimage import gaussian_filter
 from scipy.signal import resample, savgol_filter
 
 
@@ -301,6 +302,51 @@ def alpha_blend_projection_file(
     raw_rms = compute_raw_rms(audio, vector_length)
     indices = quantize_to_indices(smoothed_rolling_average(raw_rms, 3, 3, 2)[0], len(network_indices))
     return BlendResult(spectrogram, projected, combined, indices)
+
+
+# ----------------------------------------------------------------------------------------------
+# noise-blend: gaussian_data                          gance/vector_sources/primatives.py:49-74
+#              alpha_blend_vectors_max_rms_power_audio   visualization_inputs.py:94-166
+# ----------------------------------------------------------------------------------------------
+def gaussian_data(vector_length: int, num_vectors: int, sigma_across: float = 20, sigma_within: float = 0, seed: int = 1234) -> np.ndarray:
+    """
+    float32 N(0,1) draws from RandomState(seed) shaped (N, 1, L), Gaussian-filtered with mode
+    "wrap" over vectors / within vectors, divided by their RMS (all float32), flattened.
+    """
+    draws = np.random.RandomState(seed).randn(num_vectors, 1, vector_length).astype(np.float32)  # pylint: disable=no-member
+    field = gaussian_filter(input=draws, sigma=(sigma_across, 0, sigma_within), mode="wrap")
+    field /= np.sqrt(np.mean(np.square(field)))
+    return field.reshape(vector_length * num_vectors)
+
+
+class NoiseBlendResult(NamedTuple):
+    """What `alpha_blend_vectors_max_rms_power_audio` returns, as plain arrays."""
+
+    spectrogram: np.ndarray  # a_vectors.data (N*L,) float64
+    noise: np.ndarray  # b_vectors.data (N*L,) float32
+    combined: np.ndarray  # combined.data (N*L,) float64
+    network_indices: np.ndarray  # (N,) int
+
+
+def alpha_blend_vectors_max_rms_power_audio(
+    alpha: float,
+    fft_roll_enabled: bool,
+    fft_amplitude_range: Tuple[float, float],
+    audio: np.ndarray,
+    vector_length: int,
+    network_indices: List[int],
+) -> NoiseBlendResult:
+    """
+    noise = minmax_scale(gaussian_data(sigma across 50), (-4, 4)) stays float32 (:135-142);
+    combined = noise * (1 - alpha) [float32] + spectrogram * alpha [float64] (:144).
+    """
+    spectrogram = create_spectrogram_stages(audio, vector_length, fft_amplitude_range, fft_roll_enabled).final
+    num_vectors = int(spectrogram.shape[0] / vector_length)
+    noise = minmax_scale_1d(gaussian_data(vector_length, num_vectors, 50, 0), (-4, 4))
+    combined = noise * (1.0 - alpha) + spectrogram * alpha
+    raw_rms = compute_raw_rms(audio, vector_length)
+    indices = quantize_to_indices(smoothed_rolling_average(raw_rms, 3, 7, 3)[0], len(network_indices))  # defaults (:146-151)
+    return NoiseBlendResult(spectrogram, noise, combined, indices)
 
 
 def sub_vectors(data: np.ndarray, vector_length: int) -> np.ndarray:

@@ -95,6 +95,40 @@ def blend_case(name: str, num_frames: int, seed: int, roll: bool, num_networks: 
     print(f"wrote {name}.npz  ({(GOLDEN_DIR / (name + '.npz')).stat().st_size / 1024:.0f} KiB)")
 
 
+def noise_case(name: str, num_frames: int, seed: int, roll: bool, num_networks: int, stride: int) -> None:
+    """One end-to-end `alpha_blend_vectors_max_rms_power_audio` (noise-blend) case + the bare noise source."""
+    from gance.data_into_network_visualization import visualization_inputs as vi  # pylint: disable=import-outside-toplevel,import-error
+    from gance.vector_sources.primatives import Sigmas, gaussian_data  # pylint: disable=import-outside-toplevel,import-error
+
+    L, alpha, amp = 512, 0.25, (-5, 5)
+    audio = synthetic.synthetic_audio(num_frames, L, seed=seed)
+    out = vi.alpha_blend_vectors_max_rms_power_audio(
+        alpha=alpha,
+        fft_roll_enabled=roll,
+        fft_amplitude_range=amp,
+        time_series_audio_vectors=audio,
+        vector_length=L,
+        network_indices=list(range(num_networks)),
+    )
+    assert out.b_vectors.data.dtype == np.float32 and out.combined.data.dtype == np.float64
+    arrays = {
+        "meta": np.array([num_frames, L, seed, int(roll), num_networks, stride], dtype=np.int64),
+        "alpha_amp": np.array([alpha, amp[0], amp[1]], dtype=np.float64),
+        "network_indices": np.asarray(out.network_indices.result.data, dtype=np.int64),
+    }
+    for key, value in {
+        "spectrogram": out.a_vectors.data,
+        "noise": out.b_vectors.data,
+        "combined": out.combined.data,
+        "gaussian_default": gaussian_data(vector_length=L, num_vectors=num_frames),  # Sigmas(20, 0)
+        "gaussian_both": gaussian_data(vector_length=L, num_vectors=num_frames, sigmas=Sigmas(3, 2)),
+    }.items():
+        for suffix, array in sampled(value, stride).items():
+            arrays[f"{key}_{suffix}"] = array
+    np.savez_compressed(GOLDEN_DIR / f"{name}.npz", **arrays)
+    print(f"wrote {name}.npz  ({(GOLDEN_DIR / (name + '.npz')).stat().st_size / 1024:.0f} KiB)")
+
+
 def unit_cases() -> None:
     """Known answers for the array helpers of vector_sources_common / vector_reduction."""
     from gance.vector_sources import vector_reduction, vector_sources_common as vsc  # pylint: disable=import-outside-toplevel,import-error
@@ -145,6 +179,8 @@ def main() -> None:
     blend_case("blend_n60_seed2_roll_k1", 60, 2, True, 1, 13)
     blend_case("blend_n240_seed3_roll_k3", 240, 3, True, 3, 53)
     blend_case("blend_n1800_seed7_roll_k3", 1800, 7, True, 3, 257)
+    noise_case("noise_n60_seed0_roll_k3", 60, 0, True, 3, 7)
+    noise_case("noise_n600_seed5_noroll_k2", 600, 5, False, 2, 97)
 
 
 if __name__ == "__main__":

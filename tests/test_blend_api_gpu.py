@@ -96,3 +96,29 @@ def test_projection_file_blend_api_end_to_end(tmp_path: Path) -> None:
         projection_file_blend.projection_file_blend_frames(
             [str(wav_path)], network_paths, None, fps_out, out_side, 0.25, True, (-5, 5), str(incomplete), 12
         )
+
+
+def test_noise_blend_end_to_end(tmp_path: Path) -> None:
+    """WAV + two networks -> frames through the z entry, against the oracles on sampled frames."""
+    from gance_amd import noise_blend  # pylint: disable=import-outside-toplevel
+
+    L, num_frames, fps, side, out_side = 512, 24, 30.0, 64, 48
+    audio = synthetic.synthetic_audio(num_frames, L, seed=61, frames_per_second=fps)
+    wav_path = tmp_path / "audio.wav"
+    wavfile.write(str(wav_path), int(L * fps), audio)
+    network_paths = []
+    for seed in range(2):
+        path = tmp_path / f"net_{seed}.pkl"
+        network_file.write_random_network(path, side, seed=seed + 5)
+        network_paths.append(path)
+    frames = noise_blend.noise_blend_frames([str(wav_path)], network_paths, 20, fps, out_side, 0.25, True, (-5, 5))
+    assert frames.shape == (20, out_side, out_side, 3) and frames.dtype == np.uint8
+
+    want = audio_ref.alpha_blend_vectors_max_rms_power_audio(0.25, True, (-5, 5), audio, L, [0, 1])
+    z = audio_ref.sub_vectors(want.combined, L).astype(np.float32)
+    for frame_index in (0, 9, 19):
+        variables = network_file.load_network(network_paths[int(want.network_indices[frame_index])]).variables
+        image = stylegan2_ref.synthesize_z(z[frame_index : frame_index + 1], variables, side, truncation_psi=1.2)
+        expected = resize_ref.resize_bicubic_u8(stylegan2_ref.convert_images_to_uint8(image), out_side)[0]
+        diff = np.abs(frames[frame_index].astype(int) - expected.astype(int))
+        assert diff.max() <= 2 and (diff > 0).mean() < 5e-3

@@ -76,6 +76,29 @@ def test_every_stage_matches_the_reference_goldens(golden_dir, name: str) -> Non
         assert np.array_equal(result.combined[row], result.combined[0])
 
 
+NOISE_CASES = ["noise_n60_seed0_roll_k3", "noise_n600_seed5_noroll_k2"]
+
+
+@pytest.mark.parametrize("name", NOISE_CASES)
+def test_noise_blend_matches_the_reference_goldens(golden_dir, name: str) -> None:
+    """noise-blend: the noise source is the same library calls, so float32 stages are bit-equal."""
+    golden = np.load(golden_dir / f"{name}.npz")
+    num_frames, vector_length, seed, roll, num_networks, stride = (int(v) for v in golden["meta"])
+    alpha, amp_lo, amp_hi = (float(v) for v in golden["alpha_amp"])
+    audio = synthetic.synthetic_audio(num_frames, vector_length, seed=seed)
+    result = audio_ref.alpha_blend_vectors_max_rms_power_audio(
+        alpha, bool(roll), (amp_lo, amp_hi), audio, vector_length, list(range(num_networks))
+    )
+    assert result.noise.dtype == np.float32 and result.combined.dtype == np.float64
+    assert np.array_equal(result.noise[::stride], golden["noise_sample"])
+    assert np.array_equal([result.noise.min(), result.noise.max()], golden["noise_stats"][:2])
+    assert np.array_equal(result.network_indices, golden["network_indices"])
+    check_stage(golden, "spectrogram", result.spectrogram, stride)
+    check_stage(golden, "combined", result.combined, stride)
+    assert np.array_equal(audio_ref.gaussian_data(vector_length, num_frames)[::stride], golden["gaussian_default_sample"])
+    assert np.array_equal(audio_ref.gaussian_data(vector_length, num_frames, 3, 2)[::stride], golden["gaussian_both_sample"])
+
+
 def test_array_helpers_match_the_reference_goldens(golden_dir) -> None:
     golden = np.load(golden_dir / "vector_helpers.npz")
     data = golden["data"]
