@@ -165,11 +165,19 @@ def main() -> int:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world_size}: launch with torch.distributed.run")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X; there is no CPU fallback in the product path")
+    # rehearsal knob for a one-GPU box: GANCE_BENCH_REHEARSAL=1 puts every rank on cuda:0 over gloo
+    # (RCCL refuses two ranks on one device); the numbers of such a run mean nothing
+    rehearsal = os.environ.get("GANCE_BENCH_REHEARSAL", "0") == "1"
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world_size > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=device)
+        if rehearsal:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=device)
 
     resolution, batch = args.resolution, args.batch
     if args.workload == "blend":
@@ -256,7 +264,7 @@ def main() -> int:
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "f32",
-            "data": "synthetic (random-init weights seed 0, RandomState(1) z vectors)",
+            "data": "synthetic (random-init weights seed 0, RandomState(1) z vectors)" + (" REHEARSAL: ranks share one GPU over gloo, not a measurement" if rehearsal else ""),
             "config": {
                 "workload": "BASELINE.json configs[1]: FFHQ config-f %dx%d random-init, batched random-z synthesis (mapping + truncation psi=1.2 + synthesis + uint8 NHWC), frames resident in HBM" % (resolution, resolution),
                 "frames_per_step_per_gpu": batch,
