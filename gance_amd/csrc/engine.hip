@@ -219,6 +219,7 @@ struct gance_engine {
 
     // profiling / debug
     std::vector<StepRecord> steps;
+    std::string profile_only;  // non-empty: bracket only launches whose name contains it
     int steps_used = 0;
     int debug_stop_after = 0;
     int last_act_layer = 0, last_act_c = 0, last_act_side = 0;
@@ -259,6 +260,7 @@ struct StepScope {
     StepScope(gance_engine* engine, hipStream_t s, const char* name, double flops, double bytes)
         : e(engine), stream(s) {
         if (!(e->cfg.flags & GANCE_FLAG_PROFILE_STEPS)) return;
+        if (!e->profile_only.empty() && std::strstr(name, e->profile_only.c_str()) == nullptr) return;
         if (e->steps_used == (int)e->steps.size()) {
             StepRecord r{};
             hipEventCreate(&r.start);
@@ -753,7 +755,8 @@ int gance_synthesize_w(gance_engine* engine, const float* d_dlatents, int32_t ba
                        uint8_t* d_out_u8, float* d_out_f32, void* stream) {
     if (int rc = check_call(engine, d_dlatents, batch)) return rc;
     GANCE_HIP_CHECK(hipSetDevice(engine->cfg.device));
-    engine->steps_used = 0;
+    // filtered profiling keeps its records across calls (bench.py averages them); else one call's worth
+    if (engine->profile_only.empty() || engine->steps_used >= 4096) engine->steps_used = 0;
     return synthesize_from_dlat(engine, d_dlatents, batch, d_out_u8, d_out_f32, (hipStream_t)stream);
 }
 
@@ -762,7 +765,8 @@ int gance_synthesize_z(gance_engine* engine, const float* d_z, int32_t batch, fl
     if (int rc = check_call(engine, d_z, batch)) return rc;
     GANCE_HIP_CHECK(hipSetDevice(engine->cfg.device));
     hipStream_t stream = (hipStream_t)stream_;
-    engine->steps_used = 0;
+    // filtered profiling keeps its records across calls (bench.py averages them); else one call's worth
+    if (engine->profile_only.empty() || engine->steps_used >= 4096) engine->steps_used = 0;
     const float* in = d_z;
     float* bufs[2] = {engine->map_a, engine->map_b_buf};
     for (int i = 0; i < kMappingLayers; ++i) {
@@ -816,6 +820,14 @@ int gance_synthesize_z_host(gance_engine* engine, const float* h_z, int32_t batc
     if (engine == nullptr) return fail(GANCE_ERR_INVALID_ARGUMENT, "engine is NULL");
     return host_call(engine, h_z, (size_t)batch * kDlatent, batch, true, truncation_psi, h_out_u8,
                      h_out_f32);
+}
+
+int gance_engine_set_profiling(gance_engine* engine, int32_t flags, const char* only_step) {
+    if (engine == nullptr) return fail(GANCE_ERR_INVALID_ARGUMENT, "NULL engine");
+    engine->cfg.flags = (engine->cfg.flags & ~GANCE_FLAG_PROFILE_STEPS) | (flags & GANCE_FLAG_PROFILE_STEPS);
+    engine->profile_only = only_step ? only_step : "";
+    engine->steps_used = 0;
+    return GANCE_OK;
 }
 
 int32_t gance_engine_step_count(const gance_engine* engine) { return engine ? engine->steps_used : 0; }

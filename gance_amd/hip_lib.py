@@ -85,6 +85,7 @@ SIGNATURES = {
         [ctypes.POINTER(EngineConfig), _F32P, ctypes.c_uint64, ctypes.POINTER(ctypes.c_void_p)],
     ),
     "gance_engine_destroy": (None, [ctypes.c_void_p]),
+    "gance_engine_set_profiling": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32, ctypes.c_char_p]),
     "gance_engine_vector_length": (ctypes.c_int32, [ctypes.c_void_p]),
     "gance_engine_num_layers": (ctypes.c_int32, [ctypes.c_void_p]),
     "gance_engine_resolution": (ctypes.c_int32, [ctypes.c_void_p]),
@@ -328,6 +329,16 @@ class Engine:
         )
 
     # ---- profiling / debugging ----
+
+    def set_profiling(self, enabled: bool, only_step: Optional[str] = None) -> None:
+        """Per-launch HIP events on / off; `only_step` restricts them to launches whose name contains it."""
+        self._require_open()
+        _check(
+            self._lib,
+            self._lib.gance_engine_set_profiling(
+                self._handle, GANCE_FLAG_PROFILE_STEPS if enabled else 0, only_step.encode() if only_step else None
+            ),
+        )
 
     def steps(self) -> List[StepInfo]:
         """Per-launch timings of the last call (engine created with profile=True)."""

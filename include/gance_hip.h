@@ -110,6 +110,12 @@ int gance_synthesize_z_host(gance_engine* engine, const float* h_z, int32_t batc
  * gance_engine_step_info fills name (<=63 chars + NUL), elapsed milliseconds and the
  * algorithmic FLOPs and bytes of launch `index` of the LAST call (synchronises the stream).
  */
+/* Change the profiling mode between calls: `flags` replaces the GANCE_FLAG_PROFILE_STEPS bit of the
+ * engine's configuration; with a non-NULL `only_step` just the launches whose name contains that
+ * string are bracketed (two events per call instead of ~100: what bench.py's timed region uses
+ * for the dominant kernel) and their records accumulate over calls (up to 4096) until the next
+ * gance_engine_set_profiling. */
+int gance_engine_set_profiling(gance_engine* engine, int32_t flags, const char* only_step);
 int32_t gance_engine_step_count(const gance_engine* engine);
 int gance_engine_step_info(gance_engine* engine, int32_t index, char* name64, float* ms,
                            double* flops, double* bytes);
