@@ -28,9 +28,22 @@
 
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdlib>
+#include <type_traits>
 
 #include "kernels.h"
+
+// Timing ablations (GANCE_DEBUG_CONV: 1 no stores, 2 no DMA after the first chunk, 4 no MFMA,
+// 16 per-block phase stamps, 64 no XCD remap) are compiled in only with -DGANCE_CONV_DEBUG=1:
+// their uniform branches cost scalar registers and one branch per store in the product kernel.
+#ifndef GANCE_CONV_DEBUG
+#define GANCE_CONV_DEBUG 0
+#endif
+#define GANCE_DBG(flag) (GANCE_CONV_DEBUG && (p.debug_flags & (flag)))
+#ifndef GANCE_CONV_PERSIST
+#define GANCE_CONV_PERSIST 0
+#endif
 
 namespace gance {
 
@@ -71,7 +84,7 @@ __host__ __device__ constexpr int shift_dx(int s) {
     return UP ? ((s & 1) ? -1 : 0) : s % 3 - 1;
 }
 
-template <int BM, int TB, int TH, int TW, int KC, int WM, int WN, bool UP, int NBUF, bool RT = false>
+template <int BM, int TB, int TH, int TW, int KC, int WM, int WN, bool UP, int NBUF, bool RT = false, bool PERSIST = false>
 struct ConvTile {
     static constexpr int kBN = TB * TH * TW;
     static constexpr int kMT = BM / (32 * WM);
@@ -99,127 +112,145 @@ struct ConvTile {
     static constexpr int kPiecesPerWave = (kPieces + 3) / 4;
     static_assert(NBUF == 2 || NBUF == 3, "ring depth");
     static_assert(!RT || (UP && TB == 1 && kBN == 64 && NBUF == 2), "runtime geometry: 64-position up tiles");
+    static_assert(!PERSIST || (TB == 1 && NBUF == 2), "persistent blocks: one sample per tile, ring depth 2");
     // dynamic LDS: NBUF staging buffers + style [TB][Cin] + demod [TB][BM] + bias [BM]
+    // (persistent blocks: two sets of the constants, alternating per tile)
+    static constexpr int kConstSets = PERSIST ? 2 : 1;
     static size_t lds_bytes(int cin) {
-        return sizeof(float) * (NBUF * (size_t)kBufFloats + (size_t)TB * cin + (size_t)TB * BM + BM);
+        return sizeof(float) * (NBUF * (size_t)kBufFloats + kConstSets * ((size_t)TB * cin + (size_t)TB * BM + BM));
     }
 };
 
-template <int BM, int TB, int TH, int TW, int KC, int WM, int WN, bool UP, int NBUF, bool RT>
+// uniform (scalar) description of one output tile
+struct TileGeom {
+    int m_tile, split, y0, x0, tile_b;
+    int tw_log2, PHr, PWr;  // runtime geometry (RT) only
+};
+
+template <int BM, int TB, int TH, int TW, int KC, int WM, int WN, bool UP, int NBUF, bool RT, bool PERSIST>
 __global__ __launch_bounds__(256, UP ? 2 : 4) void modconv_mfma_kernel(const ConvArgs p) {
-    using T = ConvTile<BM, TB, TH, TW, KC, WM, WN, UP, NBUF, RT>;
+    using T = ConvTile<BM, TB, TH, TW, KC, WM, WN, UP, NBUF, RT, PERSIST>;
     constexpr int MT = T::kMT, NT = T::kNT, PH = T::kPH, PW = T::kPW;
     constexpr int NCLS = T::kCls;
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* const buf0 = smem;
-    float* const s_lds = smem + NBUF * T::kBufFloats;  // [TB][Cin]
-    float* const d_lds = s_lds + TB * p.Cin;        // [TB][BM]
-    float* const b_lds = d_lds + TB * BM;           // [BM]
+    // constants of a tile: style [TB][Cin] | demod [TB][BM] | bias [BM]; persistent blocks alternate two sets
+    float* const const0 = smem + NBUF * T::kBufFloats;
+    const int const_floats = TB * p.Cin + TB * BM + BM;
 
     const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = tid >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform: branches on it are scalar
     const int wm = wave / WN;
     const int wn = wave % WN;
-    const int l31 = lane & 31;
-    const int lh = lane >> 5;
+    // lane ids are laundered once per tile (below) so that per-lane address arithmetic is not
+    // hoisted out of a persistent block's tile loop into long-lived registers
+    int lane = tid & 63;
+    int l31 = lane & 31;
+    int lh = lane >> 5;
 
     unsigned long long stamp0 = 0, stamp1 = 0, stamp2 = 0;
-    if (p.debug_flags & 16) stamp0 = __builtin_amdgcn_s_memrealtime();
-    // ---- XCD-aware block remap: blocks that share an XCD (bid % 8) get a contiguous id range,
-    // so the m tiles of one pixel tile and neighbouring pixel tiles hit the same L2 ----
-    int id;
-    {
-        const int nwg = gridDim.x, bid = blockIdx.x;
-        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
-        id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-        if (p.debug_flags & 64) id = bid;
-    }
-    if ((p.debug_flags & 8) && blockIdx.x < 2048) {
-        // experiment: de-phase the first generation of blocks
-        const int reps = (blockIdx.x >> 8) & 7;
-        for (int i = 0; i < reps; ++i) __builtin_amdgcn_s_sleep(127);
-    }
-    const int m_tile = id % p.m_tiles;
-    id /= p.m_tiles;
-    const int split = id % p.nsplit;
-    id /= p.nsplit;
-    // tile geometry: compile-time, or (RT) chosen per block
-    int y0, x0, tile_b;
-    int tw_log2 = 0, th_r = TH, PHr = PH, PWr = PW;
-    if (RT) {
-        const int main_tiles = p.tiles_x * p.tiles_y;
-        const int tiles_total = main_tiles + p.row_tiles + p.col_tiles;
-        const int t = id % tiles_total;
-        tile_b = id / tiles_total;
-        if (t < main_tiles) {  // TH x TW tile of the exactly-tiled H x W position grid
-            y0 = (t / p.tiles_x) * TH;
-            x0 = (t % p.tiles_x) * TW;
-            tw_log2 = 3;
-            static_assert(!RT || (TH == 8 && TW == 8), "RT main tile is 8x8");
-        } else if (t < main_tiles + p.row_tiles) {  // 1 x 64 on the position row y' = H
-            y0 = p.H;
-            x0 = (t - main_tiles) * 64;
-            tw_log2 = 6;
-            th_r = 1;
-            PHr = 2;
-            PWr = 68;
-        } else {  // 64 x 1 on the position column x' = W
-            y0 = (t - main_tiles - p.row_tiles) * 64;
-            x0 = p.W;
-            tw_log2 = 0;
-            th_r = 64;
-            PHr = 65;
-            PWr = 8;
-        }
-    } else {
-        const int tile_x = id % p.tiles_x;
-        id /= p.tiles_x;
-        const int tile_y = id % p.tiles_y;
-        tile_b = id / p.tiles_y;
-        y0 = tile_y * TH;
-        x0 = tile_x * TW;
-    }
-    const int PLANEr = PHr * PWr;
-    (void)th_r;
+    if (GANCE_DBG(16)) stamp0 = __builtin_amdgcn_s_memrealtime();
 
-    const int m0 = m_tile * BM;
-    const int b0 = tile_b * TB;
     const int Hp = p.H + 2, Wp = p.W + 8;
+
+    // ---- virtual block id -> tile. XCD-aware remap: the ids handled by one XCD (v % 8; a
+    // persistent block strides by a multiple of 8) form a contiguous range, so the m tiles of one
+    // pixel tile and neighbouring pixel tiles hit the same L2 at about the same time ----
+    auto decode = [&](int v) {
+        TileGeom g;
+        int id;
+        {
+            const int nwg = p.total_tiles;
+            const int q = nwg >> 3, r = nwg & 7, xcd = v & 7;
+            id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (v >> 3);
+            if (GANCE_DBG(64)) id = v;
+        }
+        g.m_tile = id % p.m_tiles;
+        id /= p.m_tiles;
+        g.split = id % p.nsplit;
+        id /= p.nsplit;
+        g.tw_log2 = 0;
+        g.PHr = PH;
+        g.PWr = PW;
+        if (RT) {
+            const int main_tiles = p.tiles_x * p.tiles_y;
+            const int tiles_total = main_tiles + p.row_tiles + p.col_tiles;
+            const int t = id % tiles_total;
+            g.tile_b = id / tiles_total;
+            if (t < main_tiles) {  // TH x TW tile of the exactly-tiled H x W position grid
+                g.y0 = (t / p.tiles_x) * TH;
+                g.x0 = (t % p.tiles_x) * TW;
+                g.tw_log2 = 3;
+                static_assert(!RT || (TH == 8 && TW == 8), "RT main tile is 8x8");
+            } else if (t < main_tiles + p.row_tiles) {  // 1 x 64 on the position row y' = H
+                g.y0 = p.H;
+                g.x0 = (t - main_tiles) * 64;
+                g.tw_log2 = 6;
+                g.PHr = 2;
+                g.PWr = 68;
+            } else {  // 64 x 1 on the position column x' = W
+                g.y0 = (t - main_tiles - p.row_tiles) * 64;
+                g.x0 = p.W;
+                g.tw_log2 = 0;
+                g.PHr = 65;
+                g.PWr = 8;
+            }
+        } else {
+            const int tile_x = id % p.tiles_x;
+            id /= p.tiles_x;
+            const int tile_y = id % p.tiles_y;
+            g.tile_b = id / p.tiles_y;
+            g.y0 = tile_y * TH;
+            g.x0 = tile_x * TW;
+        }
+        return g;
+    };
 
     // ---- LDS-DMA staging: `buffer_load_dwordx4 ... lds` (MUBUF). The FLAT-encoded
     // global_load_lds would make hipcc degrade every LDS wait of the MFMA loop to lgkmcnt(0);
     // with the buffer form it emits counted waits and the fragment prefetch really overlaps. ----
-    const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)(p.w + ((size_t)m_tile * p.total_chunks) * T::kWlFloats), 0, 0x7fffffff, 0x00020000);
-    const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)(p.x + (size_t)min(b0, p.B - 1) * p.x_b_stride), 0, 0x7fffffff, 0x00020000);
+    // Staging context = the tile whose chunks are being fetched (the NEXT tile during the last
+    // chunk of a persistent block's current tile).
+    __amdgpu_buffer_rsrc_t w_rsrc, x_rsrc;
+    int st_y0 = 0, st_x0 = 0, st_b0 = 0, st_chunk_begin = 0;
     // RT: the patch image is [KC][PHr][PWr/4] float4s; a wave's pieces are i = wave, wave+4, ...
-    // (at most 3); their per-lane source offsets are computed once, a chunk only adds its plane offset
+    // (at most 3); their per-lane source offsets are computed once per tile, a chunk only adds its plane offset
     int rt_off[3] = {0, 0, 0};
     int rt_pieces = 0;
-    if (RT) {
-        const int f4_total = KC * PLANEr / 4;
-        rt_pieces = (f4_total + 63) / 64;
+    auto stage_setup = [&](const TileGeom& g) {
+        st_y0 = g.y0;
+        st_x0 = g.x0;
+        st_b0 = g.tile_b * TB;
+        st_chunk_begin = g.split * p.chunks_per_split;
+        w_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(p.w + ((size_t)g.m_tile * p.total_chunks) * T::kWlFloats), 0,
+                                                   0x7fffffff, 0x00020000);
+        x_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(p.x + (size_t)min(st_b0, p.B - 1) * p.x_b_stride), 0,
+                                                   0x7fffffff, 0x00020000);
+        if (RT) {
+            const int f4_total = KC * g.PHr * g.PWr / 4;
+            rt_pieces = (f4_total + 63) / 64;
 #pragma unroll
-        for (int r = 0; r < 3; ++r) {
-            const int i = wave + 4 * r;
-            const int f = i * 64 + lane;
-            rt_off[r] = -1;
-            if (i < rt_pieces && f < f4_total) {
-                const int q4 = PWr / 4;
-                const int q = f % q4;
-                int rr = f / q4;
-                const int py = rr % PHr;
-                const int c = rr / PHr;
-                const int gy = min(y0 + py, Hp - 1);
-                const int gx = min(x0 + 4 * q, Wp - 4);
-                rt_off[r] = ((c * Hp + gy) * Wp + gx) * 4;
+            for (int r = 0; r < 3; ++r) {
+                const int i = wave + 4 * r;
+                const int f = i * 64 + lane;
+                rt_off[r] = -1;
+                if (i < rt_pieces && f < f4_total) {
+                    const int q4 = g.PWr / 4;
+                    const int q = f % q4;
+                    int rr = f / q4;
+                    const int py = rr % g.PHr;
+                    const int c = rr / g.PHr;
+                    const int gy = min(g.y0 + py, Hp - 1);
+                    const int gx = min(g.x0 + 4 * q, Wp - 4);
+                    rt_off[r] = ((c * Hp + gy) * Wp + gx) * 4;
+                }
             }
         }
-    }
-    auto stage = [&](int chunk, float* buf) {
+    };
+    // chunk = index within the staging tile's K range
+    auto stage = [&](int chunk_in_tile, float* buf) {
+        const int chunk = st_chunk_begin + chunk_in_tile;
         const int wbase = chunk * T::kWlFloats;
         const int ci0 = chunk * KC;
         float* pl = buf + T::kWlRegion;
@@ -241,9 +272,9 @@ __global__ __launch_bounds__(256, UP ? 2 : 4) void modconv_mfma_kernel(const Con
                 rr /= PH;
                 const int c = rr % KC;
                 const int tb = rr / KC;
-                const int bb = min(b0 + tb, p.B - 1) - min(b0, p.B - 1);
-                const int gy = min(y0 + py, Hp - 1);
-                const int gx = min(x0 + 4 * q, Wp - 4);
+                const int bb = min(st_b0 + tb, p.B - 1) - min(st_b0, p.B - 1);
+                const int gy = min(st_y0 + py, Hp - 1);
+                const int gx = min(st_x0 + 4 * q, Wp - 4);
                 const long long off = (long long)bb * p.x_b_stride + ((long long)(ci0 + c) * Hp + gy) * Wp + gx;
                 if (i * 64 + lane < T::kPlF4)
                     __builtin_amdgcn_raw_ptr_buffer_load_lds(x_rsrc, (lds_ptr_t)(pl + i * 256), 16,
@@ -262,53 +293,49 @@ __global__ __launch_bounds__(256, UP ? 2 : 4) void modconv_mfma_kernel(const Con
         }
     };
 
-    // ---- per-lane operand offsets ----
-    int boff[NT];
-    int stb[NT];
-#pragma unroll
-    for (int j = 0; j < NT; ++j) {
-        const int n = (wn * NT + j) * 32 + l31;
-        const int tb = RT ? 0 : n / (TH * TW);
-        const int yy = RT ? (n >> tw_log2) : (n / TW) % TH;
-        const int xx = RT ? (n & ((1 << tw_log2) - 1)) : n % TW;
-        boff[j] = (tb * KC + lh) * PLANEr + (yy + 1) * PWr + (xx + 4);
-        stb[j] = tb * p.Cin + lh;
-    }
-    const int aoff = lh * BM + wm * (MT * 32) + l31;
+    // ---- per-tile constants (style [Cin], demod [BM], bias [BM]) -> LDS set `set`, TB == 1:
+    // dword LDS-DMA (64 consecutive floats per wave-instruction), no register staging, counted in
+    // vmcnt with the chunk pieces they travel with ----
+    auto consts_stage = [&](const TileGeom& g, int set) {
+        float* const s_dst = const0 + set * const_floats;
+        float* const d_dst = s_dst + p.Cin;
+        float* const b_dst = d_dst + BM;
+        const int b = min(g.tile_b, p.B - 1);
+        const int m0g = g.m_tile * BM;
+        const __amdgpu_buffer_rsrc_t s_rsrc =
+            __builtin_amdgcn_make_buffer_rsrc((void*)(p.s + (size_t)b * p.s_stride), 0, 0x7fffffff, 0x00020000);
+        const __amdgpu_buffer_rsrc_t d_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+            (void*)(p.d + (size_t)b * p.d_stride + m0g), 0, 0x7fffffff, 0x00020000);
+        const __amdgpu_buffer_rsrc_t b_rsrc =
+            __builtin_amdgcn_make_buffer_rsrc((void*)(p.bias + m0g), 0, 0x7fffffff, 0x00020000);
+        for (int i = wave; i * 64 < p.Cin; i += 4)
+            if (i * 64 + lane < p.Cin)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(s_rsrc, (lds_ptr_t)(s_dst + i * 64), 4, (i * 64 + lane) * 4, 0, 0, 0);
+        constexpr int kMPieces = (BM + 63) / 64;  // 1 or 2
+        if (wave < kMPieces) {
+            if (wave * 64 + lane < BM)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(d_rsrc, (lds_ptr_t)(d_dst + wave * 64), 4, (wave * 64 + lane) * 4, 0, 0, 0);
+        } else if (wave - 2 >= 0 && wave - 2 < kMPieces) {
+            if ((wave - 2) * 64 + lane < BM)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(b_rsrc, (lds_ptr_t)(b_dst + (wave - 2) * 64), 4, ((wave - 2) * 64 + lane) * 4, 0, 0, 0);
+        }
+    };
 
-    f32x16 acc[NCLS][MT][NT];
-#pragma unroll
-    for (int c = 0; c < NCLS; ++c)
-#pragma unroll
-        for (int i = 0; i < MT; ++i)
-#pragma unroll
-            for (int j = 0; j < NT; ++j)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[c][i][j][r] = 0.f;
-
-    const int chunk_begin = split * p.chunks_per_split;
     const int nchunks = p.chunks_per_split;
 
+    int v = blockIdx.x;
+    TileGeom cur = decode(v);
+    stage_setup(cur);
     // ring prologue: NBUF-1 chunks in flight before the first MFMA
-    stage(chunk_begin, buf0);
-    if (NBUF == 3 && nchunks > 1) stage(chunk_begin + 1, buf0 + T::kBufFloats);
-
-    // ---- one-time staging of style, demod and bias. All global loads of a thread are issued
-    // before the first LDS write, so the block pays one memory round trip, not three. ----
+    stage(0, buf0);
+    if (NBUF == 3 && nchunks > 1) stage(1, buf0 + T::kBufFloats);
     if (TB == 1) {
-        const int b = min(b0, p.B - 1);
-        const float* sp = p.s + (size_t)b * p.s_stride;
-        const float s0 = tid < p.Cin ? sp[tid] : 0.f;
-        const float s1 = tid + 256 < p.Cin ? sp[tid + 256] : 0.f;
-        const float dv = tid < BM ? p.d[(size_t)b * p.d_stride + m0 + tid] : 0.f;
-        const float bv = tid < BM ? p.bias[m0 + tid] : 0.f;
-        if (tid < p.Cin) s_lds[tid] = s0;
-        if (tid + 256 < p.Cin) s_lds[tid + 256] = s1;
-        if (tid < BM) {
-            d_lds[tid] = dv;
-            b_lds[tid] = bv;
-        }
+        consts_stage(cur, 0);
     } else {
+        float* s_lds = const0;
+        float* d_lds = s_lds + TB * p.Cin;
+        float* b_lds = d_lds + TB * BM;
+        const int b0 = cur.tile_b * TB, m0 = cur.m_tile * BM;
         for (int i = tid; i < TB * p.Cin; i += 256) {
             const int tb = i / p.Cin, ci = i - tb * p.Cin;
             const int b = min(b0 + tb, p.B - 1);
@@ -322,145 +349,223 @@ __global__ __launch_bounds__(256, UP ? 2 : 4) void modconv_mfma_kernel(const Con
         for (int i = tid; i < BM; i += 256) b_lds[i] = p.bias[m0 + i];
     }
 
-    for (int k = 0; k < nchunks; ++k) {
-        // Each wave waits for ITS pieces of chunk k (counted: the pieces of chunk k+1 it issued
-        // later may stay in flight), then the raw barrier makes chunk k visible to all waves and
-        // proves chunk k-1's buffer is no longer read. No __syncthreads here: its fence would make
-        // hipcc drain vmcnt to 0 and serialise the ring.
-        if (NBUF == 3 && k + 1 < nchunks) {
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(T::kPiecesPerWave) : "memory");
-        } else {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        if ((p.debug_flags & 16) && k == 0) stamp1 = __builtin_amdgcn_s_memrealtime();
-        float* const cur = buf0 + (k % NBUF) * T::kBufFloats;
-        if (k + NBUF - 1 < nchunks && !(p.debug_flags & 2))
-            stage(chunk_begin + k + NBUF - 1, buf0 + ((k + NBUF - 1) % NBUF) * T::kBufFloats);
-        const float* Wl = cur + aoff;
-        const float* Pl = cur + T::kWlRegion;
-        const int ci0 = (chunk_begin + k) * KC;
+    int ring = 0;      // buffer of the chunk about to be consumed (persistent blocks: runs on across tiles)
+    int tile_no = 0;   // tiles this block has started (selects the constants set)
+    bool first_chunk_landed = false;  // persistent: the next tile's chunk 0 was waited for before the epilogue
+    while (true) {
+        if (PERSIST) asm volatile("" : "+v"(lane), "+v"(l31), "+v"(lh));
+        const int next_v = v + (int)gridDim.x;
+        const bool has_next = PERSIST && next_v < p.total_tiles;
+        const int set = PERSIST ? (tile_no & 1) : 0;
+        const float* const s_lds = const0 + set * const_floats;
+        const float* const d_lds = s_lds + TB * p.Cin;
+        const float* const b_lds = d_lds + TB * BM;
+        const int m0 = cur.m_tile * BM;
+        const int b0 = cur.tile_b * TB;
+        const int y0 = cur.y0, x0 = cur.x0;
+        const int tw_log2 = cur.tw_log2, PWr = cur.PWr;
+        const int PLANEr = cur.PHr * cur.PWr;
+        const int chunk_begin = cur.split * p.chunks_per_split;
 
-        // Flattened steps u = kk*9 + tap, fully unrolled. The operand fragments of step u+1 are
-        // read from LDS BEFORE the MFMAs of step u are issued (sched_barrier pins that order), so
-        // the matrix pipe never waits on an LDS round trip: one wave alone keeps it busy.
-        // A group = the MT weight fragments of one (kk, tap). B group = the NT patch fragments of
-        // one (kk, shift): a stride-1 conv has one shift per tap, the transposed conv re-uses its
-        // 4 shifts across the 9 taps of a kk, so its B fragments are read once per kk.
-        constexpr int U = 9 * (KC / 2);
-        constexpr int BG = UP ? 4 : 1;
-        float afrag[2][MT];
-        float bfrag[2][BG][NT];
-        float sfrag[2];
-        auto load_a = [&](int u, float (&dst)[MT], float& sdst) {
-            const int kk = u / 9, t = u % 9;
-            // the style scale is read here but multiplied in at the USE step, so that nothing
-            // between two MFMA groups depends on an LDS read issued in the same step
-            sdst = (TB == 1) ? s_lds[lh + ci0 + 2 * kk] : 1.f;
-#pragma unroll
-            for (int i = 0; i < MT; ++i) dst[i] = Wl[(t * KC + 2 * kk) * BM + i * 32];
-        };
-        auto load_b = [&](int kk, int shift, float (&dst)[NT]) {
-#pragma unroll
-            for (int j = 0; j < NT; ++j) {
-                dst[j] = Pl[boff[j] + (2 * kk) * PLANEr + shift_dy<UP>(shift) * PWr + shift_dx<UP>(shift)];
-                if (TB > 1) dst[j] *= s_lds[stb[j] + ci0 + 2 * kk];
-            }
-        };
-        if (p.debug_flags & 4) continue;
-        load_a(0, afrag[0], sfrag[0]);
-        if (UP) {
-#pragma unroll
-            for (int sh = 0; sh < 4; ++sh) load_b(0, sh, bfrag[0][sh]);
-        } else {
-            load_b(0, 0, bfrag[0][0]);
-        }
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int kk = u / 9, t = u % 9;
-            if (u + 1 < U) {
-                load_a(u + 1, afrag[(u + 1) & 1], sfrag[(u + 1) & 1]);
-                if (UP) {
-                    if (t == 8) {
-#pragma unroll
-                        for (int sh = 0; sh < 4; ++sh) load_b(kk + 1, sh, bfrag[(kk + 1) & 1][sh]);
-                    }
-                } else {
-                    load_b((u + 1) / 9, (u + 1) % 9, bfrag[(u + 1) & 1][0]);
-                }
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            const int bsel = UP ? (kk & 1) : (u & 1);
-            const int bgrp = UP ? tap_shift<UP>(t) : 0;
-            float a[MT];
-#pragma unroll
-            for (int i = 0; i < MT; ++i) a[i] = (TB == 1) ? afrag[u & 1][i] * sfrag[u & 1] : afrag[u & 1][i];
-#pragma unroll
-            for (int i = 0; i < MT; ++i)
-#pragma unroll
-                for (int j = 0; j < NT; ++j)
-                    acc[tap_cls<UP>(t)][i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(
-                        a[i], bfrag[bsel][bgrp][j], acc[tap_cls<UP>(t)][i][j], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-    }
-
-    if (p.debug_flags & 16) stamp2 = __builtin_amdgcn_s_memrealtime();
-    // ---- epilogue: demodulate, (noise, bias, leaky relu), store 32 consecutive pixels per reg ----
-    // Per-channel constants come out of LDS in one batch (one exposed LDS round trip, not one per
-    // element); channel-plane pointers advance by adds of two precomputed strides (register r of a
-    // 32x32 accumulator is channel (r&3) + 8(r>>2) + 4*lane_half: +1,+1,+1,+5,...).
-    const bool full = !UP && p.epilogue == kEpilogueFull;
-    const long long stride1 = p.out_c_stride, stride5 = 5 * p.out_c_stride;
-    float* const out = p.out + (size_t)split * p.slab_stride +
-                       (size_t)(m0 + wm * (MT * 32) + 4 * lh) * p.out_c_stride;
-#pragma unroll
-    for (int i = 0; i < MT; ++i) {
-        float dreg[16], breg[16];
-        auto load_consts = [&](int tb) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = wm * (MT * 32) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                dreg[r] = d_lds[tb * BM + m];
-                breg[r] = b_lds[m];
-            }
-        };
-        if (TB == 1) load_consts(0);
+        // ---- per-lane operand offsets ----
+        const int aoff = lh * BM + wm * (MT * 32) + l31;
+        int boff[NT];
+        int stb[NT];
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
             const int n = (wn * NT + j) * 32 + l31;
             const int tb = RT ? 0 : n / (TH * TW);
-            const int oy = y0 + (RT ? (n >> tw_log2) : (n / TW) % TH);
-            const int ox = x0 + (RT ? (n & ((1 << tw_log2) - 1)) : n % TW);
-            const int b = b0 + tb;
-            const bool in_batch = b < p.B;
-            if (TB > 1) load_consts(tb);
-            float nz = 0.f;
-            if (full && p.noise != nullptr && in_batch && oy < p.OH && ox < p.OW)
-                nz = p.noise[(size_t)oy * p.OW + ox] * p.noise_strength;
-            float* const out_px = out + (size_t)b * p.out_b_stride + (size_t)(i * 32) * p.out_c_stride +
-                                  (size_t)(oy + p.out_y_off) * p.out_row_stride + ox + p.out_x_off;
+            const int yy = RT ? (n >> tw_log2) : (n / TW) % TH;
+            const int xx = RT ? (n & ((1 << tw_log2) - 1)) : n % TW;
+            boff[j] = (tb * KC + lh) * PLANEr + (yy + 1) * PWr + (xx + 4);
+            stb[j] = tb * p.Cin + lh;
+        }
+
+        f32x16 acc[NCLS][MT][NT];
 #pragma unroll
-            for (int c = 0; c < NCLS; ++c) {
-                // class c = (py, px): valid positions shrink by one where the parity is odd
-                const bool ok = in_batch && oy < p.OH - (UP ? (c >> 1) : 0) && ox < p.OW - (UP ? (c & 1) : 0);
-                if (!ok || (p.debug_flags & 1)) continue;
-                float* ptr = out_px + (size_t)c * p.cls_stride;
+        for (int c = 0; c < NCLS; ++c)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    float v = acc[c][i][j][r] * dreg[r];
-                    if (full) {
-                        v += nz + breg[r];
-                        v = (v < 0.f ? 0.2f * v : v) * 1.4142135623730951f;
-                    }
-                    if (p.debug_flags & 32) __builtin_nontemporal_store(v, ptr); else *ptr = v;
-                    ptr += ((r & 3) == 3) ? stride5 : stride1;
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[c][i][j][r] = 0.f;
+
+        for (int k = 0; k < nchunks; ++k) {
+            // Each wave waits for ITS pieces of chunk k (counted: the pieces of chunk k+1 it issued
+            // later may stay in flight), then the raw barrier makes chunk k visible to all waves and
+            // proves chunk k-1's buffer is no longer read. No __syncthreads here: its fence would make
+            // hipcc drain vmcnt to 0 and serialise the ring.
+            if (NBUF == 3 && k + 1 < nchunks) {
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(T::kPiecesPerWave) : "memory");
+            } else if (!(PERSIST && k == 0 && first_chunk_landed)) {
+                // (a persistent block already waited for this chunk before the previous tile's
+                // epilogue; its stores, still in flight, must not be waited for here)
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            if (GANCE_DBG(16) && k == 0 && tile_no == 0) stamp1 = __builtin_amdgcn_s_memrealtime();
+            float* const cur_buf = buf0 + (NBUF == 3 ? (k % NBUF) : ring) * T::kBufFloats;
+            float* const nxt_buf = buf0 + (NBUF == 3 ? ((k + NBUF - 1) % NBUF) : (ring ^ 1)) * T::kBufFloats;
+            const bool last = k + NBUF - 1 >= nchunks;
+            int stage_chunk = k + NBUF - 1;
+            bool do_stage = !last;
+            if (last && has_next && k + 1 == nchunks) {
+                // cross-tile prefetch: the next tile's first chunk and constants fly under this
+                // chunk's MFMAs and the epilogue's stores
+                const TileGeom nxt = decode(next_v);
+                stage_setup(nxt);
+                consts_stage(nxt, set ^ 1);
+                stage_chunk = 0;
+                do_stage = true;
+            }
+            if (do_stage && !GANCE_DBG(2)) stage(stage_chunk, nxt_buf);
+            if (NBUF == 2) ring ^= 1;
+            const float* Wl = cur_buf + aoff;
+            const float* Pl = cur_buf + T::kWlRegion;
+            const int ci0 = (chunk_begin + k) * KC;
+
+            // Flattened steps u = kk*9 + tap, fully unrolled. The operand fragments of step u+1 are
+            // read from LDS BEFORE the MFMAs of step u are issued (sched_barrier pins that order), so
+            // the matrix pipe never waits on an LDS round trip: one wave alone keeps it busy.
+            // A group = the MT weight fragments of one (kk, tap). B group = the NT patch fragments of
+            // one (kk, shift): a stride-1 conv has one shift per tap, the transposed conv re-uses its
+            // 4 shifts across the 9 taps of a kk, so its B fragments are read once per kk.
+            constexpr int U = 9 * (KC / 2);
+            constexpr int BG = UP ? 4 : 1;
+            float afrag[2][MT];
+            float bfrag[2][BG][NT];
+            float sfrag[2];
+            auto load_a = [&](int u, float (&dst)[MT], float& sdst) {
+                const int kk = u / 9, t = u % 9;
+                // the style scale is read here but multiplied in at the USE step, so that nothing
+                // between two MFMA groups depends on an LDS read issued in the same step
+                sdst = (TB == 1) ? s_lds[lh + ci0 + 2 * kk] : 1.f;
+#pragma unroll
+                for (int i = 0; i < MT; ++i) dst[i] = Wl[(t * KC + 2 * kk) * BM + i * 32];
+            };
+            auto load_b = [&](int kk, int shift, float (&dst)[NT]) {
+#pragma unroll
+                for (int j = 0; j < NT; ++j) {
+                    dst[j] = Pl[boff[j] + (2 * kk) * PLANEr + shift_dy<UP>(shift) * PWr + shift_dx<UP>(shift)];
+                    if (TB > 1) dst[j] *= s_lds[stb[j] + ci0 + 2 * kk];
                 }
+            };
+            if (GANCE_DBG(4)) continue;
+            load_a(0, afrag[0], sfrag[0]);
+            if (UP) {
+#pragma unroll
+                for (int sh = 0; sh < 4; ++sh) load_b(0, sh, bfrag[0][sh]);
+            } else {
+                load_b(0, 0, bfrag[0][0]);
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int kk = u / 9, t = u % 9;
+                if (u + 1 < U) {
+                    load_a(u + 1, afrag[(u + 1) & 1], sfrag[(u + 1) & 1]);
+                    if (UP) {
+                        if (t == 8) {
+#pragma unroll
+                            for (int sh = 0; sh < 4; ++sh) load_b(kk + 1, sh, bfrag[(kk + 1) & 1][sh]);
+                        }
+                    } else {
+                        load_b((u + 1) / 9, (u + 1) % 9, bfrag[(u + 1) & 1][0]);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                const int bsel = UP ? (kk & 1) : (u & 1);
+                const int bgrp = UP ? tap_shift<UP>(t) : 0;
+                float a[MT];
+#pragma unroll
+                for (int i = 0; i < MT; ++i) a[i] = (TB == 1) ? afrag[u & 1][i] * sfrag[u & 1] : afrag[u & 1][i];
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
+#pragma unroll
+                    for (int j = 0; j < NT; ++j)
+                        acc[tap_cls<UP>(t)][i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(
+                            a[i], bfrag[bsel][bgrp][j], acc[tap_cls<UP>(t)][i][j], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
+
+        if (has_next) {
+            // the next tile's first chunk and constants have had a whole chunk of MFMAs to land:
+            // wait for them now, so that the stores below are the only vector-memory operations
+            // still in flight when the next tile starts (vmcnt counts in issue order)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            first_chunk_landed = true;
+        }
+
+        if (GANCE_DBG(16) && tile_no == 0) stamp2 = __builtin_amdgcn_s_memrealtime();
+        // ---- epilogue: demodulate, (noise, bias, leaky relu), store 32 consecutive pixels per reg ----
+        // Per-channel constants come out of LDS in one batch (one exposed LDS round trip, not one per
+        // element). Stores are MUBUF with the channel plane in the SCALAR offset (register r of a
+        // 32x32 accumulator is channel (r&3) + 8(r>>2) + 4*lane_half): the per-lane byte offset of a
+        // pixel is computed once per 32-pixel group and no vector ALU work sits between two stores.
+        // The epilogue kind is a uniform branch around the whole store loop, not one per element.
+        const int c_stride_bytes = (int)p.out_c_stride * 4;
+        float* const out_tile = p.out + (size_t)cur.split * p.slab_stride + (size_t)b0 * p.out_b_stride +
+                                (size_t)(m0 + wm * (MT * 32)) * p.out_c_stride;
+        auto emit = [&](auto full_tag) {
+            constexpr bool kFull = decltype(full_tag)::value;
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+                float dreg[16], breg[16];
+                auto load_consts = [&](int tb) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int m = wm * (MT * 32) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                        dreg[r] = d_lds[tb * BM + m];
+                        if (kFull) breg[r] = b_lds[m];
+                    }
+                };
+                if (TB == 1) load_consts(0);
+#pragma unroll
+                for (int j = 0; j < NT; ++j) {
+                    const int n = (wn * NT + j) * 32 + l31;
+                    const int tb = RT ? 0 : n / (TH * TW);
+                    const int oy = y0 + (RT ? (n >> tw_log2) : (n / TW) % TH);
+                    const int ox = x0 + (RT ? (n & ((1 << tw_log2) - 1)) : n % TW);
+                    const bool in_batch = b0 + tb < p.B;
+                    if (TB > 1) load_consts(tb);
+                    float nz = 0.f;
+                    if (kFull && p.noise != nullptr && in_batch && oy < p.OH && ox < p.OW)
+                        nz = p.noise[(size_t)oy * p.OW + ox] * p.noise_strength;
+                    const int voff = ((oy + p.out_y_off) * p.out_row_stride + ox + p.out_x_off) * 4 +
+                                     4 * lh * c_stride_bytes + (TB > 1 ? tb * (int)p.out_b_stride * 4 : 0);
+#pragma unroll
+                    for (int c = 0; c < NCLS; ++c) {
+                        // class c = (py, px): valid positions shrink by one where the parity is odd
+                        const bool ok = in_batch && oy < p.OH - (UP ? (c >> 1) : 0) && ox < p.OW - (UP ? (c & 1) : 0);
+                        if (!ok || GANCE_DBG(1)) continue;
+                        const __amdgpu_buffer_rsrc_t o_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+                            (void*)(out_tile + (size_t)c * p.cls_stride + (size_t)(i * 32) * p.out_c_stride), 0, 0x7fffffff,
+                            0x00020000);
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            float v_out = acc[c][i][j][r] * dreg[r];
+                            if (kFull) {
+                                v_out += nz + breg[r];
+                                v_out = fmaxf(v_out, 0.2f * v_out) * 1.4142135623730951f;  // lrelu(0.2) * sqrt(2)
+                            }
+                            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v_out), o_rsrc, voff, ((r & 3) + 8 * (r >> 2)) * c_stride_bytes, 0);
+                        }
+                    }
+                }
+            }
+        };
+        if (!UP && p.epilogue == kEpilogueFull)
+            emit(std::true_type{});
+        else
+            emit(std::false_type{});
+        if (!has_next) break;
+        v = next_v;
+        cur = decode(v);
+        ++tile_no;
     }
-    if ((p.debug_flags & 16) && tid == 0) {
+    if (GANCE_DBG(16) && tid == 0) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         unsigned int hwid;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
@@ -475,19 +580,36 @@ __global__ __launch_bounds__(256, UP ? 2 : 4) void modconv_mfma_kernel(const Con
     }
 }
 
-template <int BM, int TB, int TH, int TW, int KC, int WM, int WN, bool UP, int NBUF, bool RT = false>
-static hipError_t launch_one(const ConvArgs& a, int total_blocks, hipStream_t stream) {
-    using T = ConvTile<BM, TB, TH, TW, KC, WM, WN, UP, NBUF, RT>;
-    auto kernel = modconv_mfma_kernel<BM, TB, TH, TW, KC, WM, WN, UP, NBUF, RT>;
-    static bool attr_set = false;
-    if (!attr_set) {
+template <int BM, int TB, int TH, int TW, int KC, int WM, int WN, bool UP, int NBUF, bool RT = false, bool PERSIST = false>
+static hipError_t launch_one(const ConvArgs& args, int total_blocks, hipStream_t stream) {
+    using T = ConvTile<BM, TB, TH, TW, KC, WM, WN, UP, NBUF, RT, PERSIST>;
+    auto kernel = modconv_mfma_kernel<BM, TB, TH, TW, KC, WM, WN, UP, NBUF, RT, PERSIST>;
+    static int resident_blocks = 0;  // persistent launch size: what fits the chip at once, a multiple of 8 (XCDs)
+    if (resident_blocks == 0) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
                                            hipFuncAttributeMaxDynamicSharedMemorySize,
                                            (int)T::lds_bytes(512));
         if (e != hipSuccess) return e;
-        attr_set = true;
+        int device = 0, cus = 0, per_cu = 0;
+        if ((e = hipGetDevice(&device)) != hipSuccess) return e;
+        if ((e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device)) != hipSuccess) return e;
+        if ((e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 256, T::lds_bytes(512))) != hipSuccess) return e;
+        resident_blocks = std::max(8, cus * std::max(per_cu, 1) / 8 * 8);
     }
-    hipLaunchKernelGGL(kernel, dim3(total_blocks), dim3(256), T::lds_bytes(a.Cin), stream, a);
+    ConvArgs a = args;
+    a.total_tiles = total_blocks;
+    int grid = total_blocks;
+    if (PERSIST) {
+        // LDS use shrinks with Cin, so more blocks may fit than at Cin = 512: ask for this launch
+        int per_cu = 0, device = 0, cus = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 256, T::lds_bytes(a.Cin)) == hipSuccess &&
+            hipGetDevice(&device) == hipSuccess &&
+            hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && per_cu > 0)
+            grid = std::min(total_blocks, std::max(8, cus * per_cu / 8 * 8));
+        else
+            grid = std::min(total_blocks, resident_blocks);
+    }
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(256), T::lds_bytes(a.Cin), stream, a);
     return hipGetLastError();
 }
 
@@ -511,20 +633,44 @@ const ConvTileInfo kConvTiles[kNumConvTiles] = {
 
 hipError_t launch_modconv(int tile_id, const ConvArgs& a, int total_blocks, hipStream_t stream) {
     // ring depth 2: depth 3 (prefetch distance 2, template parameter NBUF) measured slower, it costs
-    // a resident block per CU and DMA latency is already covered
+    // a resident block per CU and DMA latency is already covered.
+    // Persistent blocks (PERSIST: a block strides over tiles and fetches the next tile's first chunk
+    // under the current tile's last MFMAs and epilogue) were built and measured: 4 % slower over
+    // the whole path, +-0 % on the runtime-geometry tile alone; the hardware's own workgroup
+    // turnover is cheaper than the scalar state a tile loop keeps alive. The variants are only
+    // instantiated with -DGANCE_CONV_PERSIST=1 (GANCE_TUNE_PERSIST = bit mask over tile ids).
+#if GANCE_CONV_PERSIST
+    static const unsigned persist_mask = [] {
+        const char* v = std::getenv("GANCE_TUNE_PERSIST");
+        return v ? (unsigned)std::strtoul(v, nullptr, 0) : 0u;
+    }();
+    const bool persist = (persist_mask >> tile_id) & 1u;
+#define GANCE_CASE(id, ...)                                                              \
+    case id:                                                                             \
+        return persist ? launch_one<__VA_ARGS__, 2, false, true>(a, total_blocks, stream) \
+                       : launch_one<__VA_ARGS__, 2>(a, total_blocks, stream);
+#else
 #define GANCE_CASE(id, ...) \
     case id:               \
+        return launch_one<__VA_ARGS__, 2>(a, total_blocks, stream);
+#endif
+#define GANCE_CASE_TB(id, ...) \
+    case id:                  \
         return launch_one<__VA_ARGS__, 2>(a, total_blocks, stream);
     switch (tile_id) {
         GANCE_CASE(0, 32, 1, 8, 64, 8, 1, 4, false)
         GANCE_CASE(1, 64, 1, 4, 64, 8, 1, 4, false)
         GANCE_CASE(2, 128, 1, 4, 32, 4, 2, 2, false)
         GANCE_CASE(3, 128, 1, 8, 16, 4, 2, 2, false)
-        GANCE_CASE(4, 128, 2, 8, 8, 4, 2, 2, false)
-        GANCE_CASE(5, 128, 8, 4, 4, 4, 2, 2, false)
+        GANCE_CASE_TB(4, 128, 2, 8, 8, 4, 2, 2, false)
+        GANCE_CASE_TB(5, 128, 8, 4, 4, 4, 2, 2, false)
         GANCE_CASE(6, 32, 1, 16, 16, 8, 1, 4, true)
         GANCE_CASE(7, 64, 1, 8, 16, 8, 2, 2, true)
-        case 8: return launch_one<128, 1, 8, 8, 4, 4, 1, true, 2, true>(a, total_blocks, stream);
+        case 8:
+#if GANCE_CONV_PERSIST
+            if (persist) return launch_one<128, 1, 8, 8, 4, 4, 1, true, 2, true, true>(a, total_blocks, stream);
+#endif
+            return launch_one<128, 1, 8, 8, 4, 4, 1, true, 2, true>(a, total_blocks, stream);
         GANCE_CASE(9, 128, 1, 4, 16, 4, 4, 1, true)
         GANCE_CASE(10, 32, 1, 8, 64, 4, 1, 4, false)
         GANCE_CASE(11, 64, 1, 4, 64, 4, 1, 4, false)
@@ -533,6 +679,7 @@ hipError_t launch_modconv(int tile_id, const ConvArgs& a, int total_blocks, hipS
         default: return hipErrorInvalidValue;
     }
 #undef GANCE_CASE
+#undef GANCE_CASE_TB
 }
 
 }  // namespace gance

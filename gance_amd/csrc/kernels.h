@@ -34,6 +34,7 @@ struct ConvArgs {
     int s_stride, d_stride;
     float noise_strength;
     int tiles_x, tiles_y, m_tiles;
+    int total_tiles;  // virtual blocks of the launch (set by launch_modconv; a persistent grid is smaller)
     // runtime-geometry launches (transposed conv, BM = 128): after the tiles_x*tiles_y main tiles
     // come row_tiles 1x64 tiles on the position row y' = H and col_tiles 64x1 tiles on x' = W
     int row_tiles, col_tiles;

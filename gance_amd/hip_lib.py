@@ -7,6 +7,7 @@ MI355X is visible, calls raise: there is no CPU fallback in the product path.
 """
 
 import ctypes
+import os
 from pathlib import Path
 from typing import Dict, List, NamedTuple, Optional, Tuple
 
@@ -20,7 +21,8 @@ import torch  # noqa: F401  pylint: disable=unused-import
 from gance_amd.stylegan2 import spec as sg2_spec
 
 LIBRARY_NAME = "libgance_hip.so"
-LIBRARY_PATH = Path(__file__).resolve().parent / LIBRARY_NAME
+# GANCE_HIP_LIBRARY: another build of the same ABI (A/B timing of kernel variants); default in-tree
+LIBRARY_PATH = Path(os.environ.get("GANCE_HIP_LIBRARY") or Path(__file__).resolve().parent / LIBRARY_NAME)
 
 GANCE_OK = 0
 GANCE_FLAG_PROFILE_STEPS = 1
