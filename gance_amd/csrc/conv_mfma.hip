@@ -44,6 +44,10 @@
 #ifndef GANCE_CONV_PERSIST
 #define GANCE_CONV_PERSIST 0
 #endif
+// resident blocks per CU the transposed-conv tiles with BM <= 64 are compiled for (register cap 168 at 3)
+#ifndef GANCE_UP_BLOCKS
+#define GANCE_UP_BLOCKS 3
+#endif
 
 namespace gance {
 
@@ -128,7 +132,7 @@ struct TileGeom {
 };
 
 template <int BM, int TB, int TH, int TW, int KC, int WM, int WN, bool UP, int NBUF, bool RT, bool PERSIST>
-__global__ __launch_bounds__(256, UP ? 2 : 4) void modconv_mfma_kernel(const ConvArgs p) {
+__global__ __launch_bounds__(256, UP ? (RT || BM > 64 ? 2 : GANCE_UP_BLOCKS) : 4) void modconv_mfma_kernel(const ConvArgs p) {
     using T = ConvTile<BM, TB, TH, TW, KC, WM, WN, UP, NBUF, RT, PERSIST>;
     constexpr int MT = T::kMT, NT = T::kNT, PH = T::kPH, PW = T::kPW;
     constexpr int NCLS = T::kCls;
@@ -257,7 +261,10 @@ __global__ __launch_bounds__(256, UP ? 2 : 4) void modconv_mfma_kernel(const Con
 #pragma unroll
         for (int r = 0; r < T::kPiecesPerWave; ++r) {
             int g = wave + 4 * r;
-            if (g >= T::kPieces) g -= T::kPieces;  // spare slot: repeat an early piece
+            if (g >= T::kPieces) {
+                if (NBUF == 2) continue;  // uncounted waits: waves need not issue equal piece counts
+                g -= T::kPieces;          // counted vmcnt (ring of 3): spare slot repeats an early piece
+            }
             if (g < T::kWlInstr) {
                 if (g * 256 + lane * 4 < T::kWlFloats)
                     __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, (lds_ptr_t)(buf + g * 256), 16,
