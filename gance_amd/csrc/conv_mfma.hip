@@ -132,7 +132,7 @@ struct TileGeom {
 };
 
 template <int BM, int TB, int TH, int TW, int KC, int WM, int WN, bool UP, int NBUF, bool RT, bool PERSIST>
-__global__ __launch_bounds__(256, UP ? (RT || BM > 64 ? 2 : GANCE_UP_BLOCKS) : 4) void modconv_mfma_kernel(const ConvArgs p) {
+__global__ __launch_bounds__(256, UP ? ((RT && KC >= 4) || (!RT && BM > 64) ? 2 : GANCE_UP_BLOCKS) : 4) void modconv_mfma_kernel(const ConvArgs p) {
     using T = ConvTile<BM, TB, TH, TW, KC, WM, WN, UP, NBUF, RT, PERSIST>;
     constexpr int MT = T::kMT, NT = T::kNT, PH = T::kPH, PW = T::kPW;
     constexpr int NCLS = T::kCls;
@@ -517,6 +517,18 @@ __global__ __launch_bounds__(256, UP ? (RT || BM > 64 ? 2 : GANCE_UP_BLOCKS) : 4
                                 (size_t)(m0 + wm * (MT * 32)) * p.out_c_stride;
         auto emit = [&](auto full_tag) {
             constexpr bool kFull = decltype(full_tag)::value;
+            // the NT noise values of a lane are fetched together, ahead of the store loop
+            float nzv[NT];
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                const int n = (wn * NT + j) * 32 + l31;
+                const int tb = RT ? 0 : n / (TH * TW);
+                const int oy = y0 + (RT ? (n >> tw_log2) : (n / TW) % TH);
+                const int ox = x0 + (RT ? (n & ((1 << tw_log2) - 1)) : n % TW);
+                nzv[j] = 0.f;
+                if (kFull && p.noise != nullptr && b0 + tb < p.B && oy < p.OH && ox < p.OW)
+                    nzv[j] = p.noise[(size_t)oy * p.OW + ox];
+            }
 #pragma unroll
             for (int i = 0; i < MT; ++i) {
                 float dreg[16], breg[16];
@@ -537,9 +549,7 @@ __global__ __launch_bounds__(256, UP ? (RT || BM > 64 ? 2 : GANCE_UP_BLOCKS) : 4
                     const int ox = x0 + (RT ? (n & ((1 << tw_log2) - 1)) : n % TW);
                     const bool in_batch = b0 + tb < p.B;
                     if (TB > 1) load_consts(tb);
-                    float nz = 0.f;
-                    if (kFull && p.noise != nullptr && in_batch && oy < p.OH && ox < p.OW)
-                        nz = p.noise[(size_t)oy * p.OW + ox] * p.noise_strength;
+                    const float nz = nzv[j] * p.noise_strength;
                     const int voff = ((oy + p.out_y_off) * p.out_row_stride + ox + p.out_x_off) * 4 +
                                      4 * lh * c_stride_bytes + (TB > 1 ? tb * (int)p.out_b_stride * 4 : 0);
 #pragma unroll
@@ -636,6 +646,7 @@ const ConvTileInfo kConvTiles[kNumConvTiles] = {
     {64, 1, 4, 64, 4, 0},   // 11: as 1 with KC = 4
     {32, 1, 16, 16, 4, 1},  // 12: as 6 with KC = 4
     {64, 1, 8, 16, 4, 1},   // 13: as 7 with KC = 4
+    {128, 1, 8, 8, 2, 1},   // 14: as 8 with KC = 2 (three resident blocks per CU)
 };
 
 hipError_t launch_modconv(int tile_id, const ConvArgs& a, int total_blocks, hipStream_t stream) {
@@ -683,6 +694,7 @@ hipError_t launch_modconv(int tile_id, const ConvArgs& a, int total_blocks, hipS
         GANCE_CASE(11, 64, 1, 4, 64, 4, 1, 4, false)
         GANCE_CASE(12, 32, 1, 16, 16, 4, 1, 4, true)
         GANCE_CASE(13, 64, 1, 8, 16, 4, 2, 2, true)
+        case 14: return launch_one<128, 1, 8, 8, 2, 4, 1, true, 2, true>(a, total_blocks, stream);
         default: return hipErrorInvalidValue;
     }
 #undef GANCE_CASE

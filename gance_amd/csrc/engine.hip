@@ -114,13 +114,19 @@ int tuned_kc(bool up) {
     static const int conv_kc = [] { const char* v = std::getenv("GANCE_TUNE_KC_CONV"); return v && std::atoi(v) == 8 ? 8 : 4; }();
     return up ? 8 : conv_kc;
 }
-int layer_kc(int cout, bool up) { return layer_bm(cout) == 128 ? 4 : tuned_kc(up); }
+// GANCE_TUNE_KC_UP128 = 2: the wide transposed convs stage 2 input channels per chunk (tile 14)
+int tuned_kc_up128() {
+    static const int kc = [] { const char* v = std::getenv("GANCE_TUNE_KC_UP128"); return v && std::atoi(v) == 2 ? 2 : 4; }();
+    return kc;
+}
+int layer_kc(int cout, bool up) { return layer_bm(cout) == 128 ? (up ? tuned_kc_up128() : 4) : tuned_kc(up); }
 
 int choose_tile(int cout, bool up, int OH, int OW, int B) {
     const bool kc4 = tuned_kc(up) == 4;
     if (cout == 32) return up ? 6 : (kc4 ? 10 : 0);
     if (cout == 64) return up ? 7 : (kc4 ? 11 : 1);
-    const int first = up ? 8 : 2, last = up ? 8 : 5;
+    if (up) return tuned_kc_up128() == 2 ? 14 : 8;
+    const int first = 2, last = 5;
     int best = first;
     long best_tiles = -1;
     for (int id = first; id <= last; ++id) {

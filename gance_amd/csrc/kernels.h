@@ -50,7 +50,7 @@ struct ConvArgs {
 struct ConvTileInfo {
     int BM, TB, TH, TW, KC, up;
 };
-constexpr int kNumConvTiles = 14;
+constexpr int kNumConvTiles = 15;
 extern const ConvTileInfo kConvTiles[kNumConvTiles];
 
 hipError_t launch_modconv(int tile_id, const ConvArgs& args, int total_blocks, hipStream_t stream);
