@@ -153,6 +153,16 @@ SIGNATURES = {
         ctypes.c_int,
         [ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p],
     ),
+    "gance_phash_crops_u8": (
+        ctypes.c_int,
+        [ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.POINTER(ctypes.c_int32), ctypes.c_int32,
+         ctypes.POINTER(ctypes.c_uint64), ctypes.c_void_p],
+    ),
+    "gance_overlay_boxes_u8": (
+        ctypes.c_int,
+        [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32,
+         ctypes.POINTER(ctypes.c_int32), ctypes.c_int32, ctypes.c_void_p],
+    ),
     "gance_gaussian_noise": (
         ctypes.c_int,
         [
@@ -542,5 +552,38 @@ def gaussian_noise_device(  # pylint: disable=too-many-arguments
         lib,
         lib.gance_gaussian_noise(
             d_randn, num_vectors, vector_length, float(sigma_across), float(sigma_within), bounds, d_out, stream or None
+        ),
+    )
+
+
+def phash_crops_device(d_frames: int, num_frames: int, side: int, crops: np.ndarray, stream: int = 0) -> np.ndarray:
+    """
+    Perceptual hashes of crops of uint8 NHWC frames in HBM. `crops` is (n, 5) int32: frame index,
+    x, y, width, height. Returns (n,) uint64 (bit 63 = DCT coefficient (0, 0)).
+    """
+    lib = load_library()
+    crops = np.ascontiguousarray(crops, dtype=np.int32).reshape(-1, 5)
+    hashes = np.zeros((crops.shape[0],), dtype=np.uint64)
+    _check(
+        lib,
+        lib.gance_phash_crops_u8(
+            d_frames, num_frames, side, crops.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)), crops.shape[0],
+            hashes.ctypes.data_as(ctypes.POINTER(ctypes.c_uint64)), stream or None,
+        ),
+    )
+    return hashes
+
+
+def overlay_boxes_device(  # pylint: disable=too-many-arguments
+    d_foreground: int, d_background: int, d_out: int, num_frames: int, side: int, boxes: np.ndarray, stream: int = 0
+) -> None:
+    """Foreground regions around `boxes` ((n, 5) int32: frame, x, y, width, height) written over the background."""
+    lib = load_library()
+    boxes = np.ascontiguousarray(boxes, dtype=np.int32).reshape(-1, 5)
+    _check(
+        lib,
+        lib.gance_overlay_boxes_u8(
+            d_foreground, d_background, d_out, num_frames, side, boxes.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)),
+            boxes.shape[0], stream or None,
         ),
     )

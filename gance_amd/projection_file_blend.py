@@ -7,24 +7,29 @@ projection-file-blend end to end: WAV(s) + projection file + network(s) -> frame
 * synthesis is batched, every network is resident, and with `torch.distributed` initialised the
   frames are sharded across ranks and gathered in order on rank 0 (gance_amd/frame_sharding.py);
 * the resize to `output_side_length` is the HIP bicubic kernel, on the frames still in HBM;
-* video encoding (ffmpeg / x264), the eye-tracking overlay and the matplotlib debug video are out
-  of scope here: frames are returned / written as a `.npy` uint8 array [N][S][S][3], and asking
-  for the overlay or the debug video raises NotImplementedError.
+* the eye-tracking overlay runs on rank 0 on the gathered frames while they are still in HBM
+  (perceptual hashes and the overlay write are HIP kernels; the landmark detector is external);
+* video encoding (ffmpeg / x264) and the matplotlib debug video are out of scope here: frames are
+  returned / written as a `.npy` uint8 array [N][S][S][3], and asking for the debug video raises
+  NotImplementedError.
 """
 
 from pathlib import Path
-from typing import Iterator, List, Optional, Tuple
+from typing import Iterator, List, NamedTuple, Optional, Tuple
 
 import numpy as np
+import pandas as pd
 import torch
 import torch.distributed as dist
 
 from gance_amd import divisor, frame_sharding, hip_lib
 from gance_amd.data_into_network_visualization import visualization_inputs
+from gance_amd.data_into_network_visualization.visualization_common import DataLabel, ResultLayers
 from gance_amd.logger_common import LOGGER
 from gance_amd.network_interface.network_functions import DEFAULT_MAX_BATCH, TRUNCATION_PSI, MultiNetwork
 from gance_amd.projection import projection_file_reader
-from gance_amd.vector_sources import music
+from gance_amd.overlay import overlay_common, overlay_eye_tracking
+from gance_amd.vector_sources import music, vector_reduction
 from gance_amd.vector_sources.vector_sources_common import underlying_length
 
 
@@ -83,10 +88,12 @@ def shard_synthesize_gather(  # pylint: disable=too-many-arguments
     networks: MultiNetwork,
     output_side_length: int,
     device: torch.device,
-) -> Optional[np.ndarray]:
+    keep_on_device: bool = False,
+):
     """
     Rank 0 holds the per-frame network inputs (and `num_frames`); every rank synthesises its
-    contiguous share and rank 0 gets the frames back in order (None elsewhere).
+    contiguous share and rank 0 gets the frames back in order (None elsewhere): a numpy array,
+    or the uint8 tensor still in HBM with `keep_on_device`.
     """
     world_size = dist.get_world_size() if dist.is_initialized() else 1
     if world_size > 1:
@@ -99,7 +106,90 @@ def shard_synthesize_gather(  # pylint: disable=too-many-arguments
     local = torch.cat(batches) if batches else torch.empty((0, output_side_length, output_side_length, 3), dtype=torch.uint8, device=device)
     frames, _ = frame_sharding.gather_frames(local, num_frames)
     torch.cuda.synchronize(device)
-    return frames.cpu().numpy() if frames is not None else None
+    if frames is None or keep_on_device:
+        return frames
+    return frames.cpu().numpy()
+
+
+class OverlayParameters(NamedTuple):
+    """The eye-tracking overlay options of the reference CLI (projection_file_blend.py:56-76)."""
+
+    phash_distance: int
+    bbox_distance: float
+    track_length: int
+    complexity_change_rolling_sum_window: Optional[int] = None
+    complexity_change_threshold: Optional[int] = None
+    face_finder: Optional[overlay_eye_tracking.FaceFinder] = None  # default: overlay_eye_tracking.FACE_FINDER_FACTORY()
+
+
+def music_complexity_skip_mask(audio: np.ndarray, vector_length: int, window: int, threshold: float) -> List[bool]:
+    """
+    Frames where the music's complexity is changing too fast for an overlay
+    (gance/projection_file_blend.py:192-226): zlib size per vector, rolling average + savgol,
+    first derivative, absolute value, rolling sum; NaN (window not yet full) counts as infinity.
+    """
+    smoothed_sizes = vector_reduction.reduce_vector_gzip_compression_rolling_average(audio, vector_length)
+    derived = vector_reduction.derive_results_layers(smoothed_sizes, order=1).result.data
+    mask = vector_reduction.rolling_sum_results_layers(
+        vector_reduction.absolute_value_results_layers(
+            ResultLayers(result=DataLabel(derived, "Gzipped audio, smoothed, averaged, 1st order derivation."))
+        ),
+        window_length=window,
+    )
+    return list(pd.Series(mask.result.data).fillna(np.inf) > threshold)
+
+
+def apply_eye_tracking_overlay(  # pylint: disable=too-many-arguments,too-many-locals
+    synthesized: torch.Tensor,
+    target_images: np.ndarray,
+    frame_multiplier: int,
+    parameters: OverlayParameters,
+    audio: np.ndarray,
+    vector_length: int,
+) -> torch.Tensor:
+    """
+    The overlay stage of gance/projection_file_blend.py:181-262 on frames in HBM: the projection's
+    target images (each shown `frame_multiplier` times, scaled to the output side) are the
+    foreground, the synthesized frames the background; gate per frame, drop overlay runs shorter
+    than `track_length`, write the eye regions.
+    """
+    num_frames, side = int(synthesized.shape[0]), int(synthesized.shape[1])
+    device = synthesized.device
+    targets = torch.from_numpy(np.ascontiguousarray(target_images)).to(device)
+    if targets.shape[1] != side:
+        resized = torch.empty((targets.shape[0], side, side, 3), dtype=torch.uint8, device=device)
+        hip_lib.resize_bicubic_u8_device(
+            targets.data_ptr(), int(targets.shape[0]), int(targets.shape[1]), resized.data_ptr(), side,
+            torch.cuda.current_stream(device).cuda_stream,
+        )
+        targets = resized
+    foreground = targets.repeat_interleave(frame_multiplier, dim=0)[:num_frames].contiguous()
+    if foreground.shape[0] != num_frames:
+        raise ValueError("the projection file holds too few target images for the frames being written")
+    music_mask = parameters.complexity_change_rolling_sum_window is not None and parameters.complexity_change_threshold is not None
+    skip_mask = (
+        music_complexity_skip_mask(
+            audio, vector_length, parameters.complexity_change_rolling_sum_window, parameters.complexity_change_threshold
+        )[:num_frames]
+        if music_mask
+        else [False] * num_frames
+    )
+    overlay_results = overlay_eye_tracking.compute_eye_tracking_overlay(
+        foreground_images=foreground,
+        background_images=synthesized,
+        min_phash_distance=parameters.phash_distance,
+        min_bbox_distance=parameters.bbox_distance,
+        skip_mask=skip_mask,
+        face_finder=parameters.face_finder,
+    )
+    boxes_list = list(overlay_results.bbox_lists)
+    long_tracks_mask = vector_reduction.track_length_filter(
+        bool_tracks=[not skip and boxes is not None for skip, boxes in zip(skip_mask, boxes_list)],
+        track_length=parameters.track_length,
+    )
+    written = [boxes if in_long_track else None for boxes, in_long_track in zip(boxes_list, long_tracks_mask)]
+    LOGGER.info(f"Eye tracking overlay written on {sum(box is not None for box in written)} of {num_frames} frames")
+    return overlay_common.write_boxes_onto_frames_device(foreground, synthesized, written)
 
 
 def projection_file_blend_frames(  # pylint: disable=too-many-arguments,too-many-locals
@@ -113,10 +203,12 @@ def projection_file_blend_frames(  # pylint: disable=too-many-arguments,too-many
     fft_amplitude_range: Tuple[int, int],
     projection_file_path: str,
     blend_depth: int,
+    overlay: Optional[OverlayParameters] = None,
 ) -> Optional[np.ndarray]:
     """
     The pipeline of `projection_file_blend_api`, returning the frames [N][S][S][3] uint8 (on rank
-    0; None on other ranks when running distributed).
+    0; None on other ranks when running distributed). With `overlay`, rank 0 runs the
+    eye-tracking overlay on the gathered frames before they leave HBM.
     """
     rank = dist.get_rank() if dist.is_initialized() else 0
     device = torch.device("cuda", torch.cuda.current_device())
@@ -125,11 +217,15 @@ def projection_file_blend_frames(  # pylint: disable=too-many-arguments,too-many
         vector_length = networks.expected_vector_length
         dlatents = indices = None
         num_frames = 0
+        target_images = audio = None
+        frame_multiplier = 1
         if rank == 0:
             # the audio -> latent stage has global dependencies over a few MB: once, on rank 0
             with projection_file_reader.load_projection_file(Path(projection_file_path)) as reader:
                 final_latents = projection_file_reader.final_latents_matrices_label(reader)
                 attributes = reader.projection_attributes
+                if overlay is not None:
+                    target_images = np.stack(list(reader.target_images))
             final_latents_in_file = underlying_length(final_latents.data) / vector_length
             LOGGER.info(
                 f"Reading projection file. Complete: {attributes.complete}, "
@@ -151,7 +247,13 @@ def projection_file_blend_frames(  # pylint: disable=too-many-arguments,too-many
             if frames_to_visualize is not None:
                 dlatents, indices = dlatents[:frames_to_visualize], indices[:frames_to_visualize]
             num_frames = int(dlatents.shape[0])
-        return shard_synthesize_gather(dlatents, indices, num_frames, networks, output_side_length, device)
+        frames = shard_synthesize_gather(
+            dlatents, indices, num_frames, networks, output_side_length, device, keep_on_device=overlay is not None
+        )
+        if overlay is None or frames is None:
+            return frames
+        blended = apply_eye_tracking_overlay(frames, target_images, int(frame_multiplier), overlay, audio, vector_length)
+        return blended.cpu().numpy()
     finally:
         networks.unload()
 
@@ -182,7 +284,8 @@ def projection_file_blend_api(  # pylint: disable=too-many-arguments,too-many-lo
     written to `output_path` as a `.npy` uint8 array (no video encoder here).
     :raises ValueError: the reference's own checks (music mask without overlay, invalid projection file,
     non-integer fps ratio).
-    :raises NotImplementedError: overlay or debug video requested (next rows).
+    :raises NotImplementedError: debug video requested (out of scope), or the overlay requested
+    without a landmark detector (face_recognition / dlib is not installed; see overlay_eye_tracking).
     """
     overlay_enabled = all(param is not None for param in (phash_distance, bbox_distance, track_length))
     overlay_music_mask_enabled = all(
@@ -190,13 +293,18 @@ def projection_file_blend_api(  # pylint: disable=too-many-arguments,too-many-lo
     )
     if overlay_music_mask_enabled and not overlay_enabled:
         raise ValueError("Overlay music mask without overlay being enabled is not supported!")
-    if overlay_enabled:
-        raise NotImplementedError("the eye-tracking overlay gate is not built yet (DESIGN.md section 9)")
     if debug_path is not None:
         raise NotImplementedError("the matplotlib debug video is out of scope")
+    overlay = (
+        OverlayParameters(
+            phash_distance, bbox_distance, track_length, complexity_change_rolling_sum_window, complexity_change_threshold
+        )
+        if overlay_enabled
+        else None
+    )
     frames = projection_file_blend_frames(
         wav, network_paths, frames_to_visualize, output_fps, output_side_length, alpha, fft_roll_enabled,
-        fft_amplitude_range, projection_file_path, blend_depth,
+        fft_amplitude_range, projection_file_path, blend_depth, overlay,
     )
     if frames is not None and output_path is not None:
         np.save(output_path, frames)

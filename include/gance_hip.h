@@ -227,6 +227,28 @@ int gance_resize_bicubic_u8(const uint8_t* d_in, int32_t batch, int32_t src_side
 int gance_gaussian_noise(const float* d_randn, int32_t num_vectors, int32_t vector_length, double sigma_across,
                          double sigma_within, const double* feature_range, float* d_out, void* stream);
 
+/* ---- eye-tracking overlay gate (pixel work only; the landmark detector stays external) ---------
+ * gance_phash_crops_u8 replaces imagehash.phash(Image.fromarray(frame).crop(box)) of
+ * compute_eye_tracking_overlay (gance/overlay/overlay_eye_tracking.py:100-108): PIL convert("L"),
+ * PIL resize((32, 32), LANCZOS), scipy.fftpack.dct on both axes, top-left 8x8 > median.
+ * d_frames [num_frames][side][side][3] uint8 (device); h_crops [num_crops][5] int32 (host):
+ * frame index, x, y, width, height (a BoundingBox, overlay_common.py:19-27), inside the frame;
+ * h_hashes [num_crops] uint64 (host): bit 63 = coefficient (0,0), row-major, i.e. the integer
+ * whose hex string is str(imagehash.ImageHash). The phash distance is popcount(a ^ b).
+ * Returns after `stream` has drained. */
+int gance_phash_crops_u8(const uint8_t* d_frames, int32_t num_frames, int32_t side, const int32_t* h_crops,
+                         int32_t num_crops, uint64_t* h_hashes, void* stream);
+
+/* gance_overlay_boxes_u8 replaces write_boxes_onto_image (gance/overlay/overlay_common.py:104-172):
+ * out = background, and foreground inside the padded rectangle _draw_mask draws around each
+ * bounding box (x_pad = 0.098 side, y_pad = 0.058 side around the box's vertical centre, PIL
+ * polygon with outline: inclusive integer bounds, corners truncated toward zero).
+ * All three frame arrays are [num_frames][side][side][3] uint8 on the device; out may alias
+ * background. h_boxes [num_boxes][5] int32 (host): frame index, x, y, width, height.
+ * Returns after `stream` has drained. */
+int gance_overlay_boxes_u8(const uint8_t* d_foreground, const uint8_t* d_background, uint8_t* d_out, int32_t num_frames,
+                           int32_t side, const int32_t* h_boxes, int32_t num_boxes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

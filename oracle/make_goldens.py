@@ -129,6 +129,62 @@ def noise_case(name: str, num_frames: int, seed: int, roll: bool, num_networks: 
     print(f"wrote {name}.npz  ({(GOLDEN_DIR / (name + '.npz')).stat().st_size / 1024:.0f} KiB)")
 
 
+def overlay_cases() -> None:
+    """Known answers of the overlay gate's helpers, from the reference's own functions."""
+    import pandas as pd  # pylint: disable=import-outside-toplevel
+    from gance.overlay import overlay_common as oc  # pylint: disable=import-outside-toplevel,import-error
+    from gance.vector_sources import vector_reduction  # pylint: disable=import-outside-toplevel,import-error
+
+    rng = np.random.RandomState(77)
+    arrays = {}
+    # mask rectangles: sides whose pads have fractional parts on both sides of .5, boxes that
+    # touch every border; stored as the inclusive bounds of the painted region (-1 = nothing painted)
+    mask_rows = []
+    for side in (64, 100, 150, 256, 1000):
+        for _ in range(12):
+            w, h = int(rng.randint(1, side // 2)), int(rng.randint(1, side // 3))
+            x, y = int(rng.randint(0, side - w + 1)), int(rng.randint(0, side - h + 1))
+            mask = np.asarray(oc._draw_mask(oc.ImageResolution(side, side), [oc.BoundingBox(x, y, w, h)]))  # pylint: disable=protected-access
+            ys, xs = np.nonzero(mask)
+            assert set(np.unique(mask)) <= {0, 255}
+            bounds = [xs.min(), ys.min(), xs.max(), ys.max()] if len(ys) else [-1, -1, -1, -1]
+            if len(ys):
+                assert mask[bounds[1] : bounds[3] + 1, bounds[0] : bounds[2] + 1].all()  # a full rectangle
+            mask_rows.append([side, x, y, w, h] + [int(v) for v in bounds])
+    arrays["mask_cases"] = np.array(mask_rows, dtype=np.int64)
+    # one full composite
+    fg = rng.randint(0, 256, (96, 96, 3)).astype(np.uint8)
+    bg = rng.randint(0, 256, (96, 96, 3)).astype(np.uint8)
+    boxes = [oc.BoundingBox(10, 20, 18, 9), oc.BoundingBox(60, 70, 30, 20), oc.BoundingBox(0, 0, 4, 3)]
+    arrays["composite_seed"] = np.array([77], dtype=np.int64)
+    arrays["composite_boxes"] = np.array(boxes, dtype=np.int64)
+    arrays["composite_out"] = oc.write_boxes_onto_image(fg, bg, boxes)
+    arrays["composite_fg"] = fg
+    arrays["composite_bg"] = bg
+    # bounding box distances
+    dist_rows = []
+    for _ in range(20):
+        a = [oc.BoundingBox(*[int(v) for v in rng.randint(0, 200, 4)]) for _ in range(int(rng.randint(1, 4)))]
+        b = [oc.BoundingBox(*[int(v) for v in rng.randint(0, 200, 4)]) for _ in range(int(rng.randint(1, 4)))]
+        result = oc.bounding_box_distance(a, b)
+        dist_rows.append((np.array(a), np.array(b), result.distance, np.array(result.a_box), np.array(result.b_box)))
+    arrays["distance_count"] = np.array([len(dist_rows)], dtype=np.int64)
+    for index, (a, b, dist, a_box, b_box) in enumerate(dist_rows):
+        arrays[f"distance_{index}_a"] = a.astype(np.int64)
+        arrays[f"distance_{index}_b"] = b.astype(np.int64)
+        arrays[f"distance_{index}_result"] = np.concatenate(([dist], a_box, b_box)).astype(np.float64)
+    assert oc.bounding_box_distance([], [oc.BoundingBox(0, 0, 1, 1)]) is None
+    # track length filter
+    tracks = rng.rand(8, 60) > 0.4
+    arrays["tracks_in"] = tracks
+    arrays["tracks_lengths"] = np.array([1, 2, 3, 4, 5, 6, 10, 60], dtype=np.int64)
+    arrays["tracks_out"] = np.array(
+        [vector_reduction.track_length_filter(pd.Series(row), int(length)) for row, length in zip(tracks, arrays["tracks_lengths"])]
+    )
+    np.savez_compressed(GOLDEN_DIR / "overlay.npz", **arrays)
+    print(f"wrote overlay.npz  ({(GOLDEN_DIR / 'overlay.npz').stat().st_size / 1024:.0f} KiB)")
+
+
 def unit_cases() -> None:
     """Known answers for the array helpers of vector_sources_common / vector_reduction."""
     from gance.vector_sources import vector_reduction, vector_sources_common as vsc  # pylint: disable=import-outside-toplevel,import-error
@@ -181,6 +237,7 @@ def main() -> None:
     blend_case("blend_n1800_seed7_roll_k3", 1800, 7, True, 3, 257)
     noise_case("noise_n60_seed0_roll_k3", 60, 0, True, 3, 7)
     noise_case("noise_n600_seed5_noroll_k2", 600, 5, False, 2, 97)
+    overlay_cases()
 
 
 if __name__ == "__main__":

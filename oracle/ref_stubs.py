@@ -78,8 +78,10 @@ def install() -> None:
         _stub("ffmpeg", nodes=_stub("ffmpeg.nodes", FilterableStream=object))
     if "vidgear" not in sys.modules:
         _stub("vidgear", gears=_stub("vidgear.gears", WriteGear=object))
-    for name in ("more_itertools", "resampy"):
+    for name in ("more_itertools", "resampy", "imagehash", "face_recognition"):
         if name not in sys.modules:
             _stub(name)
+    if "lz" not in sys.modules:
+        _stub("lz", transposition=_stub("lz.transposition", transpose=lambda rows: zip(*rows)))
     if str(REFERENCE_ROOT) not in sys.path:
         sys.path.insert(0, str(REFERENCE_ROOT))

@@ -122,3 +122,63 @@ def test_noise_blend_end_to_end(tmp_path: Path) -> None:
         expected = resize_ref.resize_bicubic_u8(stylegan2_ref.convert_images_to_uint8(image), out_side)[0]
         diff = np.abs(frames[frame_index].astype(int) - expected.astype(int))
         assert diff.max() <= 2 and (diff > 0).mean() < 5e-3
+
+
+def test_projection_file_blend_with_eye_tracking_overlay(tmp_path: Path) -> None:
+    """The overlay stage end to end with a stand-in landmark detector, against the oracles on the host."""
+    from gance_amd.overlay import overlay_common  # pylint: disable=import-outside-toplevel
+    from oracle import overlay_ref  # pylint: disable=import-outside-toplevel
+
+    L, num_projection, fps_in, fps_out, side, out_side = 512, 6, 15.0, 30.0, 64, 128
+    num_frames = int(num_projection * fps_out / fps_in)
+    audio = synthetic.synthetic_audio(num_frames, L, seed=71, frames_per_second=fps_out)
+    wav_path = tmp_path / "audio.wav"
+    wavfile.write(str(wav_path), int(L * fps_out), audio)
+    latents = synthetic.synthetic_final_latents(num_projection, L, seed=72)
+    rng = np.random.RandomState(73)
+    targets = (np.kron(rng.rand(num_projection, 8, 8, 3), np.ones((1, 16, 16, 1))) * 255).astype(np.uint8)  # 128 x 128
+    projection_path = tmp_path / "projection.npz"
+    pfr.write_projection_npz(
+        projection_path, latents.reshape(18, num_projection, L).transpose(1, 0, 2), projection_fps=fps_in, target_images=targets
+    )
+    network_path = tmp_path / "net.pkl"
+    network_file.write_random_network(network_path, side, seed=9)
+
+    class EveryFrameHasAFace:  # pylint: disable=too-few-public-methods
+        """Same eye landmarks in every frame except frames whose first pixel is dark (no face)."""
+
+        @staticmethod
+        def face_landmarks(face_image):
+            if int(face_image[0, 0].sum()) < 96:
+                return []
+            return [{"left_eye": ((30, 40), (50, 52)), "right_eye": ((70, 41), (95, 55))}]
+
+    common = dict(
+        wav=[str(wav_path)], network_paths=[network_path], frames_to_visualize=None, output_fps=fps_out,
+        output_side_length=out_side, alpha=0.25, fft_roll_enabled=True, fft_amplitude_range=(-5, 5),
+        projection_file_path=str(projection_path), blend_depth=12,
+    )
+    background = projection_file_blend.projection_file_blend_frames(**common)
+    overlay = projection_file_blend.OverlayParameters(
+        phash_distance=64, bbox_distance=5.0, track_length=3, face_finder=EveryFrameHasAFace()
+    )
+    blended = projection_file_blend.projection_file_blend_frames(**common, overlay=overlay)
+    assert blended.shape == background.shape == (num_frames, out_side, out_side, 3)
+
+    # host restatement: which frames have a face in both pictures, runs >= 3, write the eye box
+    foreground = np.repeat(targets, int(fps_out / fps_in), axis=0)
+    box = overlay_common.landmarks_to_bounding_boxes(EveryFrameHasAFace.face_landmarks(np.full((1, 1, 3), 255)))[0]
+    has_face = [
+        bool(EveryFrameHasAFace.face_landmarks(fg) and EveryFrameHasAFace.face_landmarks(bg)) for fg, bg in zip(foreground, background)
+    ]
+    keep = overlay_ref.track_length_filter(has_face, 3)
+    assert any(keep), "the test should exercise at least one written overlay"
+    for index in range(num_frames):
+        want = overlay_ref.write_boxes_onto_image(foreground[index], background[index], [tuple(box)] if keep[index] else [])
+        assert np.array_equal(blended[index], want), index
+
+    with pytest.raises(NotImplementedError, match="landmark detector"):
+        projection_file_blend.projection_file_blend_api(
+            [str(wav_path)], None, [network_path], None, fps_out, out_side, None, None, None, 0.25, True, (-5, 5),
+            str(projection_path), 12, None, None, 10, 5.0, 3,
+        )

@@ -1,0 +1,100 @@
+"""
+CPU tests of the overlay gate's host logic and of its ORACLE (oracle/overlay_ref.py) against golden
+vectors captured from the reference's own functions (tests/golden/overlay.npz, written by
+oracle/make_goldens.py): mask rectangles of `_draw_mask`, a full `write_boxes_onto_image`
+composite, `bounding_box_distance`, `track_length_filter`.
+"""
+
+import numpy as np
+import pytest
+
+from gance_amd.data_into_network_visualization.visualization_common import DataLabel, ResultLayers
+from gance_amd.vector_sources import vector_reduction
+from oracle import overlay_ref
+
+
+@pytest.fixture(scope="module")
+def golden(golden_dir):
+    return np.load(golden_dir / "overlay.npz")
+
+
+def test_mask_rectangles_match_the_reference(golden) -> None:
+    for side, x, y, w, h, left, upper, right, lower in golden["mask_cases"]:
+        got = overlay_ref.draw_mask_bounds(int(side), (int(x), int(y), int(w), int(h)))
+        clipped = (max(got[0], 0), max(got[1], 0), min(got[2], side - 1), min(got[3], side - 1))
+        assert clipped == (left, upper, right, lower), (side, x, y, w, h)
+
+
+def test_composite_matches_the_reference(golden) -> None:
+    boxes = [tuple(int(v) for v in box) for box in golden["composite_boxes"]]
+    out = overlay_ref.write_boxes_onto_image(golden["composite_fg"], golden["composite_bg"], boxes)
+    assert np.array_equal(out, golden["composite_out"])
+
+
+def test_bounding_box_distance_matches_the_reference(golden) -> None:
+    from gance_amd.overlay import overlay_common  # pylint: disable=import-outside-toplevel
+
+    for index in range(int(golden["distance_count"][0])):
+        a = [tuple(int(v) for v in box) for box in golden[f"distance_{index}_a"]]
+        b = [tuple(int(v) for v in box) for box in golden[f"distance_{index}_b"]]
+        want = golden[f"distance_{index}_result"]
+        dist, a_box, b_box = overlay_ref.bounding_box_distance(a, b)
+        assert dist == want[0] and a_box == tuple(want[1:5]) and b_box == tuple(want[5:9])
+        mirrored = overlay_common.bounding_box_distance(
+            [overlay_common.BoundingBox(*box) for box in a], [overlay_common.BoundingBox(*box) for box in b]
+        )
+        assert mirrored.distance == want[0]
+        assert tuple(mirrored.a_box) == tuple(want[1:5]) and tuple(mirrored.b_box) == tuple(want[5:9])
+    assert overlay_ref.bounding_box_distance([], [(0, 0, 1, 1)]) is None
+    assert overlay_common.bounding_box_distance([], [overlay_common.BoundingBox(0, 0, 1, 1)]) is None
+
+
+def test_track_length_filter_matches_the_reference(golden) -> None:
+    for row, length, want in zip(golden["tracks_in"], golden["tracks_lengths"], golden["tracks_out"]):
+        assert overlay_ref.track_length_filter(row, int(length)) == list(want)
+        assert vector_reduction.track_length_filter(row, int(length)) == list(want)
+
+
+def test_landmarks_to_bounding_boxes_is_the_opencv_rectangle() -> None:
+    """cv2.boundingRect of integer points: min corner, extent + 1 (overlay_common.py:46-57)."""
+    from gance_amd.overlay import overlay_common  # pylint: disable=import-outside-toplevel
+
+    landmarks = [{"left_eye": ((10, 20), (14, 22), (12, 19)), "right_eye": ((30, 21), (34, 25)), "chin": ((0, 0),)}]
+    assert overlay_common.landmarks_to_bounding_boxes(landmarks) == [overlay_common.BoundingBox(10, 19, 25, 7)]
+    assert overlay_common.convert_to_pil_box(overlay_common.BoundingBox(1, 2, 3, 4)) == (1, 2, 4, 6)
+    assert overlay_common.bounding_box_center(overlay_common.BoundingBox(0, 0, 10, 5)) == (5.0, 2.5)
+
+
+@pytest.mark.parametrize("data,expected", [(np.arange(0, 10, 1), 1.0), (np.arange(0, 10, 2), 2.0), (np.full(10, np.nan), 0.0)])
+def test_derive_constant_slopes(data, expected) -> None:
+    """The reference's own known answers (test/test_vector_reduction.py:139-167)."""
+    derived = vector_reduction._derive_data(data=data, order=1)  # pylint: disable=protected-access
+    assert np.allclose(derived, expected)
+
+
+def test_music_mask_chain_shapes() -> None:
+    """gzip size -> rolling average -> derivative -> abs -> rolling sum, as projection_file_blend.py:192-217 chains them."""
+    rng = np.random.RandomState(3)
+    audio = np.concatenate([rng.randn(512).astype(np.float32) * scale for scale in np.linspace(0.01, 1.0, 40)])
+    sizes = vector_reduction.reduce_vector_gzip_compression_rolling_average(audio, 512)
+    assert sizes.layers[-1].label == "Gzipped Audio" and len(sizes.result.data) == 40
+    derived = vector_reduction.derive_results_layers(sizes, order=1)
+    mask = vector_reduction.rolling_sum_results_layers(
+        vector_reduction.absolute_value_results_layers(ResultLayers(result=DataLabel(derived.result.data, "d"))), window_length=5
+    )
+    assert np.isnan(mask.result.data[:4]).all() and (mask.result.data[4:] >= 0).all()
+    assert mask.result.label == "Rolling Sum (window=5)" and mask.layers[0].label == "Absolute Value"
+
+
+def test_phash_oracle_is_a_perceptual_hash() -> None:
+    """Identical crops hash equal; a brightness offset keeps the AC bits; an unrelated crop differs in many bits."""
+    rng = np.random.RandomState(5)
+    field = rng.rand(12, 12, 3)
+    image = (np.kron(field, np.ones((16, 16, 1))) * 255).astype(np.uint8)  # 192 x 192 blocky picture
+    other = (np.kron(rng.rand(12, 12, 3), np.ones((16, 16, 1))) * 255).astype(np.uint8)
+    box = (20, 30, 120, 90)
+    base = overlay_ref.phash(image, box)
+    assert overlay_ref.phash_distance(base, overlay_ref.phash(image.copy(), box)) == 0
+    brighter = np.clip(image.astype(int) + 10, 0, 255).astype(np.uint8)
+    assert overlay_ref.phash_distance(base, overlay_ref.phash(brighter, box)) <= 6
+    assert overlay_ref.phash_distance(base, overlay_ref.phash(other, box)) >= 16
