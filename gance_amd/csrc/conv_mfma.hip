@@ -118,10 +118,10 @@ struct ConvTile {
     static_assert(!RT || (UP && TB == 1 && kBN == 64 && NBUF == 2), "runtime geometry: 64-position up tiles");
     static_assert(!PERSIST || (TB == 1 && NBUF == 2), "persistent blocks: one sample per tile, ring depth 2");
     // dynamic LDS: NBUF staging buffers + style [TB][Cin] + demod [TB][BM] + bias [BM]
-    // (persistent blocks: two sets of the constants, alternating per tile)
+    // (persistent blocks: two sets of the constants, alternating per tile) + ToRGB coefficients [BM][4]
     static constexpr int kConstSets = PERSIST ? 2 : 1;
     static size_t lds_bytes(int cin) {
-        return sizeof(float) * (NBUF * (size_t)kBufFloats + kConstSets * ((size_t)TB * cin + (size_t)TB * BM + BM));
+        return sizeof(float) * (NBUF * (size_t)kBufFloats + kConstSets * ((size_t)TB * cin + (size_t)TB * BM + BM) + 4 * BM);
     }
 };
 
@@ -336,8 +336,14 @@ __global__ __launch_bounds__(256, UP ? ((RT && KC >= 4) || (!RT && BM > 64) ? 2 
     // ring prologue: NBUF-1 chunks in flight before the first MFMA
     stage(0, buf0);
     if (NBUF == 3 && nchunks > 1) stage(1, buf0 + T::kBufFloats);
+    float* const rgb_lds = const0 + T::kConstSets * const_floats;  // [BM][4]: style * weight of the fused ToRGB
     if (TB == 1) {
         consts_stage(cur, 0);
+        if (!UP && WM == 1 && MT == 1 && p.epilogue == kEpilogueRgb && tid < BM) {
+            const float sv = p.rgb_s[(size_t)min(cur.tile_b, p.B - 1) * p.s_stride + tid];
+            const float* wv = p.rgb_w + tid * 3;
+            *reinterpret_cast<float4*>(rgb_lds + tid * 4) = make_float4(sv * wv[0], sv * wv[1], sv * wv[2], 0.f);
+        }
     } else {
         float* s_lds = const0;
         float* d_lds = s_lds + TB * p.Cin;
@@ -573,10 +579,93 @@ __global__ __launch_bounds__(256, UP ? ((RT && KC >= 4) || (!RT && BM > 64) ? 2 
                 }
             }
         };
-        if (!UP && p.epilogue == kEpilogueFull)
-            emit(std::true_type{});
-        else
-            emit(std::false_type{});
+        // ---- last layer: activation -> ToRGB -> + skip image -> uint8, nothing but the image is stored.
+        // A wave holds every output channel of its pixels (WM == 1): lane half lh has channels
+        // (r&3) + 8(r>>2) + 4 lh of each 32-channel group, so a pixel's RGB is 16 * MT fused
+        // multiply-adds per lane and one exchange between the two lane halves.
+        auto emit_rgb = [&]() {
+            const int R = p.OW;
+            const int Rh = R >> 1;
+            // upsample_2d of the previous skip image ([1,3,3,1]/4 per axis = two taps per axis): lane
+            // half 0 fetches the upper source row of its pixels, half 1 the lower one; the weighted
+            // halves join the channel sums before the one exchange between the lane halves. All
+            // loads of the wave's NT pixel groups are issued together, ahead of the arithmetic.
+            float up[NT][3];
+            float nzv[NT];
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                const int n = (wn * NT + j) * 32 + l31;
+                const int oy = y0 + (n / TW) % TH;
+                const int ox = x0 + n % TW;
+                const bool ok = b0 < p.B && oy < p.OH && ox < p.OW;
+                nzv[j] = (p.noise != nullptr && ok) ? p.noise[(size_t)oy * p.OW + ox] : 0.f;
+                const int ya = (oy & 1) ? (oy >> 1) : (oy >> 1) - 1;
+                const int row = ya + lh;
+                const float wrow = ((oy & 1) != 0) == (lh == 0) ? 0.75f : 0.25f;  // (odd: .75, .25) (even: .25, .75)
+                const int xa = (ox & 1) ? (ox >> 1) : (ox >> 1) - 1, xb = xa + 1;
+                const float wxa = (ox & 1) ? 0.75f : 0.25f, wxb = 1.0f - wxa;
+                const bool row_ok = p.rgb_y_prev != nullptr && ok && row >= 0 && row < Rh;
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    const float* yp = p.rgb_y_prev + (((size_t)b0 * 3 + k) * Rh + (row_ok ? row : 0)) * Rh;
+                    const float va = (row_ok && xa >= 0) ? yp[xa] : 0.f;
+                    const float vb = (row_ok && xb < Rh) ? yp[xb] : 0.f;
+                    up[j][k] = wrow * (wxa * va + wxb * vb);
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                const int n = (wn * NT + j) * 32 + l31;
+                const int oy = y0 + (n / TW) % TH;
+                const int ox = x0 + n % TW;
+                const bool ok = b0 < p.B && oy < p.OH && ox < p.OW;
+                const float nz = nzv[j] * p.noise_strength;
+                float rgb[3] = {up[j][0], up[j][1], up[j][2]};
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    float v_out = acc[0][0][j][r] * d_lds[m];
+                    v_out += nz + b_lds[m];
+                    v_out = fmaxf(v_out, 0.2f * v_out) * 1.4142135623730951f;
+                    const float4 coef = *reinterpret_cast<const float4*>(rgb_lds + m * 4);
+                    rgb[0] = fmaf(v_out, coef.x, rgb[0]);
+                    rgb[1] = fmaf(v_out, coef.y, rgb[1]);
+                    rgb[2] = fmaf(v_out, coef.z, rgb[2]);
+                }
+#pragma unroll
+                for (int k = 0; k < 3; ++k) rgb[k] += __shfl_xor(rgb[k], 32);
+                if (lh == 0 && ok && !GANCE_DBG(1)) {
+                    const size_t pix = (size_t)oy * R + ox;
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) {
+                        const float y = rgb[k] + p.rgb_bias[k];
+                        if (p.rgb_y != nullptr) p.rgb_y[((size_t)b0 * 3 + k) * R * R + pix] = y;
+                        if (p.rgb_u8 != nullptr) {
+                            // tf.saturate_cast(x * 127.5 + 128): two roundings (the barrier keeps them apart)
+                            float q = y * 127.5f;
+                            asm volatile("" : "+v"(q));
+                            q += 128.0f;
+                            q = fminf(fmaxf(q, 0.f), 255.f);
+                            p.rgb_u8[((size_t)b0 * R * R + pix) * 3 + k] = (unsigned char)(int)q;
+                        }
+                    }
+                }
+            }
+        };
+        if constexpr (!UP && TB == 1 && WM == 1 && MT == 1 && !RT) {
+            if (p.epilogue == kEpilogueRgb) {
+                emit_rgb();
+            } else if (p.epilogue == kEpilogueFull) {
+                emit(std::true_type{});
+            } else {
+                emit(std::false_type{});
+            }
+        } else {
+            if (!UP && p.epilogue == kEpilogueFull)
+                emit(std::true_type{});
+            else
+                emit(std::false_type{});
+        }
         if (!has_next) break;
         v = next_v;
         cur = decode(v);

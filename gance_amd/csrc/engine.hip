@@ -112,7 +112,8 @@ int layer_bm(int cout) { return cout == 32 ? 32 : (cout == 64 ? 64 : 128); }
 // GANCE_TUNE_KC_CONV = 4 or 8 (read once). Transposed convs use 8.
 int tuned_kc(bool up) {
     static const int conv_kc = [] { const char* v = std::getenv("GANCE_TUNE_KC_CONV"); return v && std::atoi(v) == 8 ? 8 : 4; }();
-    return up ? 8 : conv_kc;
+    static const int up_kc = [] { const char* v = std::getenv("GANCE_TUNE_KC_UP"); return v && std::atoi(v) == 4 ? 4 : 8; }();
+    return up ? up_kc : conv_kc;
 }
 // GANCE_TUNE_KC_UP128 = 2: the wide transposed convs stage 2 input channels per chunk (tile 14)
 int tuned_kc_up128() {
@@ -123,8 +124,8 @@ int layer_kc(int cout, bool up) { return layer_bm(cout) == 128 ? (up ? tuned_kc_
 
 int choose_tile(int cout, bool up, int OH, int OW, int B) {
     const bool kc4 = tuned_kc(up) == 4;
-    if (cout == 32) return up ? 6 : (kc4 ? 10 : 0);
-    if (cout == 64) return up ? 7 : (kc4 ? 11 : 1);
+    if (cout == 32) return up ? (kc4 ? 12 : 6) : (kc4 ? 10 : 0);
+    if (cout == 64) return up ? (kc4 ? 13 : 7) : (kc4 ? 11 : 1);
     if (up) return tuned_kc_up128() == 2 ? 14 : 8;
     const int first = 2, last = 5;
     int best = first;
@@ -228,6 +229,7 @@ struct gance_engine {
     std::string profile_only;  // non-empty: bracket only launches whose name contains it
     int steps_used = 0;
     int debug_stop_after = 0;
+    bool keep_skip_image = false;  // the caller will read the final fp32 skip image out of ybuf
     int last_act_layer = 0, last_act_c = 0, last_act_side = 0;
     hipStream_t last_stream = nullptr;
 };
@@ -284,12 +286,27 @@ struct StepScope {
     }
 };
 
+// the ToRGB a last-layer conv launch absorbs (kEpilogueRgb)
+struct FusedRgb {
+    const float *w, *s, *bias, *y_prev;
+    float* y;
+    uint8_t* u8;
+};
+
 int run_conv(gance_engine* e, const ConvLayerHost& c, int li, const LayerPlan& p, const float* x,
              long long x_b_stride, int H, int W, float* out, int epilogue, int out_row_stride,
              int out_y_off, int out_x_off, long long out_b_stride, long long out_c_stride,
              long long slab_stride, long long cls_stride, int B, hipStream_t stream,
-             const char* name) {
+             const char* name, const FusedRgb* rgb = nullptr) {
     gance::ConvArgs a{};
+    if (rgb != nullptr) {
+        a.rgb_w = rgb->w;
+        a.rgb_s = rgb->s;
+        a.rgb_bias = rgb->bias;
+        a.rgb_y_prev = rgb->y_prev;
+        a.rgb_y = rgb->y;
+        a.rgb_u8 = rgb->u8;
+    }
     a.x = x;
     a.w = e->pool + e->conv_w[li];
     a.s = e->styles + e->conv_s_off[li];
@@ -332,9 +349,13 @@ int run_conv(gance_engine* e, const ConvLayerHost& c, int li, const LayerPlan& p
         if (stamps == nullptr) hipMalloc((void**)&stamps, (size_t)5 * 8 * 65536);
         a.debug_stamps = stamps;
     }
-    const double flops = 2.0 * 9 * (double)c.cin * c.cout * H * W * B;
+    double flops = 2.0 * 9 * (double)c.cin * c.cout * H * W * B;
     const double out_elems = (double)B * c.cout * (c.up ? 4.0 * H * W : (double)H * W) * p.nsplit;
-    const double bytes = 4.0 * ((double)B * c.cin * H * W + out_elems + 9.0 * c.cin * c.cout);
+    double bytes = 4.0 * ((double)B * c.cin * H * W + out_elems + 9.0 * c.cin * c.cout);
+    if (rgb != nullptr) {  // no activation leaves the chip: the uint8 image and the half-size skip image instead
+        flops += 2.0 * 3 * (double)c.cout * H * W * B;
+        bytes = 4.0 * ((double)B * c.cin * H * W + 9.0 * c.cin * c.cout + 0.75 * B * H * W) + 3.0 * B * H * W;
+    }
     StepScope scope(e, stream, name, flops, bytes);
     GANCE_HIP_CHECK(gance::launch_modconv(p.tile_id, a, p.total_blocks, stream));
     if ((debug_flags & 16) && p.total_blocks <= 65536) {
@@ -388,6 +409,7 @@ int synthesize_from_dlat(gance_engine* e, const float* d_dlat, int B, uint8_t* d
     const float* x_in = e->pool + e->const_off;  // zero-bordered [512][6][12], shared by the batch
     long long x_b_stride = 0;
 
+    bool fused_rgb = false;
     for (int li = 0; li < limit; ++li) {
         const ConvLayerHost& c = e->convs[li];
         const int res = 1 << c.res_log2;
@@ -401,7 +423,23 @@ int synthesize_from_dlat(gance_engine* e, const float* d_dlat, int B, uint8_t* d
         if (!c.up) {
             std::snprintf(name, sizeof(name), "conv%d_%dx%d_%d->%d", c.layer_idx, res, res, c.cin,
                           c.cout);
-            if (p.nsplit == 1) {
+            // the network's last conv absorbs its ToRGB when one block holds all channels of a pixel
+            // (BM = Cout = 32, i.e. the 1024^2 generator): neither its activation nor the fp32 image is
+            // written, only the uint8 frame (GANCE_TUNE_FUSE_RGB=0 turns this off)
+            static const bool fuse_enabled = [] { const char* v = std::getenv("GANCE_TUNE_FUSE_RGB"); return !(v && std::atoi(v) == 0); }();
+            const auto& tile = gance::kConvTiles[p.tile_id];
+            fused_rgb = fuse_enabled && c.res_log2 == e->res_log2 && limit == num_convs && p.nsplit == 1 &&
+                        p.m_tiles == 1 && tile.TB == 1 && tile.BM == 32 && have_y;
+            if (fused_rgb) {
+                const int ri = c.res_log2 - 2;
+                FusedRgb rgb{e->pool + e->rgb_w[ri], e->styles + e->rgb_s_off[ri], e->pool + e->rgb_bias[ri],
+                             e->ybuf[ycur], (d_f32 != nullptr || e->keep_skip_image) ? e->ybuf[1 - ycur] : nullptr, d_u8};
+                std::snprintf(name, sizeof(name), "conv%d+torgb_%dx%d_%d->%d", c.layer_idx, res, res, c.cin, c.cout);
+                int rc = run_conv(e, c, li, p, x_in, x_b_stride, res, res, x_out, gance::kEpilogueRgb, res + 8, 1, 4,
+                                  out_b, out_c, 0, 0, B, stream, name, &rgb);
+                if (rc) return rc;
+                ycur = 1 - ycur;
+            } else if (p.nsplit == 1) {
                 int rc = run_conv(e, c, li, p, x_in, x_b_stride, res, res, x_out,
                                   gance::kEpilogueFull, res + 8, 1, 4, out_b, out_c, 0, 0, B, stream,
                                   name);
@@ -455,7 +493,7 @@ int synthesize_from_dlat(gance_engine* e, const float* d_dlat, int B, uint8_t* d
         e->last_act_side = res;
 
         // ToRGB after the 4x4 conv and after every Conv1
-        if (!c.up) {
+        if (!c.up && !fused_rgb) {
             int ri = c.res_log2 - 2;
             const RgbLayerHost& r = e->rgbs[ri];
             gance::ToRgbArgs t{};
@@ -799,8 +837,10 @@ static int host_call(gance_engine* e, const float* h_in, size_t in_floats, int b
     const size_t px = (size_t)e->cfg.resolution * e->cfg.resolution * 3;
     float* d_in = is_z ? e->z_in : e->dlat;
     GANCE_HIP_CHECK(hipMemcpy(d_in, h_in, in_floats * sizeof(float), hipMemcpyHostToDevice));
+    e->keep_skip_image = h_f32 != nullptr;
     int rc = is_z ? gance_synthesize_z(e, d_in, batch, psi, e->u8buf, nullptr, nullptr)
                   : gance_synthesize_w(e, d_in, batch, e->u8buf, nullptr, nullptr);
+    e->keep_skip_image = false;
     if (rc) return rc;
     GANCE_HIP_CHECK(hipDeviceSynchronize());
     if (e->debug_stop_after > 0) return GANCE_OK;

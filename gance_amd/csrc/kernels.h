@@ -16,6 +16,10 @@ int set_last_error(int code, const std::string& message);
 constexpr int kMaxTaps = 9;
 constexpr int kEpilogueRaw = 0;   // out = acc * d            (split-K slabs, transposed-conv planes)
 constexpr int kEpilogueFull = 1;  // out = lrelu(acc * d + noise * strength + bias) * sqrt(2)
+// kEpilogueFull's activation is not stored but fed straight to the layer's ToRGB (1x1 modulated conv
+// to 3 channels, + bias + upsampled skip image) and converted to uint8 NHWC: the LAST layer of the
+// network, when one wave holds every output channel of its pixels (Cout = BM = 32: the 1024^2 generator)
+constexpr int kEpilogueRgb = 2;
 
 // One launch of the implicit-GEMM modulated convolution (conv_mfma.hip).
 // Activations are zero-bordered: x is [B][Cin][H+2][W+8] with the interior at [y+1][x+4].
@@ -43,6 +47,15 @@ struct ConvArgs {
     int out_row_stride, out_y_off, out_x_off;
     long long out_b_stride, out_c_stride, slab_stride, cls_stride;
     long long x_b_stride;  // Cin*(H+2)*(W+8), or 0 when every sample reads the same tensor
+    // kEpilogueRgb only: ToRGB weight [Cout][3] (runtime-scaled), its style rgb_s[b*s_stride + c], bias [3],
+    // previous skip image [B][3][H/2][W/2] (or nullptr), outputs [B][3][H][W] float (or nullptr) and
+    // [B][H][W][3] uint8 (or nullptr)
+    const float* rgb_w;
+    const float* rgb_s;
+    const float* rgb_bias;
+    const float* rgb_y_prev;
+    float* rgb_y;
+    unsigned char* rgb_u8;
     unsigned long long* debug_stamps;  // [blocks][4] s_memrealtime stamps when debug_flags & 16
     int debug_flags;       // timing ablations only (GANCE_DEBUG_CONV): 1 no stores, 2 no DMA after chunk 0, 4 no MFMA
 };
