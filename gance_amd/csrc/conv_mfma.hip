@@ -45,6 +45,10 @@
 #define GANCE_CONV_PERSIST 0
 #endif
 // resident blocks per CU the transposed-conv tiles with BM <= 64 are compiled for (register cap 168 at 3)
+// wave priority (0..3) raised for the epilogue, experiment
+#ifndef GANCE_TUNE_EPILOGUE_PRIO
+#define GANCE_TUNE_EPILOGUE_PRIO 0
+#endif
 #ifndef GANCE_UP_BLOCKS
 #define GANCE_UP_BLOCKS 3
 #endif
@@ -120,8 +124,14 @@ struct ConvTile {
     // dynamic LDS: NBUF staging buffers + style [TB][Cin] + demod [TB][BM] + bias [BM]
     // (persistent blocks: two sets of the constants, alternating per tile) + ToRGB coefficients [BM][4]
     static constexpr int kConstSets = PERSIST ? 2 : 1;
+    // the fused last-layer ToRGB (kEpilogueRgb): its coefficients [BM][4] and the tile's window of the
+    // half-resolution skip image [3][TH/2 + 2][TW/2 + 2]
+    static constexpr bool kCanFuseRgb = !UP && !RT && TB == 1 && WM == 1 && kMT == 1;
+    static constexpr int kSkipRows = TH / 2 + 2, kSkipCols = TW / 2 + 2;
+    static constexpr int kSkipFloats = (3 * kSkipRows * kSkipCols + 63) / 64 * 64;
+    static constexpr int kRgbFloats = kCanFuseRgb ? 4 * BM + kSkipFloats : 0;
     static size_t lds_bytes(int cin) {
-        return sizeof(float) * (NBUF * (size_t)kBufFloats + kConstSets * ((size_t)TB * cin + (size_t)TB * BM + BM) + 4 * BM);
+        return sizeof(float) * (NBUF * (size_t)kBufFloats + kConstSets * ((size_t)TB * cin + (size_t)TB * BM + BM) + kRgbFloats);
     }
 };
 
@@ -339,10 +349,32 @@ __global__ __launch_bounds__(256, UP ? ((RT && KC >= 4) || (!RT && BM > 64) ? 2 
     float* const rgb_lds = const0 + T::kConstSets * const_floats;  // [BM][4]: style * weight of the fused ToRGB
     if (TB == 1) {
         consts_stage(cur, 0);
-        if (!UP && WM == 1 && MT == 1 && p.epilogue == kEpilogueRgb && tid < BM) {
-            const float sv = p.rgb_s[(size_t)min(cur.tile_b, p.B - 1) * p.s_stride + tid];
-            const float* wv = p.rgb_w + tid * 3;
-            *reinterpret_cast<float4*>(rgb_lds + tid * 4) = make_float4(sv * wv[0], sv * wv[1], sv * wv[2], 0.f);
+        if constexpr (T::kCanFuseRgb) {
+            if (p.epilogue == kEpilogueRgb) {
+                if (tid < BM) {
+                    const float sv = p.rgb_s[(size_t)min(cur.tile_b, p.B - 1) * p.s_stride + tid];
+                    const float* wv = p.rgb_w + tid * 3;
+                    *reinterpret_cast<float4*>(rgb_lds + tid * 4) = make_float4(sv * wv[0], sv * wv[1], sv * wv[2], 0.f);
+                }
+                // the tile's window of the previous skip image -> LDS by dword LDS-DMA (lands with the
+                // first chunk): the epilogue then has no global load to wait for
+                if (p.rgb_y_prev != nullptr) {
+                    const int Rh = p.OW >> 1;
+                    const __amdgpu_buffer_rsrc_t y_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+                        (void*)(p.rgb_y_prev + (size_t)min(cur.tile_b, p.B - 1) * 3 * Rh * Rh), 0, 0x7fffffff, 0x00020000);
+                    const int row0 = (cur.y0 >> 1) - 1, col0 = (cur.x0 >> 1) - 1;
+                    for (int i = wave; i * 64 < 3 * T::kSkipRows * T::kSkipCols; i += 4) {
+                        const int idx = i * 64 + lane;
+                        const int cc = idx % T::kSkipCols;
+                        const int rr = (idx / T::kSkipCols) % T::kSkipRows;
+                        const int k = idx / (T::kSkipCols * T::kSkipRows);
+                        const int row = row0 + rr, col = col0 + cc;
+                        if (k < 3 && row >= 0 && row < Rh && col >= 0 && col < Rh)
+                            __builtin_amdgcn_raw_ptr_buffer_load_lds(y_rsrc, (lds_ptr_t)(rgb_lds + 4 * BM + i * 64), 4,
+                                                                     ((k * Rh + row) * Rh + col) * 4, 0, 0, 0);
+                    }
+                }
+            }
         }
     } else {
         float* s_lds = const0;
@@ -512,6 +544,7 @@ __global__ __launch_bounds__(256, UP ? ((RT && KC >= 4) || (!RT && BM > 64) ? 2 
         }
 
         if (GANCE_DBG(16) && tile_no == 0) stamp2 = __builtin_amdgcn_s_memrealtime();
+        if (GANCE_TUNE_EPILOGUE_PRIO) __builtin_amdgcn_s_setprio(GANCE_TUNE_EPILOGUE_PRIO);
         // ---- epilogue: demodulate, (noise, bias, leaky relu), store 32 consecutive pixels per reg ----
         // Per-channel constants come out of LDS in one batch (one exposed LDS round trip, not one per
         // element). Stores are MUBUF with the channel plane in the SCALAR offset (register r of a
@@ -586,10 +619,10 @@ __global__ __launch_bounds__(256, UP ? ((RT && KC >= 4) || (!RT && BM > 64) ? 2 
         auto emit_rgb = [&]() {
             const int R = p.OW;
             const int Rh = R >> 1;
-            // upsample_2d of the previous skip image ([1,3,3,1]/4 per axis = two taps per axis): lane
-            // half 0 fetches the upper source row of its pixels, half 1 the lower one; the weighted
-            // halves join the channel sums before the one exchange between the lane halves. All
-            // loads of the wave's NT pixel groups are issued together, ahead of the arithmetic.
+            // upsample_2d of the previous skip image ([1,3,3,1]/4 per axis = two taps per axis), read
+            // from the window the prologue put in LDS: lane half 0 takes the upper source row of its
+            // pixels, half 1 the lower one; the weighted halves join the channel sums before the one
+            // exchange between the lane halves.
             float up[NT][3];
             float nzv[NT];
 #pragma unroll
@@ -605,11 +638,11 @@ __global__ __launch_bounds__(256, UP ? ((RT && KC >= 4) || (!RT && BM > 64) ? 2 
                 const int xa = (ox & 1) ? (ox >> 1) : (ox >> 1) - 1, xb = xa + 1;
                 const float wxa = (ox & 1) ? 0.75f : 0.25f, wxb = 1.0f - wxa;
                 const bool row_ok = p.rgb_y_prev != nullptr && ok && row >= 0 && row < Rh;
+                const float* skip = rgb_lds + 4 * BM + (row - ((y0 >> 1) - 1)) * T::kSkipCols - ((x0 >> 1) - 1);
 #pragma unroll
                 for (int k = 0; k < 3; ++k) {
-                    const float* yp = p.rgb_y_prev + (((size_t)b0 * 3 + k) * Rh + (row_ok ? row : 0)) * Rh;
-                    const float va = (row_ok && xa >= 0) ? yp[xa] : 0.f;
-                    const float vb = (row_ok && xb < Rh) ? yp[xb] : 0.f;
+                    const float va = (row_ok && xa >= 0) ? skip[k * T::kSkipRows * T::kSkipCols + xa] : 0.f;
+                    const float vb = (row_ok && xb < Rh) ? skip[k * T::kSkipRows * T::kSkipCols + xb] : 0.f;
                     up[j][k] = wrow * (wxa * va + wxb * vb);
                 }
             }
@@ -634,22 +667,29 @@ __global__ __launch_bounds__(256, UP ? ((RT && KC >= 4) || (!RT && BM > 64) ? 2 
                 }
 #pragma unroll
                 for (int k = 0; k < 3; ++k) rgb[k] += __shfl_xor(rgb[k], 32);
-                if (lh == 0 && ok && !GANCE_DBG(1)) {
-                    const size_t pix = (size_t)oy * R + ox;
+                const size_t pix = (size_t)oy * R + ox;
+                unsigned packed = 0;  // this pixel's three bytes
 #pragma unroll
-                    for (int k = 0; k < 3; ++k) {
-                        const float y = rgb[k] + p.rgb_bias[k];
-                        if (p.rgb_y != nullptr) p.rgb_y[((size_t)b0 * 3 + k) * R * R + pix] = y;
-                        if (p.rgb_u8 != nullptr) {
-                            // tf.saturate_cast(x * 127.5 + 128): two roundings (the barrier keeps them apart)
-                            float q = y * 127.5f;
-                            asm volatile("" : "+v"(q));
-                            q += 128.0f;
-                            q = fminf(fmaxf(q, 0.f), 255.f);
-                            p.rgb_u8[((size_t)b0 * R * R + pix) * 3 + k] = (unsigned char)(int)q;
-                        }
-                    }
+                for (int k = 0; k < 3; ++k) {
+                    const float y = rgb[k] + p.rgb_bias[k];
+                    if (p.rgb_y != nullptr && lh == 0 && ok && !GANCE_DBG(1)) p.rgb_y[((size_t)b0 * 3 + k) * R * R + pix] = y;
+                    // tf.saturate_cast(x * 127.5 + 128): two roundings (the barrier keeps them apart)
+                    float q = y * 127.5f;
+                    asm volatile("" : "+v"(q));
+                    q += 128.0f;
+                    q = fminf(fmaxf(q, 0.f), 255.f);
+                    packed |= (unsigned)(int)q << (8 * k);
                 }
+                // 32 pixels x 3 bytes = 24 dwords, contiguous in the NHWC frame: lane t < 24 assembles
+                // dword t from the packed pixels floor(4t/3) and floor(4t/3)+1 and stores it, so the
+                // group leaves as ONE 96-byte store instead of three byte-strided ones
+                const int first = (4 * l31) / 3, skew = (4 * l31) % 3;
+                const unsigned lo = __shfl(packed, first), hi = __shfl(packed, min(first + 1, 31));
+                const unsigned word = skew == 0 ? (lo | (hi << 24)) : (skew == 1 ? ((lo >> 8) | (hi << 16)) : ((lo >> 16) | (hi << 8)));
+                // (the tile is 64 pixels wide and R % 64 == 0, so a 32-pixel group is whole or absent)
+                const bool group_ok = b0 < p.B && oy < p.OH && (ox - l31) + 31 < p.OW;
+                if (p.rgb_u8 != nullptr && lh == 0 && l31 < 24 && group_ok && !GANCE_DBG(1))
+                    reinterpret_cast<unsigned*>(p.rgb_u8 + ((size_t)b0 * R * R + (pix - l31)) * 3)[l31] = word;
             }
         };
         if constexpr (!UP && TB == 1 && WM == 1 && MT == 1 && !RT) {
