@@ -147,7 +147,7 @@ def main() -> int:
     parser.add_argument("--gpus", type=int, default=1)
     parser.add_argument("--steps", type=int, default=20)
     parser.add_argument("--warmup", type=int, default=3)
-    parser.add_argument("--batch", type=int, default=16, help="frames per step per GPU")
+    parser.add_argument("--batch", type=int, default=32, help="frames per step per GPU")
     parser.add_argument("--resolution", type=int, default=1024)
     parser.add_argument("--no-cpu-baseline", action="store_true")
     parser.add_argument("--print-steps", action="store_true", help="per-launch table on stderr")
