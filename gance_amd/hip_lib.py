@@ -163,6 +163,10 @@ SIGNATURES = {
         [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32,
          ctypes.POINTER(ctypes.c_int32), ctypes.c_int32, ctypes.c_void_p],
     ),
+    "gance_resample_audio_f32": (
+        ctypes.c_int,
+        [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_double, ctypes.c_double, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p],
+    ),
     "gance_gaussian_noise": (
         ctypes.c_int,
         [
@@ -587,3 +591,9 @@ def overlay_boxes_device(  # pylint: disable=too-many-arguments
             boxes.shape[0], stream or None,
         ),
     )
+
+
+def resample_audio_device(d_in: int, num_in: int, sr_orig: float, sr_new: float, d_out: int, num_out: int, stream: int = 0) -> None:
+    """Band-limited resampling of a mono float32 signal in HBM (raw device pointers); num_out = int(num_in * sr_new / sr_orig)."""
+    lib = load_library()
+    _check(lib, lib.gance_resample_audio_f32(d_in, num_in, float(sr_orig), float(sr_new), d_out, num_out, stream or None))

@@ -11,9 +11,10 @@ Same names, modes, error behaviour and output contract as gance/vector_sources/m
 * Time-stretching used `resampy.resample` (kaiser_best), a third-party dependency that is not
   available here and whose sample values no reference test pins (SURVEY.md §8c: parity UNPINNED;
   only the output length is pinned, test/test_vector_source_music.py:13-24). `resample_audio`
-  below is this implementation's own band-limited (Kaiser-windowed sinc) resampler with the same
-  length rule, `int(len(x) * ratio)`; it is NOT bit-compatible with resampy. When the ratio is
-  exactly 1 (the benchmark synthesises its WAV at L * fps Hz) the samples pass through unchanged.
+  below is this implementation's own band-limited (Kaiser-windowed sinc) resampler, a HIP kernel
+  (gance_amd/csrc/resample.hip), with the same length rule, `int(len(x) * ratio)`; it is NOT
+  bit-compatible with resampy. When the ratio is exactly 1 (the benchmark synthesises its WAV at
+  L * fps Hz) the samples pass through unchanged and no GPU is touched.
 """
 
 import pickle
@@ -21,8 +22,10 @@ from pathlib import Path
 from typing import List, NamedTuple, Optional, Union
 
 import numpy as np
+import torch
 from scipy.io import wavfile
 
+from gance_amd import hip_lib
 from gance_amd.logger_common import LOGGER
 from gance_amd.vector_sources.vector_sources_common import pad_array
 
@@ -34,10 +37,6 @@ _INTEGER_RANGES = {
     np.dtype(np.int16): (-32768, 32767),
     np.dtype(np.int8): (0, 255),
 }
-
-_SINC_ZERO_CROSSINGS = 64
-_KAISER_BETA = 14.769656459379492
-_ROLLOFF = 0.9475937167399596
 
 
 class WavFileProperties(NamedTuple):
@@ -68,31 +67,22 @@ def read_wav_file(wav_path: Path, convert_to_32bit_float: bool = True) -> WavFil
 def resample_audio(samples: np.ndarray, sr_orig: float, sr_new: float) -> np.ndarray:
     """
     Band-limited resampling by a Kaiser-windowed sinc (64 zero crossings, beta 14.77, roll-off
-    0.9476: the published kaiser_best design). Output length int(len(samples) * sr_new / sr_orig).
+    0.9476: the published kaiser_best design) on the GPU (gance_resample_audio_f32). Output length
+    int(len(samples) * sr_new / sr_orig). A ratio of exactly 1 passes the samples through.
     """
     ratio = float(sr_new) / float(sr_orig)
     if ratio <= 0:
         raise ValueError("sample rates must be positive")
     count = int(samples.shape[0] * ratio)
-    if ratio == 1.0:
+    if ratio == 1.0 or count == 0:
         return np.array(samples[:count], copy=True)
-    x = np.asarray(samples, dtype=np.float64)
-    scale = min(1.0, ratio) * _ROLLOFF  # cut-off relative to the lower Nyquist
-    half_width = int(np.ceil(_SINC_ZERO_CROSSINGS / scale))
-    out = np.empty(count, dtype=np.float64)
-    taps = np.arange(-half_width, half_width + 1)
-    for start in range(0, count, 16384):  # bounded working set: chunk x taps
-        positions = np.arange(start, min(count, start + 16384)) / ratio
-        centre = np.floor(positions).astype(np.int64)
-        index = centre[:, None] + taps[None, :]
-        offset = (positions[:, None] - index) * scale
-        window_arg = offset / _SINC_ZERO_CROSSINGS
-        inside = np.abs(window_arg) < 1.0
-        kaiser = np.i0(_KAISER_BETA * np.sqrt(np.clip(1.0 - window_arg * window_arg, 0.0, None))) / np.i0(_KAISER_BETA)
-        kernel = np.where(inside, np.sinc(offset) * kaiser, 0.0) * scale
-        valid = (index >= 0) & (index < len(x))
-        out[start : start + len(positions)] = np.sum(np.where(valid, x[np.clip(index, 0, len(x) - 1)], 0.0) * kernel, axis=1)
-    return out.astype(samples.dtype if np.issubdtype(samples.dtype, np.floating) else np.float32)
+    out_dtype = samples.dtype if np.issubdtype(samples.dtype, np.floating) else np.float32
+    d_in = torch.from_numpy(np.ascontiguousarray(samples, dtype=np.float32)).cuda()
+    d_out = torch.empty((count,), dtype=torch.float32, device=d_in.device)
+    hip_lib.resample_audio_device(
+        d_in.data_ptr(), int(d_in.shape[0]), sr_orig, sr_new, d_out.data_ptr(), count, torch.cuda.current_stream().cuda_stream
+    )
+    return d_out.cpu().numpy().astype(out_dtype, copy=False)
 
 
 def _scale_wav_to_sample_rate(wav_file: WavFileProperties, new_sample_rate: float) -> WavFileProperties:

@@ -249,6 +249,15 @@ int gance_phash_crops_u8(const uint8_t* d_frames, int32_t num_frames, int32_t si
 int gance_overlay_boxes_u8(const uint8_t* d_foreground, const uint8_t* d_background, uint8_t* d_out, int32_t num_frames,
                            int32_t side, const int32_t* h_boxes, int32_t num_boxes, void* stream);
 
+/* ---- audio time-stretch ---------------------------------------------------------------------
+ * Replaces resampy.resample(wav, sr_orig, sr_new) of _scale_wav_to_sample_rate
+ * (gance/vector_sources/music.py:212-230) inside read_wavs_scale_for_video (:60-169): band-limited
+ * (Kaiser-windowed sinc, 64 zero crossings) resampling of a mono float32 signal on the device.
+ * num_out must equal (uint64_t)(num_in * sr_new / sr_orig), the reference's length rule
+ * (test/test_vector_source_music.py:13-24). Asynchronous on `stream` after a short internal sync. */
+int gance_resample_audio_f32(const float* d_in, uint64_t num_in, double sr_orig, double sr_new, float* d_out,
+                             uint64_t num_out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -349,6 +349,47 @@ def alpha_blend_vectors_max_rms_power_audio(
     return NoiseBlendResult(spectrogram, noise, combined, indices)
 
 
+# ----------------------------------------------------------------------------------------------
+# a2  time-stretch (music.py:212-230). resampy is absent and unpinned by any reference test: this is
+#     the numpy statement of THIS implementation's Kaiser-windowed-sinc design, the checker of the
+#     HIP kernel (gance_amd/csrc/resample.hip). PARITY UNPINNED against resampy.
+# ----------------------------------------------------------------------------------------------
+SINC_ZERO_CROSSINGS = 64
+KAISER_BETA = 14.769656459379492
+ROLLOFF = 0.9475937167399596
+
+
+def resample_audio(samples: np.ndarray, sr_orig: float, sr_new: float) -> np.ndarray:
+    """
+    Band-limited resampling by a Kaiser-windowed sinc (64 zero crossings, beta 14.77, roll-off
+    0.9476: the published kaiser_best design). Output length int(len(samples) * sr_new / sr_orig).
+    """
+    ratio = float(sr_new) / float(sr_orig)
+    if ratio <= 0:
+        raise ValueError("sample rates must be positive")
+    count = int(samples.shape[0] * ratio)
+    if ratio == 1.0:
+        return np.array(samples[:count], copy=True)
+    x = np.asarray(samples, dtype=np.float64)
+    scale = min(1.0, ratio) * ROLLOFF  # cut-off relative to the lower Nyquist
+    half_width = int(np.ceil(SINC_ZERO_CROSSINGS / scale))
+    out = np.empty(count, dtype=np.float64)
+    taps = np.arange(-half_width, half_width + 1)
+    for start in range(0, count, 16384):  # bounded working set: chunk x taps
+        positions = np.arange(start, min(count, start + 16384)) / ratio
+        centre = np.floor(positions).astype(np.int64)
+        index = centre[:, None] + taps[None, :]
+        offset = (positions[:, None] - index) * scale
+        window_arg = offset / SINC_ZERO_CROSSINGS
+        inside = np.abs(window_arg) < 1.0
+        kaiser = np.i0(KAISER_BETA * np.sqrt(np.clip(1.0 - window_arg * window_arg, 0.0, None))) / np.i0(KAISER_BETA)
+        kernel = np.where(inside, np.sinc(offset) * kaiser, 0.0) * scale
+        valid = (index >= 0) & (index < len(x))
+        out[start : start + len(positions)] = np.sum(np.where(valid, x[np.clip(index, 0, len(x) - 1)], 0.0) * kernel, axis=1)
+    return out.astype(samples.dtype if np.issubdtype(samples.dtype, np.floating) else np.float32)
+
+
+
 def sub_vectors(data: np.ndarray, vector_length: int) -> np.ndarray:
     """vsc:86-101: (N*L,) -> (N, L); (depth, N*L) -> (N, depth, L)."""
     if data.ndim >= 2:

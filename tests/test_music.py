@@ -1,6 +1,7 @@
 """
-CPU tests of the WAV input stage. Mirrors test/test_vector_source_music.py:13-24
-(output length for several stretch factors) and adds what the reference leaves unpinned.
+CPU tests of the WAV input stage: reading, mono mix, modes, padding, errors,
+and the ORACLE of the time-stretch (oracle/audio_ref.resample_audio). Whatever actually resamples
+runs a HIP kernel and is tested in tests/test_music_gpu.py.
 """
 
 from pathlib import Path
@@ -9,31 +10,25 @@ import numpy as np
 import pytest
 from scipy.io import wavfile
 
-from gance_amd import synthetic
 from gance_amd.vector_sources import music
+from oracle import audio_ref
 
 
-@pytest.mark.parametrize("multiplier", [2, 1.5, 0.3, 0.1, 10])
-def test_scaled_length_follows_the_reference_rule(multiplier: float) -> None:
-    wav = music.WavFileProperties(44100, synthetic.synthetic_audio(8, 512, seed=1), "synthetic")
-    scaled = music._scale_wav_to_sample_rate(wav, int(wav.sample_rate * multiplier))  # pylint: disable=protected-access
-    assert len(scaled.wav_data) == int(len(wav.wav_data) * int(wav.sample_rate * multiplier) / wav.sample_rate)
-    assert scaled.sample_rate == wav.sample_rate and scaled.wav_data.dtype == np.float32
-
-
-def test_resampler_preserves_a_tone_and_is_identity_at_ratio_one() -> None:
+def test_resampler_oracle_preserves_a_tone_and_is_identity_at_ratio_one() -> None:
     rate, tone = 8000, 440.0
     t = np.arange(8000) / rate
     x = np.sin(2 * np.pi * tone * t).astype(np.float32)
-    assert np.array_equal(music.resample_audio(x, rate, rate), x)
+    assert np.array_equal(audio_ref.resample_audio(x, rate, rate), x)
+    assert np.array_equal(music.resample_audio(x, rate, rate), x)  # ratio 1 never reaches the GPU
     for new_rate in (12000, 5000):
-        y = music.resample_audio(x, rate, new_rate)
+        y = audio_ref.resample_audio(x, rate, new_rate)
+        assert len(y) == int(len(x) * new_rate / rate)
         want = np.sin(2 * np.pi * tone * np.arange(len(y)) / new_rate)
         inner = slice(200, len(y) - 200)  # away from the zero-padded ends
         assert np.abs(y[inner] - want[inner]).max() < 2e-3
     # a tone above the new Nyquist is removed, not aliased
     high = np.sin(2 * np.pi * 3500.0 * t).astype(np.float32)
-    assert np.abs(music.resample_audio(high, rate, 4000)[100:-100]).max() < 5e-3
+    assert np.abs(audio_ref.resample_audio(high, rate, 4000)[100:-100]).max() < 5e-3
 
 
 def _write(path: Path, rate: int, data: np.ndarray) -> Path:
@@ -65,14 +60,14 @@ def test_scale_for_video_modes_padding_mono_and_errors(tmp_path: Path) -> None:
     by_fps = music.read_wavs_scale_for_video(paths, L, frames_per_second=60.0)
     assert by_fps.wav_data.shape == (120 * L,) and by_fps.sample_rate == rate and by_fps.name == "s_m_mono_scaled_padded"
     np.testing.assert_allclose(by_fps.wav_data[:rate], 0.0, atol=2e-5)  # stereo halves cancel in the mono mix
-    by_count = music.read_wavs_scale_for_video(paths, L, target_num_vectors=90)
-    assert by_count.wav_data.shape == (90 * L,)
-    unpadded = music.read_wavs_scale_for_video(paths[1:], L, target_num_vectors=7, pad_to_length=False)
-    assert len(unpadded.wav_data) == 7 * L
+    by_count = music.read_wavs_scale_for_video(paths, L, target_num_vectors=120)  # still the identity stretch
+    assert by_count.wav_data.shape == (120 * L,) and np.array_equal(by_count.wav_data, by_fps.wav_data)
+    unpadded = music.read_wavs_scale_for_video(paths[1:], L, target_num_vectors=60, pad_to_length=False)
+    assert len(unpadded.wav_data) == 60 * L
     cache = tmp_path / "cache.p"
-    first = music.read_wavs_scale_for_video(paths, L, target_num_vectors=30, cache_path=cache)
+    first = music.read_wavs_scale_for_video(paths, L, target_num_vectors=120, cache_path=cache)
     assert cache.exists()
-    again = music.read_wavs_scale_for_video([], L, target_num_vectors=30, cache_path=cache)  # served from the cache
+    again = music.read_wavs_scale_for_video([], L, target_num_vectors=120, cache_path=cache)  # served from the cache
     assert np.array_equal(first.wav_data, again.wav_data)
     with pytest.raises(ValueError, match="both FPS mode"):
         music.read_wavs_scale_for_video(paths, L, frames_per_second=60, target_num_vectors=3)
