@@ -106,25 +106,43 @@ def blend_workload(args, device) -> int:
     from gance_amd import synthetic  # pylint: disable=import-outside-toplevel
     from gance_amd.data_into_network_visualization import visualization_inputs  # pylint: disable=import-outside-toplevel
 
-    resolution, batch, num_frames = args.resolution, args.batch, 1800
-    variables = sg2_spec.make_random_variables(resolution, seed=0)
-    engine = hip_lib.Engine(variables, resolution, max_batch=batch, device=device.index)
+    from types import SimpleNamespace  # pylint: disable=import-outside-toplevel
+
+    from gance_amd import projection_file_blend  # pylint: disable=import-outside-toplevel
+
+    resolution, batch, num_frames, num_networks = args.resolution, args.batch, 1800, args.networks
+    engines = [
+        hip_lib.Engine(sg2_spec.make_random_variables(resolution, seed=seed), resolution, max_batch=batch, device=device.index)
+        for seed in range(num_networks)
+    ]
     audio, latents = synthetic.benchmark_blend_inputs(num_frames)
     frames = torch.empty((batch, resolution, resolution, 3), dtype=torch.uint8, device=device)
     stream = torch.cuda.current_stream(device)
-    rows = engine.num_layers
+    rows = engines[0].num_layers
+    # what synthesize_device_frames_network_major needs of a MultiNetwork
+    resident = SimpleNamespace(_network_at=lambda index: SimpleNamespace(engine=engines[index]))
+    switches = 0
 
     def run_once():
+        nonlocal switches
         t0 = time.perf_counter()
         blend = visualization_inputs.alpha_blend_projection_file_device(
-            latents, 0.25, True, (-5, 5), 12, audio, 512, 1, device=device.index
+            latents, 0.25, True, (-5, 5), 12, audio, 512, num_networks, device=device.index
         )
         torch.cuda.synchronize(device)
         t1 = time.perf_counter()
-        dlat = blend.dlatents[:, :rows, :].contiguous()
-        for start in range(0, num_frames, batch):
-            count = min(batch, num_frames - start)
-            engine.synthesize_w_device(dlat[start : start + count].data_ptr(), count, frames.data_ptr(), 0, stream.cuda_stream)
+        if num_networks == 1 and args.output_side is None:
+            dlat = blend.dlatents[:, :rows, :].contiguous()
+            for start in range(0, num_frames, batch):
+                count = min(batch, num_frames - start)
+                engines[0].synthesize_w_device(dlat[start : start + count].data_ptr(), count, frames.data_ptr(), 0, stream.cuda_stream)
+        else:  # the RMS-driven index switches networks; every network is resident, frames come back in order
+            ordered = projection_file_blend.synthesize_device_frames_network_major(
+                blend.dlatents, blend.network_indices, resident, args.output_side, batch
+            )
+            assert ordered.shape[0] == num_frames
+            chosen = blend.network_indices.cpu().numpy()
+            switches = int((chosen[1:] != chosen[:-1]).sum())
         torch.cuda.synchronize(device)
         t2 = time.perf_counter()
         blend.blend.close()
@@ -136,9 +154,12 @@ def blend_workload(args, device) -> int:
         "metric": "projection-file-blend frames/sec at 1024x1024 (config 3), host audio -> frames in HBM",
         "value": round(num_frames / (audio_s + synth_s), 3), "unit": "frames/s", "n_gpus": 1,
         "frames": num_frames, "audio_to_latents_ms": round(audio_s * 1e3, 3), "synthesis_ms": round(synth_s * 1e3, 3),
-        "frames_per_call": batch, "dtype": "f64 (audio) / f32 (synthesis)", "data": "synthetic",
+        "frames_per_call": batch, "networks_resident": num_networks, "network_switches": switches,
+        "output_side_length": args.output_side or resolution,
+        "dtype": "f64 (audio) / f32 (synthesis)", "data": "synthetic",
     }), flush=True)
-    engine.close()
+    for engine in engines:
+        engine.close()
     return 0
 
 
@@ -156,6 +177,8 @@ def main() -> int:
         help="synthesis = BASELINE configs[1] (the contract line); blend = configs[2]: 30 s synthetic WAV -> "
         "FFT + fft-roll -> alpha-blended latents -> 1024 synthesis, single GPU, extra line for DESIGN.md",
     )
+    parser.add_argument("--networks", type=int, default=1, help="blend workload: resident networks the RMS index switches between")
+    parser.add_argument("--output-side", type=int, default=None, help="blend workload: --output-side-length (bicubic resize in HBM), e.g. 2160")
     args = parser.parse_args()
 
     world_size = int(os.environ.get("WORLD_SIZE", "1"))

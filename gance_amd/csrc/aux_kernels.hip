@@ -7,6 +7,8 @@
 
 #include <hip/hip_runtime.h>
 
+#include <cmath>
+
 #include <cstdlib>
 
 #include "kernels.h"
@@ -517,49 +519,93 @@ __device__ __forceinline__ void cubic_weights(float t, float (&w)[4]) {
     w[3] = 1.f - w[0] - w[1] - w[2];
 }
 
+// One block = a 64 x 4 tile of output pixels of one frame. The source pixels the tile touches are
+// copied into LDS once (consecutive threads read consecutive bytes), every thread then takes its
+// 16 taps from LDS, and the 768 result bytes leave as 192 coalesced dword stores. Arithmetic and
+// its order are those of the per-pixel formulation (row sums over x, then the sum over rows).
+constexpr int kResizeTW = 64, kResizeTH = 4;
+
 __global__ __launch_bounds__(256) void resize_bicubic_u8_kernel(const uint8_t* __restrict__ in, int src,
-                                                                uint8_t* __restrict__ out, int dst,
-                                                                size_t total) {
-    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= total) return;
-    const int ox = (int)(i % dst);
-    const int oy = (int)((i / dst) % dst);
-    const size_t b = i / ((size_t)dst * dst);
+                                                                uint8_t* __restrict__ out, int dst, int tiles_x,
+                                                                int tiles_y, int max_cols, int max_rows) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t resize_lds[];
+    uint8_t* const tile = resize_lds;                                 // [rows][cols * 3]
+    uint8_t* const result = resize_lds + ((size_t)max_rows * max_cols * 3 + 15) / 16 * 16;  // [kResizeTH][kResizeTW * 3]
+    const int tid = threadIdx.x;
+    const int tx = blockIdx.x % tiles_x;
+    const int ty = (blockIdx.x / tiles_x) % tiles_y;
+    const size_t b = blockIdx.x / ((size_t)tiles_x * tiles_y);
+    const int ox0 = tx * kResizeTW, oy0 = ty * kResizeTH;
     const float scale = (float)src / (float)dst;
-    const float fy = ((float)oy + 0.5f) * scale - 0.5f;
-    const float fx = ((float)ox + 0.5f) * scale - 0.5f;
-    const int iy = (int)floorf(fy), ix = (int)floorf(fx);
-    float wy[4], wx[4];
-    cubic_weights(fy - (float)iy, wy);
-    cubic_weights(fx - (float)ix, wx);
-    float acc[3] = {0.f, 0.f, 0.f};
+    // source window of the tile (before clamping): taps iy-1 .. iy+2 of its first and last pixel
+    auto first_tap = [&](int o) { return (int)floorf(((float)o + 0.5f) * scale - 0.5f) - 1; };
+    const int x_lo = first_tap(ox0), x_hi = first_tap(min(ox0 + kResizeTW, dst) - 1) + 3;
+    const int y_lo = first_tap(oy0), y_hi = first_tap(min(oy0 + kResizeTH, dst) - 1) + 3;
+    const int cols = x_hi - x_lo + 1, rows = y_hi - y_lo + 1;  // <= max_cols, max_rows
     const uint8_t* img = in + b * (size_t)src * src * 3;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int yy = min(max(iy - 1 + r, 0), src - 1);
-        float row[3] = {0.f, 0.f, 0.f};
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const int xx = min(max(ix - 1 + c, 0), src - 1);
-            const uint8_t* px = img + ((size_t)yy * src + xx) * 3;
-            row[0] += wx[c] * (float)px[0];
-            row[1] += wx[c] * (float)px[1];
-            row[2] += wx[c] * (float)px[2];
-        }
-        acc[0] += wy[r] * row[0];
-        acc[1] += wy[r] * row[1];
-        acc[2] += wy[r] * row[2];
+    const int row_bytes = cols * 3;
+    for (int i = tid; i < rows * row_bytes; i += 256) {
+        const int r = i / row_bytes, cb = i % row_bytes;
+        const int yy = min(max(y_lo + r, 0), src - 1);            // replicated border
+        const int xx = min(max(x_lo + cb / 3, 0), src - 1);
+        tile[i] = img[((size_t)yy * src + xx) * 3 + cb % 3];
     }
-    uint8_t* o = out + i * 3;
+    __syncthreads();
+    const int lx = tid % kResizeTW, ly = tid / kResizeTW;
+    const int ox = ox0 + lx, oy = oy0 + ly;
+    if (ox < dst && oy < dst) {
+        const float fy = ((float)oy + 0.5f) * scale - 0.5f;
+        const float fx = ((float)ox + 0.5f) * scale - 0.5f;
+        const int iy = (int)floorf(fy), ix = (int)floorf(fx);
+        float wy[4], wx[4];
+        cubic_weights(fy - (float)iy, wy);
+        cubic_weights(fx - (float)ix, wx);
+        float acc[3] = {0.f, 0.f, 0.f};
 #pragma unroll
-    for (int ch = 0; ch < 3; ++ch) o[ch] = (uint8_t)(int)fminf(fmaxf(floorf(acc[ch] + 0.5f), 0.f), 255.f);
+        for (int r = 0; r < 4; ++r) {
+            const uint8_t* px = tile + (size_t)(iy - 1 + r - y_lo) * row_bytes + (ix - 1 - x_lo) * 3;
+            float row[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                row[0] += wx[c] * (float)px[3 * c + 0];
+                row[1] += wx[c] * (float)px[3 * c + 1];
+                row[2] += wx[c] * (float)px[3 * c + 2];
+            }
+            acc[0] += wy[r] * row[0];
+            acc[1] += wy[r] * row[1];
+            acc[2] += wy[r] * row[2];
+        }
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch)
+            result[(ly * kResizeTW + lx) * 3 + ch] = (uint8_t)(int)fminf(fmaxf(floorf(acc[ch] + 0.5f), 0.f), 255.f);
+    }
+    __syncthreads();
+    // a tile row is kResizeTW * 3 = 192 bytes = 48 dwords, 4-byte aligned in the frame when dst % 4 == 0
+    const int valid_w = min(kResizeTW, dst - ox0);
+    if ((dst & 3) == 0 && valid_w == kResizeTW) {
+        if (tid < kResizeTH * 48) {
+            const int r = tid / 48, d = tid % 48;
+            if (oy0 + r < dst)
+                reinterpret_cast<uint32_t*>(out + ((b * dst + oy0 + r) * (size_t)dst + ox0) * 3)[d] =
+                    reinterpret_cast<const uint32_t*>(result + r * kResizeTW * 3)[d];
+        }
+    } else {
+        for (int i = tid; i < kResizeTH * valid_w * 3; i += 256) {
+            const int r = i / (valid_w * 3), cb = i % (valid_w * 3);
+            if (oy0 + r < dst) out[((b * dst + oy0 + r) * (size_t)dst + ox0) * 3 + cb] = result[r * kResizeTW * 3 + cb];
+        }
+    }
 }
 
 hipError_t launch_resize_bicubic_u8(const uint8_t* in, int batch, int src, uint8_t* out, int dst,
                                     hipStream_t stream) {
-    const size_t total = (size_t)batch * dst * dst;
-    hipLaunchKernelGGL(resize_bicubic_u8_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream,
-                       in, src, out, dst, total);
+    const int tiles_x = (dst + kResizeTW - 1) / kResizeTW, tiles_y = (dst + kResizeTH - 1) / kResizeTH;
+    const double scale = (double)src / dst;
+    const int max_cols = (int)std::ceil(kResizeTW * scale) + 6, max_rows = (int)std::ceil(kResizeTH * scale) + 6;
+    const size_t lds = ((size_t)max_rows * max_cols * 3 + 15) / 16 * 16 + (size_t)kResizeTH * kResizeTW * 3;
+    if (lds > 64 * 1024) return hipErrorInvalidValue;  // down-scaling by more than ~10x: not a use of this path
+    hipLaunchKernelGGL(resize_bicubic_u8_kernel, dim3((unsigned)((size_t)batch * tiles_x * tiles_y)), dim3(256), lds,
+                       stream, in, src, out, dst, tiles_x, tiles_y, max_cols, max_rows);
     return hipGetLastError();
 }
 

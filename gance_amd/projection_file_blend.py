@@ -81,6 +81,62 @@ def synthesize_device_frames(  # pylint: disable=too-many-locals
         yield frames
 
 
+def synthesize_device_frames_network_major(  # pylint: disable=too-many-locals
+    dlatents: torch.Tensor,
+    network_indices: torch.Tensor,
+    networks: MultiNetwork,
+    output_side_length: Optional[int] = None,
+    batch: int = DEFAULT_MAX_BATCH,
+) -> torch.Tensor:
+    """
+    The same frames as `synthesize_device_frames`, as one tensor [n, S, S, 3], computed network by
+    network: every engine call is a full batch however often the index switches (the reference
+    sorts by network for the same reason, network_visualization.py:653-674: there a switch costs a
+    process restart, here only a short batch). Frames land at their own positions, so the order of
+    the result is the frame order.
+    """
+    device = dlatents.device
+    indices = network_indices.cpu().numpy()
+    stream = torch.cuda.current_stream(device).cuda_stream
+    num_frames = int(dlatents.shape[0])
+    out: Optional[torch.Tensor] = None
+    for network_index in np.unique(indices):
+        engine = networks._network_at(int(network_index)).engine  # pylint: disable=protected-access
+        side = engine.resolution
+        out_side = output_side_length if output_side_length is not None else side
+        if out is None:
+            out = torch.empty((num_frames, out_side, out_side, 3), dtype=torch.uint8, device=device)
+        frames_of_network = np.nonzero(indices == network_index)[0]
+        for start in range(0, len(frames_of_network), batch):
+            host_members = frames_of_network[start : start + batch]
+            count = len(host_members)
+            first = int(host_members[0])
+            # a run of consecutive frames (always, with one network) is produced in place
+            in_place = int(host_members[-1]) - first + 1 == count
+            members = torch.from_numpy(host_members).to(device)
+            native = out[first : first + count] if in_place and out_side == side else torch.empty(
+                (count, side, side, 3), dtype=torch.uint8, device=device
+            )
+            if dlatents.dim() == 2:
+                selected = dlatents[first : first + count] if in_place else dlatents.index_select(0, members)
+                engine.synthesize_z_device(selected.contiguous().data_ptr(), count, TRUNCATION_PSI, native.data_ptr(), 0, stream)
+            else:
+                selected = (dlatents[first : first + count] if in_place else dlatents.index_select(0, members))[:, : engine.num_layers, :]
+                engine.synthesize_w_device(selected.contiguous().data_ptr(), count, native.data_ptr(), 0, stream)
+            if out_side != side:
+                target = out[first : first + count] if in_place else torch.empty(
+                    (count, out_side, out_side, 3), dtype=torch.uint8, device=device
+                )
+                hip_lib.resize_bicubic_u8_device(native.data_ptr(), count, side, target.data_ptr(), out_side, stream)
+                native = target
+            if not in_place:
+                out.index_copy_(0, members, native)
+    if out is None:
+        side = output_side_length if output_side_length is not None else 0
+        out = torch.empty((0, side, side, 3), dtype=torch.uint8, device=device)
+    return out
+
+
 def shard_synthesize_gather(  # pylint: disable=too-many-arguments
     dlatents: Optional[torch.Tensor],
     indices: Optional[torch.Tensor],
@@ -102,8 +158,7 @@ def shard_synthesize_gather(  # pylint: disable=too-many-arguments
         num_frames = count[0]
         dlatents = frame_sharding.scatter_latents(dlatents, num_frames, device)
         indices = frame_sharding.scatter_latents(indices, num_frames, device)
-    batches = list(synthesize_device_frames(dlatents, indices, networks, output_side_length))
-    local = torch.cat(batches) if batches else torch.empty((0, output_side_length, output_side_length, 3), dtype=torch.uint8, device=device)
+    local = synthesize_device_frames_network_major(dlatents, indices, networks, output_side_length)
     frames, _ = frame_sharding.gather_frames(local, num_frames)
     torch.cuda.synchronize(device)
     if frames is None or keep_on_device:
