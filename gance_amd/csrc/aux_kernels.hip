@@ -209,7 +209,17 @@ template <int RQ>
 __global__ __launch_bounds__(256) void fir_epilogue_kernel(const FirArgs p) {
     const int W4 = p.W >> 2;
     const int HQ = p.H / RQ;
-    const size_t q = (size_t)blockIdx.x * 256 + threadIdx.x;
+    // XCD-aware block order: a thread re-reads 3 of its 2*RQ+3 T rows that the strip below it also
+    // reads. Consecutive block ids land on different XCDs (separate L2s), so with the plain order
+    // those re-reads went to HBM (measured 1.6x the algorithmic read bytes); giving every XCD a
+    // contiguous range of strips keeps them in its L2.
+    size_t vb;
+    {
+        const unsigned nwg = gridDim.x, bid = blockIdx.x;
+        const unsigned per = nwg >> 3, rem = nwg & 7, xcd = bid & 7;
+        vb = (size_t)(xcd < rem ? xcd * (per + 1) : rem * (per + 1) + (xcd - rem) * per) + (bid >> 3);
+    }
+    const size_t q = vb * 256 + threadIdx.x;
     const size_t total = (size_t)p.B * p.C * HQ * W4;
     if (q >= total) return;
     const int X = (int)(q % W4) * 4;
