@@ -205,6 +205,7 @@ struct gance_engine {
     size_t map_w[kMappingLayers]{}, map_b[kMappingLayers]{};
     size_t avg_off = 0, const_off = 0, A_off = 0, bias1_off = 0, w2_off = 0;
     std::vector<size_t> conv_w, conv_bias, conv_noise;
+    std::vector<size_t> wino_w;  // Winograd-domain weights of the stride-1 layers that support them (else SIZE_MAX)
     std::vector<float> conv_ns;
     std::vector<int> conv_s_off, conv_d_off;
     std::vector<size_t> rgb_w, rgb_bias;
@@ -297,7 +298,7 @@ int run_conv(gance_engine* e, const ConvLayerHost& c, int li, const LayerPlan& p
              long long x_b_stride, int H, int W, float* out, int epilogue, int out_row_stride,
              int out_y_off, int out_x_off, long long out_b_stride, long long out_c_stride,
              long long slab_stride, long long cls_stride, int B, hipStream_t stream,
-             const char* name, const FusedRgb* rgb = nullptr) {
+             const char* name, const FusedRgb* rgb = nullptr, bool winograd = false) {
     gance::ConvArgs a{};
     if (rgb != nullptr) {
         a.rgb_w = rgb->w;
@@ -357,6 +358,11 @@ int run_conv(gance_engine* e, const ConvLayerHost& c, int li, const LayerPlan& p
         bytes = 4.0 * ((double)B * c.cin * H * W + 9.0 * c.cin * c.cout + 0.75 * B * H * W) + 3.0 * B * H * W;
     }
     StepScope scope(e, stream, name, flops, bytes);
+    if (winograd) {
+        a.w = e->pool + e->wino_w[li];
+        GANCE_HIP_CHECK(gance::launch_winograd_conv(a, stream));
+        return GANCE_OK;
+    }
     GANCE_HIP_CHECK(gance::launch_modconv(p.tile_id, a, p.total_blocks, stream));
     if ((debug_flags & 16) && p.total_blocks <= 65536) {
         // timing experiment: dump per-block phase stamps (100 MHz clock) of this launch
@@ -440,9 +446,15 @@ int synthesize_from_dlat(gance_engine* e, const float* d_dlat, int B, uint8_t* d
                 if (rc) return rc;
                 ycur = 1 - ycur;
             } else if (p.nsplit == 1) {
+                // Winograd F(2x2,3x3) form where the layer supports it and the launch fills the chip
+                // (one block per CU): GANCE_TUNE_WINOGRAD=0 keeps the direct form
+                static const int wino_mode = [] { const char* v = std::getenv("GANCE_TUNE_WINOGRAD"); return v ? std::atoi(v) : 0; }();
+                const bool winograd = wino_mode != 0 && e->wino_w[li] != SIZE_MAX &&
+                                      (wino_mode == 2 || (long long)(c.cout / 32) * (res / 8) * (res / 64) * B >= 256);
+                if (winograd) std::snprintf(name, sizeof(name), "convW%d_%dx%d_%d->%d", c.layer_idx, res, res, c.cin, c.cout);
                 int rc = run_conv(e, c, li, p, x_in, x_b_stride, res, res, x_out,
                                   gance::kEpilogueFull, res + 8, 1, 4, out_b, out_c, 0, 0, B, stream,
-                                  name);
+                                  name, nullptr, winograd);
                 if (rc) return rc;
             } else {
                 const long long dense_c = (long long)res * res;
@@ -664,6 +676,14 @@ int gance_engine_create(const gance_engine_config* config, const float* host_wei
                                 w2[(size_t)ci * c.cout + co] += v * v;
                             }
                     }
+        }
+        e->wino_w.push_back(SIZE_MAX);
+        if (!c.up && gance::winograd_supported(c.cin, c.cout, 1 << c.res_log2, 1 << c.res_log2)) {
+            // U = G w G^T of the scaled weights, in the Winograd kernel's LDS image [m tile][chunk][16][4][32]
+            std::vector<float> scaled(wn);
+            for (size_t j = 0; j < wn; ++j) scaled[j] = src[j] * coef;
+            e->wino_w[i] = reserve(gance::winograd_weight_floats(c.cin, c.cout));
+            gance::winograd_transform_weights(scaled.data(), c.cin, c.cout, &pool[e->wino_w[i]]);
         }
         src += wn;
         demod_layers[i] = {(long long)w2_cursor, e->conv_s_off[i], e->conv_d_off[i], c.cin, c.cout};

@@ -68,6 +68,13 @@ extern const ConvTileInfo kConvTiles[kNumConvTiles];
 
 hipError_t launch_modconv(int tile_id, const ConvArgs& args, int total_blocks, hipStream_t stream);
 
+// Winograd F(2x2, 3x3) form of the stride-1 conv (winograd_conv.hip): 32 output channels x 8x64 pixels
+// per block; args.w points at the layer's transformed weights [m_tile][chunk][16][4][32].
+bool winograd_supported(int cin, int cout, int H, int W);
+size_t winograd_weight_floats(int cin, int cout);
+void winograd_transform_weights(const float* w_in /*[9][cin][cout]*/, int cin, int cout, float* w_out);
+hipError_t launch_winograd_conv(const ConvArgs& args, hipStream_t stream);
+
 // ---- aux_kernels.hip ----
 
 // Mapping network: one dense 512->512 layer with lrelu*sqrt2 (G_mapping DenseN).
