@@ -447,8 +447,11 @@ int synthesize_from_dlat(gance_engine* e, const float* d_dlat, int B, uint8_t* d
                 ycur = 1 - ycur;
             } else if (p.nsplit == 1) {
                 // Winograd F(2x2,3x3) form where the layer supports it and the launch fills the chip
-                // (one block per CU): GANCE_TUNE_WINOGRAD=0 keeps the direct form
-                static const int wino_mode = [] { const char* v = std::getenv("GANCE_TUNE_WINOGRAD"); return v ? std::atoi(v) : 0; }();
+                // (one block per CU). Engine flags choose: DIRECT_CONV = never, FORCE_WINOGRAD = whatever
+                // the block count; GANCE_TUNE_WINOGRAD = 0 / 1 / 2 overrides them for tuning.
+                static const int env_mode = [] { const char* v = std::getenv("GANCE_TUNE_WINOGRAD"); return v ? std::atoi(v) : -1; }();
+                const int wino_mode = env_mode >= 0 ? env_mode
+                                                    : ((e->cfg.flags & GANCE_FLAG_DIRECT_CONV) ? 0 : ((e->cfg.flags & GANCE_FLAG_FORCE_WINOGRAD) ? 2 : 1));
                 const bool winograd = wino_mode != 0 && e->wino_w[li] != SIZE_MAX &&
                                       (wino_mode == 2 || (long long)(c.cout / 32) * (res / 8) * (res / 64) * B >= 256);
                 if (winograd) std::snprintf(name, sizeof(name), "convW%d_%dx%d_%d->%d", c.layer_idx, res, res, c.cin, c.cout);

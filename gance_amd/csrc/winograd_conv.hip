@@ -251,7 +251,7 @@ __global__ __launch_bounds__(256, 1) void winograd_conv_kernel(const ConvArgs p)
         const float* const Un = buf0 + ((c + 1) % kWNBUF) * kWBufFloats;
 #pragma unroll
         for (int j = 0; j < KS; ++j) {
-            if (j + 2 == KS) {
+            if (j + 2 == KS && !(p.debug_flags & 8)) {
                 // L leaves chunk c: every wave's reads of it are done once they have returned
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 if (c + kWNBUF <= nchunks - 1) wait_vmcnt<(kWNBUF - 2) * kWPiecesPerWave>(); else wait_vmcnt<0>();

@@ -26,6 +26,8 @@ LIBRARY_PATH = Path(os.environ.get("GANCE_HIP_LIBRARY") or Path(__file__).resolv
 
 GANCE_OK = 0
 GANCE_FLAG_PROFILE_STEPS = 1
+GANCE_FLAG_DIRECT_CONV = 2
+GANCE_FLAG_FORCE_WINOGRAD = 4
 
 STATUS_NAMES = {
     1: "GANCE_ERR_INVALID_ARGUMENT",
@@ -240,12 +242,19 @@ class Engine:
         max_batch: int = 1,
         device: int = 0,
         profile: bool = False,
+        conv_form: str = "auto",
     ) -> None:
+        """
+        :param conv_form: "auto" = Winograd F(2x2,3x3) for the stride-1 convs of the >= 64x64 layers
+        when a launch has at least one block per CU, else the direct form; "direct" = never Winograd;
+        "winograd" = Winograd on every layer that supports it, whatever the batch.
+        """
         self._lib = load_library()
         self._handle = ctypes.c_void_p()
         spec = sg2_spec.make_spec(resolution)
         blob = sg2_spec.pack_variables(variables, spec)
-        config = EngineConfig(resolution, max_batch, device, GANCE_FLAG_PROFILE_STEPS if profile else 0)
+        form_flags = {"auto": 0, "direct": GANCE_FLAG_DIRECT_CONV, "winograd": GANCE_FLAG_FORCE_WINOGRAD}[conv_form]
+        config = EngineConfig(resolution, max_batch, device, (GANCE_FLAG_PROFILE_STEPS if profile else 0) | form_flags)
         _check(
             self._lib,
             self._lib.gance_engine_create(

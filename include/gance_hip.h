@@ -47,6 +47,12 @@ typedef struct gance_engine_config {
 } gance_engine_config;
 
 #define GANCE_FLAG_PROFILE_STEPS 1 /* record a hipEvent pair around every kernel launch        */
+/* The stride-1 3x3 convs of the >= 64x64 layers run in Winograd F(2x2,3x3) form (4/9 of the multiply-adds;
+ * results differ from the direct form by fp32 rounding only, ~1e-6 relative) whenever a launch has at
+ * least one block per CU. DIRECT_CONV keeps every layer in direct form; FORCE_WINOGRAD drops the
+ * block-count condition (small batches: slower, used by the parity tests). */
+#define GANCE_FLAG_DIRECT_CONV 2
+#define GANCE_FLAG_FORCE_WINOGRAD 4
 
 /*
  * Load a network. Replaces load_network_network + wrap_loaded_network

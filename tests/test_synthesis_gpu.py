@@ -46,13 +46,18 @@ def library():
     return hip_lib.load_library()
 
 
-@pytest.mark.parametrize("resolution,batch", [(8, 1), (32, 3), (64, 9)])
-def test_layerwise_activations_match_oracle(library, resolution: int, batch: int) -> None:
-    """Every conv layer's activation (all terms on: noise, biases) against the fp64 oracle."""
+@pytest.mark.parametrize(
+    "resolution,batch,conv_form", [(8, 1, "auto"), (32, 3, "auto"), (64, 9, "direct"), (64, 9, "winograd"), (128, 3, "winograd")]
+)
+def test_layerwise_activations_match_oracle(library, resolution: int, batch: int, conv_form: str) -> None:
+    """
+    Every conv layer's activation (all terms on: noise, biases) against the fp64 oracle, in the
+    direct form and with the Winograd F(2x2,3x3) kernel forced onto the >= 64x64 stride-1 layers.
+    """
     spec = sg2_spec.make_spec(resolution)
     variables = sg2_spec.make_random_variables(resolution, seed=3, perturb=True)
     dlatents = np.random.RandomState(5).randn(batch, spec.num_layers, 512).astype(np.float32)
-    engine = hip_lib.Engine(variables, resolution, max_batch=batch)
+    engine = hip_lib.Engine(variables, resolution, max_batch=batch, conv_form=conv_form)
     try:
         for n in range(1, len(spec.convs) + 1):
             got = engine.debug_activation_after(dlatents, n)
@@ -65,13 +70,16 @@ def test_layerwise_activations_match_oracle(library, resolution: int, batch: int
         engine.close()
 
 
-@pytest.mark.parametrize("resolution,batch,perturb", [(16, 2, True), (128, 2, True), (256, 3, False), (256, 1, True)])
-def test_matrix_path_matches_oracle(library, resolution: int, batch: int, perturb: bool) -> None:
+@pytest.mark.parametrize(
+    "resolution,batch,perturb,conv_form",
+    [(16, 2, True, "auto"), (128, 2, True, "direct"), (256, 3, False, "auto"), (256, 1, True, "direct"), (256, 2, True, "winograd")],
+)
+def test_matrix_path_matches_oracle(library, resolution: int, batch: int, perturb: bool, conv_form: str) -> None:
     """create_image_matrix semantics (network_functions.py:160-169): dlatents -> frames."""
     spec = sg2_spec.make_spec(resolution)
     variables = sg2_spec.make_random_variables(resolution, seed=1, perturb=perturb)
     dlatents = np.random.RandomState(7).randn(batch, spec.num_layers, 512).astype(np.float32)
-    engine = hip_lib.Engine(variables, resolution, max_batch=batch + 1)
+    engine = hip_lib.Engine(variables, resolution, max_batch=batch + 1, conv_form=conv_form)
     try:
         frames, image = engine.synthesize_w(dlatents, want_float=True)
     finally:
