@@ -21,6 +21,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cstdint>
 #include <cstdlib>
 
 #include "kernels.h"
@@ -77,13 +78,17 @@ struct WinoOps {
 __device__ __forceinline__ void wino_load(const float* __restrict__ U, const float* __restrict__ P,
                                           const float* __restrict__ s_chunk, int kk, int poff, int l31, int lh, WinoRaw& r) {
     const int cl = 2 * kk + lh;
-    const float* pc = P + cl * (kWPH * kWPW) + poff;
+    // one opaque offset per k-step: the four window rows are then immediate offsets (72 dwords apart) of
+    // the LDS reads from ONE address register instead of eight separately added addresses
+    typedef const __attribute__((address_space(3))) float* lds_cfloat;
+    unsigned window = (unsigned)(uintptr_t)((lds_cfloat)P + cl * (kWPH * kWPW) + poff);  // 32-bit LDS byte address
+    asm volatile("" : "+v"(window));
+    lds_cfloat pc = (lds_cfloat)(uintptr_t)window;
 #pragma unroll
     for (int y = 0; y < 4; ++y) {
         r.d[y][0] = pc[y * kWPW];
-        const float2 mid = *reinterpret_cast<const float2*>(pc + y * kWPW + 1);  // even index: 8-byte aligned
-        r.d[y][1] = mid.x;
-        r.d[y][2] = mid.y;
+        r.d[y][1] = pc[y * kWPW + 1];
+        r.d[y][2] = pc[y * kWPW + 2];
         r.d[y][3] = pc[y * kWPW + 3];
     }
 #pragma unroll
@@ -91,15 +96,18 @@ __device__ __forceinline__ void wino_load(const float* __restrict__ U, const flo
     r.s = s_chunk[cl];
 }
 
-// V = B^T d B (B^T = [[1,0,-1,0],[0,1,1,0],[0,-1,1,0],[0,1,0,-1]]) and the style scale on the weights
+// V = B^T (s d) B, B^T = [[1,0,-1,0],[0,1,1,0],[0,-1,1,0],[0,1,0,-1]]
 __device__ __forceinline__ void wino_transform(const WinoRaw& r, WinoOps& o) {
+    // the style scale rides on the activation side (V is linear in d): two multiplies and two fused
+    // multiply-adds per window column instead of sixteen multiplies on the weight fragment
     float t[4][4];
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
-        t[0][c] = r.d[0][c] - r.d[2][c];
-        t[1][c] = r.d[1][c] + r.d[2][c];
-        t[2][c] = r.d[2][c] - r.d[1][c];
-        t[3][c] = r.d[1][c] - r.d[3][c];
+        const float e1 = r.s * r.d[1][c], e2 = r.s * r.d[2][c];
+        t[0][c] = fmaf(r.s, r.d[0][c], -e2);
+        t[1][c] = e1 + e2;
+        t[2][c] = e2 - e1;
+        t[3][c] = fmaf(-r.s, r.d[3][c], e1);
     }
 #pragma unroll
     for (int y = 0; y < 4; ++y) {
@@ -109,7 +117,7 @@ __device__ __forceinline__ void wino_transform(const WinoRaw& r, WinoOps& o) {
         o.v[y * 4 + 3] = t[y][1] - t[y][3];
     }
 #pragma unroll
-    for (int q = 0; q < 16; ++q) o.a[q] = r.a[q] * r.s;
+    for (int q = 0; q < 16; ++q) o.a[q] = r.a[q];
 }
 
 }  // namespace
@@ -151,15 +159,24 @@ __global__ __launch_bounds__(256, 1) void winograd_conv_kernel(const ConvArgs p)
     // LDS-DMA of one chunk = kWPiecesPerWave `buffer_load_dwordx4 ... lds` per wave. A piece's per-lane
     // source offset does not depend on the chunk (only the scalar offset does), so it is computed once:
     // a chunk's staging is then 10 instructions per wave with no address arithmetic in the K loop.
+    // Pieces of a wave: r < kWWlPerWave are weight pieces (wave + 4r), the rest patch pieces
+    // (wave + 4(r - kWWlPerWave), one spare slot wraps round): the KIND of slot r is a compile-time fact,
+    // so a chunk's staging is straight-line code that can be woven between MFMAs.
+    static_assert((kWWlFloats / 256) % 4 == 0, "weight pieces split evenly over the four waves");
+    constexpr int kWWlPerWave = kWWlFloats / 256 / 4;
+    constexpr int kWPlPerWave = (kWPlInstr + 3) / 4;
+    static_assert(kWWlPerWave + kWPlPerWave == kWPiecesPerWave, "piece slots per wave");
     int dma_voff[kWPiecesPerWave];
+    int dma_lds[kWPiecesPerWave];  // float offset of the slot's 1 KiB piece inside a ring buffer (wave-uniform)
 #pragma unroll
     for (int r = 0; r < kWPiecesPerWave; ++r) {
-        int g = wave + 4 * r;
-        if (g >= kWPieces) g -= kWPieces;
-        if (g < kWWlFloats / 256) {
+        if (r < kWWlPerWave) {
+            const int g = wave + 4 * r;
             dma_voff[r] = (g * 256 + lane * 4) * 4;
+            dma_lds[r] = g * 256;
         } else {
-            const int i = g - kWWlFloats / 256;
+            int i = wave + 4 * (r - kWWlPerWave);
+            if (i >= kWPlInstr) i -= kWPlInstr;            // spare slot: repeat an early piece (same bytes)
             const int f = min(i * 64 + lane, kWPlF4 - 1);  // tail lanes of the last piece repeat its last float4
             const int q = f % (kWPW / 4);
             int rr = f / (kWPW / 4);
@@ -168,25 +185,24 @@ __global__ __launch_bounds__(256, 1) void winograd_conv_kernel(const ConvArgs p)
             const int gy = min(y0 + py, Hp - 1);
             const int gx = min(x0 + 4 * q, Wp - 4);
             dma_voff[r] = ((c * Hp + gy) * Wp + gx) * 4;
+            dma_lds[r] = kWWlFloats + i * 256;
         }
     }
     const int x_chunk_bytes = kWKC * Hp * Wp * 4;
     auto stage = [&](int chunk, float* buf) {
 #pragma unroll
         for (int r = 0; r < kWPiecesPerWave; ++r) {
-            int g = wave + 4 * r;
-            if (g >= kWPieces) g -= kWPieces;
-            if (g < kWWlFloats / 256)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, (lds_ptr_t)(buf + g * 256), 16, dma_voff[r],
+            if (r < kWWlPerWave)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, (lds_ptr_t)(buf + dma_lds[r]), 16, dma_voff[r],
                                                          chunk * (kWWlFloats * 4), 0, 0);
             else
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(x_rsrc, (lds_ptr_t)(buf + kWWlFloats + (g - kWWlFloats / 256) * 256), 16,
-                                                         dma_voff[r], chunk * x_chunk_bytes, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(x_rsrc, (lds_ptr_t)(buf + dma_lds[r]), 16, dma_voff[r],
+                                                         chunk * x_chunk_bytes, 0, 0);
         }
     };
 
     // ring prologue: every slot in flight (every wave issues exactly kWPiecesPerWave pieces per chunk)
-    for (int c = 0; c < kWNBUF && c < nchunks; ++c) stage(c, buf0 + c * kWBufFloats);
+    for (int c = 0; c < kWNBUF; ++c) stage(min(c, nchunks - 1), buf0 + c * kWBufFloats);
     {   // per-tile constants: plain loads issued after the ring prologue; hipcc waits for them with
         // vmcnt(0), i.e. for the whole prologue, before the LDS writes below
         const int b = min(b0, p.B - 1);
@@ -224,7 +240,7 @@ __global__ __launch_bounds__(256, 1) void winograd_conv_kernel(const ConvArgs p)
     static_assert(kWNBUF >= 2 && (kWNBUF - 1) * kWPiecesPerWave <= 63, "ring depth vmcnt can express");
     WinoRaw raw[2];
     WinoOps ops[2];
-    if (nchunks >= kWNBUF) wait_vmcnt<(kWNBUF - 1) * kWPiecesPerWave>(); else wait_vmcnt<0>();
+    wait_vmcnt<(kWNBUF - 1) * kWPiecesPerWave>();
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     wino_load(buf0, buf0 + kWWlFloats, s_lds, 0, poff, l31, lh, raw[0]);
@@ -235,13 +251,14 @@ __global__ __launch_bounds__(256, 1) void winograd_conv_kernel(const ConvArgs p)
 #pragma unroll
         for (int q = 0; q < 16; ++q) acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(o.a[q], o.v[q], acc[q], 0, 0, 0);
     };
-    // weave: 16 x (1 MFMA, 4 VALU, 2 LDS reads)
-    auto weave = [&]() {
+    // weave: 16 x (1 MFMA, 4 VALU, 2 LDS reads [, 1 LDS-DMA issue])
+    auto weave = [&](bool with_dma) {
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
             __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
             __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+            if (with_dma) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
         }
     };
 
@@ -252,24 +269,28 @@ __global__ __launch_bounds__(256, 1) void winograd_conv_kernel(const ConvArgs p)
 #pragma unroll
         for (int j = 0; j < KS; ++j) {
             if (j + 2 == KS && !(p.debug_flags & 8)) {
-                // L leaves chunk c: every wave's reads of it are done once they have returned
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                if (c + kWNBUF <= nchunks - 1) wait_vmcnt<(kWNBUF - 2) * kWPiecesPerWave>(); else wait_vmcnt<0>();
+                // L moves on to chunk c+1: it must have landed (the NBUF-2 younger chunks stay in flight)
+                // and every wave must be here before chunk c's slot may be refilled
+                wait_vmcnt<(kWNBUF - 2) * kWPiecesPerWave>();
                 __builtin_amdgcn_s_barrier();
                 asm volatile("" ::: "memory");
-                if (c + kWNBUF < nchunks && !(p.debug_flags & 2)) stage(c + kWNBUF, buf0 + (c % kWNBUF) * kWBufFloats);
             }
             __builtin_amdgcn_sched_barrier(0);
+            // one k-step later every wave's last LDS reads of chunk c (issued before the barrier above)
+            // have long returned: refill its slot, the DMA issues woven between this k-step's MFMAs.
+            // Past the end the last chunk is fetched again (same count of pieces in flight, no tail case).
+            if (j + 1 == KS && !(p.debug_flags & 10)) stage(min(c + kWNBUF, nchunks - 1), buf0 + (c % kWNBUF) * kWBufFloats);
             if (j + 2 < KS)
                 wino_load(Uc, Uc + kWWlFloats, s_lds + c * kWKC, j + 2, poff, l31, lh, raw[j & 1]);
             else
                 wino_load(Un, Un + kWWlFloats, s_lds + (c + 1) * kWKC, j + 2 - KS, poff, l31, lh, raw[j & 1]);
             wino_transform(raw[(j + 1) & 1], ops[(j + 1) & 1]);
             mfma16(ops[j & 1]);
-            weave();
+            weave(j + 1 == KS);
             __builtin_amdgcn_sched_barrier(0);
         }
     }
+    wait_vmcnt<0>();  // nothing of the ring may still be landing when the block's LDS is given back
     {   // the last chunk: the pipeline drains
         const int c = nchunks - 1;
         const float* const Uc = buf0 + (c % kWNBUF) * kWBufFloats;
@@ -279,7 +300,7 @@ __global__ __launch_bounds__(256, 1) void winograd_conv_kernel(const ConvArgs p)
             if (j + 2 < KS) wino_load(Uc, Uc + kWWlFloats, s_lds + c * kWKC, j + 2, poff, l31, lh, raw[j & 1]);
             if (j + 1 < KS) wino_transform(raw[(j + 1) & 1], ops[(j + 1) & 1]);
             mfma16(ops[j & 1]);
-            weave();
+            weave(false);
             __builtin_amdgcn_sched_barrier(0);
         }
     }
