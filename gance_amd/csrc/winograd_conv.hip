@@ -54,7 +54,10 @@ constexpr int kWPieces = kWWlFloats / 256 + kWPlInstr;     // 20
 // the same count for every wave (counted vmcnt); a spare slot re-issues an early piece (same bytes)
 constexpr int kWPiecesPerWave = (kWPieces + 3) / 4;
 
-inline size_t winograd_lds_bytes(int cin) { return sizeof(float) * ((size_t)kWNBUF * kWBufFloats + cin + 2 * kWBM); }
+constexpr int kWConstFloats = 512 + 64 + 64;  // per-tile constants: style [<= 512] | demod [32 of 64] | bias [32 of 64]
+inline size_t winograd_lds_bytes() {
+    return sizeof(float) * ((size_t)kWNBUF * kWBufFloats + 2 * kWConstFloats + (size_t)kWPiecesPerWave * 256);
+}
 
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
@@ -64,7 +67,6 @@ __device__ __forceinline__ void wait_vmcnt() {
 // Operands of one k-step (2 input channels: lane half = k index of the MFMA) as they come out of LDS.
 struct WinoRaw {
     float d[4][4];  // the tile's 4x4 input window
-    float a[16];    // transformed-weight fragment of the 16 positions
     float s;        // style scale of the lane's channel
 };
 // ... and as the MFMAs take them
@@ -75,8 +77,13 @@ struct WinoOps {
 // LDS reads of k-step `kk` of a chunk. U, P and s are __restrict__: that scoped no-alias against the
 // ring slot a later chunk's LDS-DMA is writing keeps hipcc from putting `s_waitcnt vmcnt(0)` in front
 // of these reads (it would drain the whole ring every chunk).
-__device__ __forceinline__ void wino_load(const float* __restrict__ U, const float* __restrict__ P,
-                                          const float* __restrict__ s_chunk, int kk, int poff, int l31, int lh, WinoRaw& r) {
+__device__ __forceinline__ void wino_load_a(const float* __restrict__ U, int kk, int l31, int lh, WinoOps& o) {
+    const int cl = 2 * kk + lh;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) o.a[q] = U[(q * kWKC + cl) * kWBM + l31];
+}
+__device__ __forceinline__ void wino_load(const float* __restrict__ P, const float* __restrict__ s_chunk, int kk, int poff,
+                                          int lh, WinoRaw& r) {
     const int cl = 2 * kk + lh;
     // one opaque offset per k-step: the four window rows are then immediate offsets (72 dwords apart) of
     // the LDS reads from ONE address register instead of eight separately added addresses
@@ -91,8 +98,6 @@ __device__ __forceinline__ void wino_load(const float* __restrict__ U, const flo
         r.d[y][2] = pc[y * kWPW + 2];
         r.d[y][3] = pc[y * kWPW + 3];
     }
-#pragma unroll
-    for (int q = 0; q < 16; ++q) r.a[q] = U[(q * kWKC + cl) * kWBM + l31];
     r.s = s_chunk[cl];
 }
 
@@ -116,8 +121,6 @@ __device__ __forceinline__ void wino_transform(const WinoRaw& r, WinoOps& o) {
         o.v[y * 4 + 2] = t[y][2] - t[y][1];
         o.v[y * 4 + 3] = t[y][1] - t[y][3];
     }
-#pragma unroll
-    for (int q = 0; q < 16; ++q) o.a[q] = r.a[q];
 }
 
 }  // namespace
@@ -125,99 +128,131 @@ __device__ __forceinline__ void wino_transform(const WinoRaw& r, WinoOps& o) {
 __global__ __launch_bounds__(256, 1) void winograd_conv_kernel(const ConvArgs p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* const buf0 = smem;
-    float* const s_lds = smem + kWNBUF * kWBufFloats;  // [Cin]
-    float* const d_lds = s_lds + p.Cin;                // [BM]
-    float* const b_lds = d_lds + kWBM;                 // [BM]
+    // two sets of per-tile constants (tile parity), in 64-dword DMA pieces: style [512] | demod [64] | bias [64]
+    float* const const0 = smem + kWNBUF * kWBufFloats;
 
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lane = tid & 63, l31 = lane & 31, lh = lane >> 5;
-
-    // virtual block id -> tile, XCD-aware (same scheme as the direct kernel)
-    int id;
-    {
-        const int nwg = gridDim.x, v = blockIdx.x;
-        const int q = nwg >> 3, r = nwg & 7, xcd = v & 7;
-        id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (v >> 3);
-    }
-    const int m_tile = id % p.m_tiles;
-    id /= p.m_tiles;
-    const int tile_x = id % p.tiles_x;
-    id /= p.tiles_x;
-    const int tile_y = id % p.tiles_y;
-    const int b0 = id / p.tiles_y;
-    const int y0 = tile_y * kWTH, x0 = tile_x * kWTW;
-    const int m0 = m_tile * kWBM;
+    const int l31_k = l31, lh_k = lh;
     const int Hp = p.H + 2, Wp = p.W + 8;
-    const int nchunks = p.total_chunks;
+    const int n = p.total_chunks;  // chunks per tile
 
-    const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)(p.w + ((size_t)m_tile * p.total_chunks) * kWWlFloats), 0, 0x7fffffff, 0x00020000);
-    const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)(p.x + (size_t)min(b0, p.B - 1) * p.x_b_stride), 0, 0x7fffffff, 0x00020000);
+    // A block is persistent: it walks tiles blockIdx.x, + gridDim.x, ... and treats their chunks as ONE
+    // stream, so the ring keeps prefetching across tile boundaries (with one block per CU nothing else
+    // would hide a tile's first fetch).
+    const int my_tiles = (p.total_tiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int total_q = my_tiles * n;
+    struct Tile {
+        int m_tile, y0, x0, b0;
+    };
+    auto decode = [&](int i) {
+        // virtual block id -> tile, XCD-aware (a persistent block strides by a multiple of 8)
+        const int v = (int)blockIdx.x + min(i, my_tiles - 1) * (int)gridDim.x;
+        const int nwg = p.total_tiles;
+        const int q = nwg >> 3, r = nwg & 7, xcd = v & 7;
+        int id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (v >> 3);
+        Tile t;
+        t.m_tile = id % p.m_tiles;
+        id /= p.m_tiles;
+        t.x0 = (id % p.tiles_x) * kWTW;
+        id /= p.tiles_x;
+        t.y0 = (id % p.tiles_y) * kWTH;
+        t.b0 = id / p.tiles_y;
+        return t;
+    };
 
-    // LDS-DMA of one chunk = kWPiecesPerWave `buffer_load_dwordx4 ... lds` per wave. A piece's per-lane
-    // source offset does not depend on the chunk (only the scalar offset does), so it is computed once:
-    // a chunk's staging is then 10 instructions per wave with no address arithmetic in the K loop.
-    // Pieces of a wave: r < kWWlPerWave are weight pieces (wave + 4r), the rest patch pieces
-    // (wave + 4(r - kWWlPerWave), one spare slot wraps round): the KIND of slot r is a compile-time fact,
-    // so a chunk's staging is straight-line code that can be woven between MFMAs.
+    // LDS-DMA of one chunk = kWPiecesPerWave `buffer_load_dwordx4 ... lds` per wave. Tiles are whole
+    // (H % 8 == 0, W % 64 == 0), so a piece's per-lane source offset depends neither on the chunk nor
+    // on the tile: only scalar offsets do. Slot r < kWWlPerWave of a wave is a weight piece (wave + 4r),
+    // the rest are patch pieces (one spare slot repeats an early piece): the KIND of a slot is a
+    // compile-time fact, so a chunk's staging is straight-line code that can be woven between MFMAs.
     static_assert((kWWlFloats / 256) % 4 == 0, "weight pieces split evenly over the four waves");
     constexpr int kWWlPerWave = kWWlFloats / 256 / 4;
     constexpr int kWPlPerWave = (kWPlInstr + 3) / 4;
     static_assert(kWWlPerWave + kWPlPerWave == kWPiecesPerWave, "piece slots per wave");
-    int dma_voff[kWPiecesPerWave];
+    // The per-lane offsets live in LDS, not in registers: they are needed once per chunk, and a register
+    // hipcc decided to spill would come back by a scratch load, i.e. a vector-memory operation whose wait
+    // drains the whole ring.
+    int* const voff_lds = reinterpret_cast<int*>(const0 + 2 * kWConstFloats);  // [kWPiecesPerWave][256]
     int dma_lds[kWPiecesPerWave];  // float offset of the slot's 1 KiB piece inside a ring buffer (wave-uniform)
 #pragma unroll
     for (int r = 0; r < kWPiecesPerWave; ++r) {
         if (r < kWWlPerWave) {
             const int g = wave + 4 * r;
-            dma_voff[r] = (g * 256 + lane * 4) * 4;
+            voff_lds[r * 256 + tid] = (g * 256 + lane * 4) * 4;
             dma_lds[r] = g * 256;
         } else {
             int i = wave + 4 * (r - kWWlPerWave);
-            if (i >= kWPlInstr) i -= kWPlInstr;            // spare slot: repeat an early piece (same bytes)
+            if (i >= kWPlInstr) i -= kWPlInstr;
             const int f = min(i * 64 + lane, kWPlF4 - 1);  // tail lanes of the last piece repeat its last float4
             const int q = f % (kWPW / 4);
             int rr = f / (kWPW / 4);
             const int py = rr % kWPH;
             const int c = rr / kWPH;
-            const int gy = min(y0 + py, Hp - 1);
-            const int gx = min(x0 + 4 * q, Wp - 4);
-            dma_voff[r] = ((c * Hp + gy) * Wp + gx) * 4;
+            voff_lds[r * 256 + tid] = ((c * Hp + py) * Wp + 4 * q) * 4;
             dma_lds[r] = kWWlFloats + i * 256;
         }
     }
     const int x_chunk_bytes = kWKC * Hp * Wp * 4;
-    auto stage = [&](int chunk, float* buf) {
+    const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, 0x7fffffff, 0x00020000);
+
+    // ---- staging side of the stream (scalar state): which tile / chunk / ring slot comes next ----
+    int st_tile = 0, st_chunk = 0, st_slot = 0;
+    int st_w_soff = 0, st_x_soff = 0;
+    __amdgpu_buffer_rsrc_t st_x_rsrc = w_rsrc;
+    // first chunk of a tile: its source descriptors, and its constants by dword LDS-DMA (3 per wave, every
+    // wave, so the counted waits stay uniform; lanes past an array's end read zeros into padding)
+    auto stage_setup = [&](int i) {
+        const Tile t = decode(i);
+        const int b = min(t.b0, p.B - 1);
+        st_x_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(p.x + (size_t)b * p.x_b_stride), 0, 0x7fffffff, 0x00020000);
+        st_w_soff = t.m_tile * n * (kWWlFloats * 4);
+        st_x_soff = (t.y0 * Wp + t.x0) * 4;
+        float* const set = const0 + (i & 1) * kWConstFloats;
+        int ln = lane;
+        asm volatile("" : "+v"(ln));  // recompute the three offsets here instead of keeping them live
+        const __amdgpu_buffer_rsrc_t s_rsrc =
+            __builtin_amdgcn_make_buffer_rsrc((void*)(p.s + (size_t)b * p.s_stride), 0, p.Cin * 4, 0x00020000);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(s_rsrc, (lds_ptr_t)(set + wave * 64), 4, (wave * 64 + ln) * 4, 0, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(s_rsrc, (lds_ptr_t)(set + (wave + 4) * 64), 4, ((wave + 4) * 64 + ln) * 4, 0, 0, 0);
+        const bool demod_piece = wave < 2;
+        const __amdgpu_buffer_rsrc_t c_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+            (void*)(demod_piece ? p.d + (size_t)b * p.d_stride + t.m_tile * kWBM : p.bias + t.m_tile * kWBM), 0, kWBM * 4, 0x00020000);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(c_rsrc, (lds_ptr_t)(set + 512 + (demod_piece ? 0 : 64)), 4, ln * 4, 0, 0, 0);
+    };
+    // the next chunk of the stream into the next ring slot; past the end the last chunk is fetched again
+    // (same number of pieces in flight, no tail case in the waits)
+    auto stage_next = [&]() {
+        float* const buf = buf0 + st_slot * kWBufFloats;
+        const int w_soff = st_w_soff + st_chunk * (kWWlFloats * 4);
+        const int x_soff = st_x_soff + st_chunk * x_chunk_bytes;
 #pragma unroll
         for (int r = 0; r < kWPiecesPerWave; ++r) {
+            const int voff = voff_lds[r * 256 + tid];
             if (r < kWWlPerWave)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, (lds_ptr_t)(buf + dma_lds[r]), 16, dma_voff[r],
-                                                         chunk * (kWWlFloats * 4), 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, (lds_ptr_t)(buf + dma_lds[r]), 16, voff, w_soff, 0, 0);
             else
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(x_rsrc, (lds_ptr_t)(buf + dma_lds[r]), 16, dma_voff[r],
-                                                         chunk * x_chunk_bytes, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(st_x_rsrc, (lds_ptr_t)(buf + dma_lds[r]), 16, voff, x_soff, 0, 0);
+        }
+        st_slot = st_slot + 1 == kWNBUF ? 0 : st_slot + 1;
+        const bool more = st_tile * n + st_chunk + 1 < total_q;  // else stay on the last chunk
+        const bool wrap = more && st_chunk + 1 == n;
+        st_chunk = more ? (wrap ? 0 : st_chunk + 1) : st_chunk;
+        st_tile = wrap ? st_tile + 1 : st_tile;
+    };
+    // does the next stage_next() open a tile whose setup has not been done?
+    int st_setup_done = 0;  // tiles set up so far
+    auto stage_setup_if_due = [&]() {
+        if (st_chunk == 0 && st_tile == st_setup_done && st_tile < my_tiles) {
+            stage_setup(st_tile);
+            st_setup_done = st_tile + 1;
         }
     };
 
-    // ring prologue: every slot in flight (every wave issues exactly kWPiecesPerWave pieces per chunk)
-    for (int c = 0; c < kWNBUF; ++c) stage(min(c, nchunks - 1), buf0 + c * kWBufFloats);
-    {   // per-tile constants: plain loads issued after the ring prologue; hipcc waits for them with
-        // vmcnt(0), i.e. for the whole prologue, before the LDS writes below
-        const int b = min(b0, p.B - 1);
-        const float* sp = p.s + (size_t)b * p.s_stride;
-        const float s0 = tid < p.Cin ? sp[tid] : 0.f;
-        const float s1 = tid + 256 < p.Cin ? sp[tid + 256] : 0.f;
-        const float dv = tid < kWBM ? p.d[(size_t)b * p.d_stride + m0 + tid] : 0.f;
-        const float bv = tid < kWBM ? p.bias[m0 + tid] : 0.f;
-        if (tid < p.Cin) s_lds[tid] = s0;
-        if (tid + 256 < p.Cin) s_lds[tid + 256] = s1;
-        if (tid < kWBM) {
-            d_lds[tid] = dv;
-            b_lds[tid] = bv;
-        }
-    }
+    // ring prologue: every slot in flight (a tile has at least kWNBUF chunks: only tile 0 is touched)
+    stage_setup_if_due();
+    for (int c = 0; c < kWNBUF; ++c) stage_next();
 
     f32x16 acc[16];
 #pragma unroll
@@ -229,22 +264,90 @@ __global__ __launch_bounds__(256, 1) void winograd_conv_kernel(const ConvArgs p)
     const int poff = (2 * wave) * kWPW + 2 * l31 + 3;
     constexpr int KS = kWKC / 2;  // k-steps per chunk
     static_assert(KS % 2 == 0 && KS >= 2, "the pipeline's register parity is per chunk");
+    static_assert(kWNBUF >= 2 && (kWNBUF - 1) * kWPiecesPerWave + 3 <= 63, "ring depth vmcnt can express");
 
-    // Three-stage software pipeline over k-steps g = c*KS + j, so that ONE wave keeps the matrix pipe busy:
-    //   L: LDS reads of k-step g+2   T: input transform + style scale of k-step g+1   M: the 16 MFMAs of k-step g
+    // ---- output transform Y = A^T M A (A^T = [[1,1,1,0],[0,1,-1,-1]]), epilogue, stores; clears acc ----
+    auto epilogue = [&](int i) {
+        const Tile t = decode(i);
+        const float* const d_lds = const0 + (i & 1) * kWConstFloats + 512;
+        const float* const b_lds = d_lds + 64;
+        // lane ids re-derived here from opaque copies: the epilogue's per-lane address arithmetic is then
+        // redone per tile (a dozen instructions) instead of being kept live through the K loop, where
+        // hipcc would spill it to scratch (a scratch reload is a vector-memory operation: it drains the ring)
+        int l31 = l31_k, lh = lh_k;
+        asm volatile("" : "+v"(l31), "+v"(lh));
+        const int oy = t.y0 + 2 * wave, ox = t.x0 + 2 * l31;
+        const bool ok = t.b0 < p.B && oy < p.OH && ox < p.OW;
+        float nz[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
+        if (p.noise != nullptr && ok) {
+#pragma unroll
+            for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+                for (int dx = 0; dx < 2; ++dx) nz[dy][dx] = p.noise[(size_t)(oy + dy) * p.OW + ox + dx] * p.noise_strength;
+        }
+        const bool full = p.epilogue == kEpilogueFull;
+        const int c_stride_bytes = (int)p.out_c_stride * 4;
+        const __amdgpu_buffer_rsrc_t o_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+            (void*)(p.out + (size_t)t.b0 * p.out_b_stride + (size_t)(t.m_tile * kWBM) * p.out_c_stride), 0, 0x7fffffff, 0x00020000);
+        const int voff0 = ((oy + p.out_y_off) * p.out_row_stride + ox + p.out_x_off) * 4 + 4 * lh * c_stride_bytes;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            // one accumulator row at a time: the pipeline's operand registers stay live across the
+            // epilogue, and without this fence hipcc pulls all 256 accumulators into VGPRs at once (spills)
+            __builtin_amdgcn_sched_barrier(0);
+            const int m = (r & 3) + 8 * (r >> 2) + 4 * lh;
+            float u[2][4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                u[0][j] = acc[0 * 4 + j][r] + acc[1 * 4 + j][r] + acc[2 * 4 + j][r];
+                u[1][j] = acc[1 * 4 + j][r] - acc[2 * 4 + j][r] - acc[3 * 4 + j][r];
+            }
+            const float dm = d_lds[m], bm = b_lds[m];
+#pragma unroll
+            for (int dy = 0; dy < 2; ++dy) {
+                float y2[2];
+                y2[0] = u[dy][0] + u[dy][1] + u[dy][2];
+                y2[1] = u[dy][1] - u[dy][2] - u[dy][3];
+#pragma unroll
+                for (int dx = 0; dx < 2; ++dx) {
+                    float v = y2[dx] * dm;
+                    if (full) {
+                        v += nz[dy][dx] + bm;
+                        v = fmaxf(v, 0.2f * v) * 1.4142135623730951f;
+                    }
+                    y2[dx] = v;
+                }
+                if (ok) {
+                    const int soff = ((r & 3) + 8 * (r >> 2)) * c_stride_bytes;
+                    u32x2 pair;
+                    pair[0] = __float_as_uint(y2[0]);
+                    pair[1] = __float_as_uint(y2[1]);
+                    __builtin_amdgcn_raw_buffer_store_b64(pair, o_rsrc, voff0 + dy * p.out_row_stride * 4, soff, 0);
+                }
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 16; ++q)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[q][r] = 0.f;
+    };
+
+    // Three-stage software pipeline over the k-steps of the stream, so that ONE wave keeps the matrix pipe busy:
+    //   L: LDS reads (input window of k-step g+2, weight fragments of k-step g+1)   T: input transform (with the
+    //   style scale) of k-step g+1   M: the 16 MFMAs of k-step g
     // The three stages of an iteration are independent, and a sched_group_barrier pattern weaves them:
-    // one MFMA, then a few VALU / LDS instructions that fit in its shadow. L runs two k-steps ahead of M,
-    // so it is L that crosses into the next chunk first: there the chunk's landing is awaited (counted
-    // vmcnt: the younger chunks stay in flight), the block synchronises, and the ring slot L has just
-    // left is refilled by LDS-DMA.
-    static_assert(kWNBUF >= 2 && (kWNBUF - 1) * kWPiecesPerWave <= 63, "ring depth vmcnt can express");
+    // one MFMA, then a few VALU / LDS / DMA-issue instructions that fit in its shadow. L runs two k-steps
+    // ahead of M, so it is L that crosses into the next chunk first: there the chunk's landing is awaited
+    // (counted vmcnt: the younger chunks stay in flight) and the block synchronises; one k-step later the
+    // ring slot L has left is refilled.
     WinoRaw raw[2];
     WinoOps ops[2];
     wait_vmcnt<(kWNBUF - 1) * kWPiecesPerWave>();
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
-    wino_load(buf0, buf0 + kWWlFloats, s_lds, 0, poff, l31, lh, raw[0]);
-    wino_load(buf0, buf0 + kWWlFloats, s_lds, 1, poff, l31, lh, raw[1]);
+    wino_load(buf0 + kWWlFloats, const0, 0, poff, lh, raw[0]);
+    wino_load(buf0 + kWWlFloats, const0, 1, poff, lh, raw[1]);
+    wino_load_a(buf0, 0, l31, lh, ops[0]);
     wino_transform(raw[0], ops[0]);
 
     auto mfma16 = [&](const WinoOps& o) {
@@ -262,99 +365,72 @@ __global__ __launch_bounds__(256, 1) void winograd_conv_kernel(const ConvArgs p)
         }
     };
 
-    // every chunk but the last: the k-steps L and T reach for always exist
-    for (int c = 0; c + 1 < nchunks; ++c) {
-        const float* const Uc = buf0 + (c % kWNBUF) * kWBufFloats;
-        const float* const Un = buf0 + ((c + 1) % kWNBUF) * kWBufFloats;
+    int tile = 0, slot = 0;  // M's position in the stream
+    // `count` chunks of tile `tile` starting at chunk c0, none of them the last chunk of the stream:
+    // the k-steps L and T reach for always exist (in this tile, or the first of the next one)
+    auto run_chunks = [&](int c0, int count) {
+        for (int c = c0; c < c0 + count; ++c) {
+            const int next_slot = slot + 1 == kWNBUF ? 0 : slot + 1;
+            const float* const Uc = buf0 + slot * kWBufFloats;
+            const float* const Un = buf0 + next_slot * kWBufFloats;
+            const float* const s_c = const0 + (tile & 1) * kWConstFloats + c * kWKC;
+            const float* const s_n = c + 1 < n ? s_c + kWKC : const0 + ((tile + 1) & 1) * kWConstFloats;
 #pragma unroll
-        for (int j = 0; j < KS; ++j) {
-            if (j + 2 == KS && !(p.debug_flags & 8)) {
-                // L moves on to chunk c+1: it must have landed (the NBUF-2 younger chunks stay in flight)
-                // and every wave must be here before chunk c's slot may be refilled
-                wait_vmcnt<(kWNBUF - 2) * kWPiecesPerWave>();
-                __builtin_amdgcn_s_barrier();
-                asm volatile("" ::: "memory");
+            for (int j = 0; j < KS; ++j) {
+                if (j + 2 == KS && !(p.debug_flags & 8)) {
+                    // L moves on to the next chunk: it must have landed (the NBUF-2 younger chunks stay
+                    // in flight) and every wave must be here before this chunk's slot may be refilled
+                    wait_vmcnt<(kWNBUF - 2) * kWPiecesPerWave>();
+                    __builtin_amdgcn_s_barrier();
+                    asm volatile("" ::: "memory");
+                    stage_setup_if_due();
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                // one k-step later every wave's last LDS reads of this chunk (issued before the barrier
+                // above) have long returned: refill its slot, the DMA issues woven between the MFMAs
+                if (j + 1 == KS && !(p.debug_flags & 10)) stage_next();
+                if (j + 2 < KS)
+                    wino_load(Uc + kWWlFloats, s_c, j + 2, poff, lh, raw[j & 1]);
+                else
+                    wino_load(Un + kWWlFloats, s_n, j + 2 - KS, poff, lh, raw[j & 1]);
+                if (j + 1 < KS)
+                    wino_load_a(Uc, j + 1, l31, lh, ops[(j + 1) & 1]);
+                else
+                    wino_load_a(Un, 0, l31, lh, ops[(j + 1) & 1]);
+                wino_transform(raw[(j + 1) & 1], ops[(j + 1) & 1]);
+                mfma16(ops[j & 1]);
+                weave(j + 1 == KS);
+                __builtin_amdgcn_sched_barrier(0);
             }
-            __builtin_amdgcn_sched_barrier(0);
-            // one k-step later every wave's last LDS reads of chunk c (issued before the barrier above)
-            // have long returned: refill its slot, the DMA issues woven between this k-step's MFMAs.
-            // Past the end the last chunk is fetched again (same count of pieces in flight, no tail case).
-            if (j + 1 == KS && !(p.debug_flags & 10)) stage(min(c + kWNBUF, nchunks - 1), buf0 + (c % kWNBUF) * kWBufFloats);
-            if (j + 2 < KS)
-                wino_load(Uc, Uc + kWWlFloats, s_lds + c * kWKC, j + 2, poff, l31, lh, raw[j & 1]);
-            else
-                wino_load(Un, Un + kWWlFloats, s_lds + (c + 1) * kWKC, j + 2 - KS, poff, l31, lh, raw[j & 1]);
-            wino_transform(raw[(j + 1) & 1], ops[(j + 1) & 1]);
-            mfma16(ops[j & 1]);
-            weave(j + 1 == KS);
-            __builtin_amdgcn_sched_barrier(0);
+            slot = next_slot;
         }
+    };
+    // every tile but the block's last: all its chunks, then its epilogue (L and T already hold the next
+    // tile's first k-steps in their registers)
+    for (; tile + 1 < my_tiles; ++tile) {
+        run_chunks(0, n);
+        epilogue(tile);
     }
+    run_chunks(0, n - 1);
+    const int c = n - 1;
     wait_vmcnt<0>();  // nothing of the ring may still be landing when the block's LDS is given back
-    {   // the last chunk: the pipeline drains
-        const int c = nchunks - 1;
-        const float* const Uc = buf0 + (c % kWNBUF) * kWBufFloats;
+    {   // the last chunk of the stream: the pipeline drains
+        const float* const Uc = buf0 + slot * kWBufFloats;
+        const float* const s_c = const0 + (tile & 1) * kWConstFloats + c * kWKC;
 #pragma unroll
         for (int j = 0; j < KS; ++j) {
             __builtin_amdgcn_sched_barrier(0);
-            if (j + 2 < KS) wino_load(Uc, Uc + kWWlFloats, s_lds + c * kWKC, j + 2, poff, l31, lh, raw[j & 1]);
-            if (j + 1 < KS) wino_transform(raw[(j + 1) & 1], ops[(j + 1) & 1]);
+            if (j + 2 < KS) wino_load(Uc + kWWlFloats, s_c, j + 2, poff, lh, raw[j & 1]);
+            if (j + 1 < KS) {
+                wino_load_a(Uc, j + 1, l31, lh, ops[(j + 1) & 1]);
+                wino_transform(raw[(j + 1) & 1], ops[(j + 1) & 1]);
+            }
             mfma16(ops[j & 1]);
             weave(false);
             __builtin_amdgcn_sched_barrier(0);
         }
     }
-
-    // ---- output transform Y = A^T M A (A^T = [[1,1,1,0],[0,1,-1,-1]]), epilogue, stores ----
-    const int oy = y0 + 2 * wave, ox = x0 + 2 * l31;
-    const bool in_batch = b0 < p.B;
-    float nz[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
-    if (p.noise != nullptr && in_batch) {
-#pragma unroll
-        for (int dy = 0; dy < 2; ++dy)
-#pragma unroll
-            for (int dx = 0; dx < 2; ++dx)
-                if (oy + dy < p.OH && ox + dx < p.OW) nz[dy][dx] = p.noise[(size_t)(oy + dy) * p.OW + ox + dx] * p.noise_strength;
-    }
-    const bool full = p.epilogue == kEpilogueFull;
-    const int c_stride_bytes = (int)p.out_c_stride * 4;
-    const __amdgpu_buffer_rsrc_t o_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)(p.out + (size_t)b0 * p.out_b_stride + (size_t)m0 * p.out_c_stride), 0, 0x7fffffff, 0x00020000);
-    const int voff0 = ((oy + p.out_y_off) * p.out_row_stride + ox + p.out_x_off) * 4 + 4 * lh * c_stride_bytes;
-    const bool ok = in_batch && oy < p.OH && ox < p.OW;  // tiles are whole: H and W are multiples of the tile
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int m = (r & 3) + 8 * (r >> 2) + 4 * lh;
-        float u[2][4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            u[0][j] = acc[0 * 4 + j][r] + acc[1 * 4 + j][r] + acc[2 * 4 + j][r];
-            u[1][j] = acc[1 * 4 + j][r] - acc[2 * 4 + j][r] - acc[3 * 4 + j][r];
-        }
-        const float dm = d_lds[m], bm = b_lds[m];
-#pragma unroll
-        for (int dy = 0; dy < 2; ++dy) {
-            float y2[2];
-            y2[0] = u[dy][0] + u[dy][1] + u[dy][2];
-            y2[1] = u[dy][1] - u[dy][2] - u[dy][3];
-#pragma unroll
-            for (int dx = 0; dx < 2; ++dx) {
-                float v = y2[dx] * dm;
-                if (full) {
-                    v += nz[dy][dx] + bm;
-                    v = fmaxf(v, 0.2f * v) * 1.4142135623730951f;
-                }
-                y2[dx] = v;
-            }
-            if (ok) {
-                const int soff = ((r & 3) + 8 * (r >> 2)) * c_stride_bytes;
-                u32x2 pair;
-                pair[0] = __float_as_uint(y2[0]);
-                pair[1] = __float_as_uint(y2[1]);
-                __builtin_amdgcn_raw_buffer_store_b64(pair, o_rsrc, voff0 + dy * p.out_row_stride * 4, soff, 0);
-            }
-        }
-    }
+    epilogue(tile);
 }
 
 size_t winograd_weight_floats(int cin, int cout) { return (size_t)16 * cin * cout; }
@@ -384,20 +460,24 @@ bool winograd_supported(int cin, int cout, int H, int W) {
 }
 
 hipError_t launch_winograd_conv(const ConvArgs& args, hipStream_t stream) {
-    static bool attr_set = false;
-    if (!attr_set) {
+    static int resident_blocks = 0;  // one block per CU (512 registers per wave), a multiple of 8 (XCDs)
+    if (resident_blocks == 0) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(winograd_conv_kernel),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)winograd_lds_bytes(512));
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)winograd_lds_bytes());
         if (e != hipSuccess) return e;
-        attr_set = true;
+        int device = 0, cus = 0;
+        if ((e = hipGetDevice(&device)) != hipSuccess) return e;
+        if ((e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device)) != hipSuccess) return e;
+        resident_blocks = std::max(8, cus / 8 * 8);
     }
     ConvArgs a = args;
     a.tiles_x = a.W / kWTW;
     a.tiles_y = a.H / kWTH;
     a.m_tiles = a.Cout / kWBM;
     a.total_chunks = a.Cin / kWKC;
-    const int blocks = a.m_tiles * a.tiles_x * a.tiles_y * a.B;
-    hipLaunchKernelGGL(winograd_conv_kernel, dim3(blocks), dim3(256), winograd_lds_bytes(a.Cin), stream, a);
+    a.total_tiles = a.m_tiles * a.tiles_x * a.tiles_y * a.B;
+    const int blocks = std::min(a.total_tiles, resident_blocks);
+    hipLaunchKernelGGL(winograd_conv_kernel, dim3(blocks), dim3(256), winograd_lds_bytes(), stream, a);
     return hipGetLastError();
 }
 
