@@ -278,6 +278,10 @@ def main() -> int:
     conv_steps = [s for s in steps_info if s.flops > 0 and s.name.startswith("conv")]
     conv_ms = sum(s.ms for s in conv_steps)
     conv_flops = sum(s.flops for s in conv_steps)
+    # Winograd F(2x2,3x3) launches ("convW..."): flops above are the ALGORITHMIC (direct-form) ones; the
+    # matrix cores execute 4/9 of them
+    executed_flops = sum(s.flops * (4.0 / 9.0 if s.name.startswith("convW") else 1.0) for s in conv_steps)
+    winograd_launches = sum(1 for s in conv_steps if s.name.startswith("convW"))
     total_ms = sum(s.ms for s in steps_info)
     if args.print_steps and rank == 0:
         for info in steps_info:
@@ -321,6 +325,9 @@ def main() -> int:
                     "achieved": round(conv_flops / (conv_ms * 1e-3) / 1e12, 3),
                     "frac": round(conv_flops / (conv_ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4),
                     "share_of_step_time": round(conv_ms / total_ms, 4),
+                    "winograd_launches": winograd_launches,
+                    "executed_mfma_tflops": round(executed_flops / (conv_ms * 1e-3) / 1e12, 3),
+                    "note": "achieved / frac count direct-form (algorithmic) flops; %d of the %d conv launches run in Winograd F(2x2,3x3) form and execute 4/9 of theirs" % (winograd_launches, len(conv_steps)),
                 },
                 "whole_path_frac": round(
                     (fps / world_size) * ALGORITHMIC_GFLOP_PER_FRAME_1024 * (resolution / 1024) ** 2 / 1e3 / FP32_MFMA_PEAK_TFLOPS, 4

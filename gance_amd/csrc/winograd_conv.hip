@@ -356,12 +356,15 @@ __global__ __launch_bounds__(256, 1) void winograd_conv_kernel(const ConvArgs p)
     };
     // weave: 16 x (1 MFMA, 4 VALU, 2 LDS reads [, 1 LDS-DMA issue])
     auto weave = [&](bool with_dma) {
+#ifndef GANCE_WINO_WEAVE
+#define GANCE_WINO_WEAVE 1
+#endif
 #pragma unroll
-        for (int q = 0; q < 16; ++q) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
-            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-            if (with_dma) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+        for (int q = 0; q < 16 / GANCE_WINO_WEAVE; ++q) {
+            __builtin_amdgcn_sched_group_barrier(0x008, GANCE_WINO_WEAVE, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, 4 * GANCE_WINO_WEAVE, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 2 * GANCE_WINO_WEAVE, 0);
+            if (with_dma) __builtin_amdgcn_sched_group_barrier(0x020, GANCE_WINO_WEAVE, 0);
         }
     };
 
