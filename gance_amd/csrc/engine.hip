@@ -436,24 +436,29 @@ int synthesize_from_dlat(gance_engine* e, const float* d_dlat, int B, uint8_t* d
             const auto& tile = gance::kConvTiles[p.tile_id];
             fused_rgb = fuse_enabled && c.res_log2 == e->res_log2 && limit == num_convs && p.nsplit == 1 &&
                         p.m_tiles == 1 && tile.TB == 1 && tile.BM == 32 && have_y;
+            // Winograd F(2x2,3x3) form where the layer supports it and the launch fills the chip
+            // (one block per CU). Engine flags choose: DIRECT_CONV = never, FORCE_WINOGRAD = whatever
+            // the block count; GANCE_TUNE_WINOGRAD = 0 / 1 / 2 overrides them for tuning.
+            static const int env_mode = [] { const char* v = std::getenv("GANCE_TUNE_WINOGRAD"); return v ? std::atoi(v) : -1; }();
+            const int wino_mode = env_mode >= 0 ? env_mode
+                                                : ((e->cfg.flags & GANCE_FLAG_DIRECT_CONV) ? 0 : ((e->cfg.flags & GANCE_FLAG_FORCE_WINOGRAD) ? 2 : 1));
+            const bool winograd = p.nsplit == 1 && wino_mode != 0 && e->wino_w[li] != SIZE_MAX &&
+                                  (wino_mode == 2 || (long long)(c.cout / 32) * (res / 8) * (res / 64) * B >= 256);
+            // the fused last layer stays in direct form unless Winograd is forced: its Winograd variant
+            // (built, parity-green) is register-starved in the fused epilogue and measured no faster
+            // (4.83 ms against 5.01 ms direct, 3.94 + 0.93 ms unfused); GANCE_TUNE_WINOGRAD_RGB=1 selects it
+            static const bool wino_rgb = [] { const char* v = std::getenv("GANCE_TUNE_WINOGRAD_RGB"); return v && std::atoi(v) != 0; }();
+            const bool winograd_last = winograd && (wino_mode == 2 || wino_rgb);
             if (fused_rgb) {
                 const int ri = c.res_log2 - 2;
                 FusedRgb rgb{e->pool + e->rgb_w[ri], e->styles + e->rgb_s_off[ri], e->pool + e->rgb_bias[ri],
                              e->ybuf[ycur], (d_f32 != nullptr || e->keep_skip_image) ? e->ybuf[1 - ycur] : nullptr, d_u8};
-                std::snprintf(name, sizeof(name), "conv%d+torgb_%dx%d_%d->%d", c.layer_idx, res, res, c.cin, c.cout);
+                std::snprintf(name, sizeof(name), "conv%s%d+torgb_%dx%d_%d->%d", winograd_last ? "W" : "", c.layer_idx, res, res, c.cin, c.cout);
                 int rc = run_conv(e, c, li, p, x_in, x_b_stride, res, res, x_out, gance::kEpilogueRgb, res + 8, 1, 4,
-                                  out_b, out_c, 0, 0, B, stream, name, &rgb);
+                                  out_b, out_c, 0, 0, B, stream, name, &rgb, winograd_last);
                 if (rc) return rc;
                 ycur = 1 - ycur;
             } else if (p.nsplit == 1) {
-                // Winograd F(2x2,3x3) form where the layer supports it and the launch fills the chip
-                // (one block per CU). Engine flags choose: DIRECT_CONV = never, FORCE_WINOGRAD = whatever
-                // the block count; GANCE_TUNE_WINOGRAD = 0 / 1 / 2 overrides them for tuning.
-                static const int env_mode = [] { const char* v = std::getenv("GANCE_TUNE_WINOGRAD"); return v ? std::atoi(v) : -1; }();
-                const int wino_mode = env_mode >= 0 ? env_mode
-                                                    : ((e->cfg.flags & GANCE_FLAG_DIRECT_CONV) ? 0 : ((e->cfg.flags & GANCE_FLAG_FORCE_WINOGRAD) ? 2 : 1));
-                const bool winograd = wino_mode != 0 && e->wino_w[li] != SIZE_MAX &&
-                                      (wino_mode == 2 || (long long)(c.cout / 32) * (res / 8) * (res / 64) * B >= 256);
                 if (winograd) std::snprintf(name, sizeof(name), "convW%d_%dx%d_%d->%d", c.layer_idx, res, res, c.cin, c.cout);
                 int rc = run_conv(e, c, li, p, x_in, x_b_stride, res, res, x_out,
                                   gance::kEpilogueFull, res + 8, 1, 4, out_b, out_c, 0, 0, B, stream,

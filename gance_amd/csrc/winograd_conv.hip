@@ -54,9 +54,13 @@ constexpr int kWPieces = kWWlFloats / 256 + kWPlInstr;     // 20
 // the same count for every wave (counted vmcnt); a spare slot re-issues an early piece (same bytes)
 constexpr int kWPiecesPerWave = (kWPieces + 3) / 4;
 
-constexpr int kWConstFloats = 512 + 64 + 64;  // per-tile constants: style [<= 512] | demod [32 of 64] | bias [32 of 64]
+// per-tile constants, in 64-dword DMA pieces: style [<= 512] | demod [32 of 64] | bias [32 of 64] | and for the
+// fused last layer: ToRGB style [32 of 64] | the tile's window of the half-resolution skip image [3][6][34] in 10 pieces
+constexpr int kWSkipRows = kWTH / 2 + 2, kWSkipCols = kWTW / 2 + 2;
+constexpr int kWSkipPieces = (3 * kWSkipRows * kWSkipCols + 63) / 64;
+constexpr int kWConstFloats = 512 + 64 + 64 + 64 + kWSkipPieces * 64;
 inline size_t winograd_lds_bytes() {
-    return sizeof(float) * ((size_t)kWNBUF * kWBufFloats + 2 * kWConstFloats + (size_t)kWPiecesPerWave * 256);
+    return sizeof(float) * ((size_t)kWNBUF * kWBufFloats + 2 * kWConstFloats + (size_t)kWPiecesPerWave * 256 + 128);
 }
 
 template <int N>
@@ -125,6 +129,9 @@ __device__ __forceinline__ void wino_transform(const WinoRaw& r, WinoOps& o) {
 
 }  // namespace
 
+// RGB = the network's last layer: the epilogue feeds the activation straight to its ToRGB, adds the
+// upsampled skip image and stores uint8 (kEpilogueRgb, as in conv_mfma.hip), no activation is written.
+template <bool RGB>
 __global__ __launch_bounds__(256, 1) void winograd_conv_kernel(const ConvArgs p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* const buf0 = smem;
@@ -175,6 +182,8 @@ __global__ __launch_bounds__(256, 1) void winograd_conv_kernel(const ConvArgs p)
     // hipcc decided to spill would come back by a scratch load, i.e. a vector-memory operation whose wait
     // drains the whole ring.
     int* const voff_lds = reinterpret_cast<int*>(const0 + 2 * kWConstFloats);  // [kWPiecesPerWave][256]
+    float* const rgbw_lds = reinterpret_cast<float*>(voff_lds + kWPiecesPerWave * 256);  // ToRGB weight [32][3] (+ pad)
+    if (RGB && tid < 96) rgbw_lds[tid] = p.rgb_w[tid];
     int dma_lds[kWPiecesPerWave];  // float offset of the slot's 1 KiB piece inside a ring buffer (wave-uniform)
 #pragma unroll
     for (int r = 0; r < kWPiecesPerWave; ++r) {
@@ -220,6 +229,30 @@ __global__ __launch_bounds__(256, 1) void winograd_conv_kernel(const ConvArgs p)
         const __amdgpu_buffer_rsrc_t c_rsrc = __builtin_amdgcn_make_buffer_rsrc(
             (void*)(demod_piece ? p.d + (size_t)b * p.d_stride + t.m_tile * kWBM : p.bias + t.m_tile * kWBM), 0, kWBM * 4, 0x00020000);
         __builtin_amdgcn_raw_ptr_buffer_load_lds(c_rsrc, (lds_ptr_t)(set + 512 + (demod_piece ? 0 : 64)), 4, ln * 4, 0, 0, 0);
+        if (RGB) {
+            // ToRGB style of the sample (every wave fetches the same piece: uniform counts)
+            const __amdgpu_buffer_rsrc_t rs_rsrc =
+                __builtin_amdgcn_make_buffer_rsrc((void*)(p.rgb_s + (size_t)b * p.s_stride), 0, kWBM * 4, 0x00020000);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_rsrc, (lds_ptr_t)(set + 640), 4, ln * 4, 0, 0, 0);
+            // the tile's window of the previous (half-resolution) skip image, 3 pieces per wave (two spare
+            // slots repeat pieces 0 and 1); addresses are clamped into the image, validity is decided at use
+            const int Rh = p.OW >> 1;
+            const __amdgpu_buffer_rsrc_t y_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+                (void*)(p.rgb_y_prev != nullptr ? p.rgb_y_prev + (size_t)b * 3 * Rh * Rh : p.x), 0, 0x7fffffff, 0x00020000);
+            const int row0 = (t.y0 >> 1) - 1, col0 = (t.x0 >> 1) - 1;
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+                int piece = wave + 4 * r;
+                if (piece >= kWSkipPieces) piece -= kWSkipPieces;
+                const int idx = min(piece * 64 + ln, 3 * kWSkipRows * kWSkipCols - 1);
+                const int cc = idx % kWSkipCols;
+                const int rr = (idx / kWSkipCols) % kWSkipRows;
+                const int k = idx / (kWSkipCols * kWSkipRows);
+                const int row = min(max(row0 + rr, 0), Rh - 1), col = min(max(col0 + cc, 0), Rh - 1);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(y_rsrc, (lds_ptr_t)(set + 704 + piece * 64), 4, ((k * Rh + row) * Rh + col) * 4,
+                                                         0, 0, 0);
+            }
+        }
     };
     // the next chunk of the stream into the next ring slot; past the end the last chunk is fetched again
     // (same number of pieces in flight, no tail case in the waits)
@@ -264,7 +297,7 @@ __global__ __launch_bounds__(256, 1) void winograd_conv_kernel(const ConvArgs p)
     const int poff = (2 * wave) * kWPW + 2 * l31 + 3;
     constexpr int KS = kWKC / 2;  // k-steps per chunk
     static_assert(KS % 2 == 0 && KS >= 2, "the pipeline's register parity is per chunk");
-    static_assert(kWNBUF >= 2 && (kWNBUF - 1) * kWPiecesPerWave + 3 <= 63, "ring depth vmcnt can express");
+    static_assert(kWNBUF >= 2 && (kWNBUF - 1) * kWPiecesPerWave + 7 <= 63, "ring depth vmcnt can express");
 
     // ---- output transform Y = A^T M A (A^T = [[1,1,1,0],[0,1,-1,-1]]), epilogue, stores; clears acc ----
     auto epilogue = [&](int i) {
@@ -285,6 +318,90 @@ __global__ __launch_bounds__(256, 1) void winograd_conv_kernel(const ConvArgs p)
 #pragma unroll
                 for (int dx = 0; dx < 2; ++dx) nz[dy][dx] = p.noise[(size_t)(oy + dy) * p.OW + ox + dx] * p.noise_strength;
         }
+        if constexpr (RGB) {
+            // ---- last layer: activation -> ToRGB (32 channels x 3, style * weight) -> + bias + upsampled skip
+            // image -> uint8. A lane holds its tile's 2x2 pixels for the 16 channels of its lane half.
+            const float* const set = const0 + (i & 1) * kWConstFloats;
+            const float* const srgb = set + 640;
+            const float* const skip = set + 704;
+            const int R = p.OW, Rh = R >> 1;
+            float rgb[2][2][3] = {};
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                __builtin_amdgcn_sched_barrier(0);
+                const int m = (r & 3) + 8 * (r >> 2) + 4 * lh;
+                float u[2][4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    u[0][j] = acc[0 * 4 + j][r] + acc[1 * 4 + j][r] + acc[2 * 4 + j][r];
+                    u[1][j] = acc[1 * 4 + j][r] - acc[2 * 4 + j][r] - acc[3 * 4 + j][r];
+                }
+                const float dm = d_lds[m], bm = b_lds[m], sm = srgb[m];
+                const float c0 = sm * rgbw_lds[m * 3 + 0], c1 = sm * rgbw_lds[m * 3 + 1], c2 = sm * rgbw_lds[m * 3 + 2];
+#pragma unroll
+                for (int dy = 0; dy < 2; ++dy) {
+                    float y2[2];
+                    y2[0] = u[dy][0] + u[dy][1] + u[dy][2];
+                    y2[1] = u[dy][1] - u[dy][2] - u[dy][3];
+#pragma unroll
+                    for (int dx = 0; dx < 2; ++dx) {
+                        float v = y2[dx] * dm;
+                        v += nz[dy][dx] + bm;
+                        v = fmaxf(v, 0.2f * v) * 1.4142135623730951f;
+                        rgb[dy][dx][0] = fmaf(v, c0, rgb[dy][dx][0]);
+                        rgb[dy][dx][1] = fmaf(v, c1, rgb[dy][dx][1]);
+                        rgb[dy][dx][2] = fmaf(v, c2, rgb[dy][dx][2]);
+                    }
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int dy = 0; dy < 2; ++dy) {
+                unsigned short q16[3];  // the row's two pixels = 6 bytes = three 16-bit stores
+                unsigned bytes[6];
+#pragma unroll
+                for (int dx = 0; dx < 2; ++dx) {
+                    // upsample_2d of the skip image ([1,3,3,1]/4 per axis = two taps per axis): lane half 0
+                    // takes the upper source row, half 1 the lower one; the halves join in the exchange below
+                    const int py = oy + dy, px = ox + dx;
+                    const int ya = (py & 1) ? (py >> 1) : (py >> 1) - 1;
+                    const int row = ya + lh;
+                    const float wrow = ((py & 1) != 0) == (lh == 0) ? 0.75f : 0.25f;
+                    const int xa = (px & 1) ? (px >> 1) : (px >> 1) - 1, xb = xa + 1;
+                    const float wxa = (px & 1) ? 0.75f : 0.25f, wxb = 1.0f - wxa;
+                    const bool row_ok = p.rgb_y_prev != nullptr && row >= 0 && row < Rh;
+                    const float* w0 = skip + (row - ((t.y0 >> 1) - 1)) * kWSkipCols - ((t.x0 >> 1) - 1);
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) {
+                        const float va = (row_ok && xa >= 0) ? w0[k * kWSkipRows * kWSkipCols + xa] : 0.f;
+                        const float vb = (row_ok && xb < Rh) ? w0[k * kWSkipRows * kWSkipCols + xb] : 0.f;
+                        rgb[dy][dx][k] += wrow * (wxa * va + wxb * vb);
+                    }
+                }
+#pragma unroll
+                for (int dx = 0; dx < 2; ++dx)
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) {
+                        const float y = rgb[dy][dx][k] + __shfl_xor(rgb[dy][dx][k], 32) + p.rgb_bias[k];
+                        if (p.rgb_y != nullptr && lh == 0 && ok)
+                            p.rgb_y[((size_t)t.b0 * 3 + k) * R * R + (size_t)(oy + dy) * R + ox + dx] = y;
+                        // tf.saturate_cast(x * 127.5 + 128): two roundings (the barrier keeps them apart)
+                        float q = y * 127.5f;
+                        asm volatile("" : "+v"(q));
+                        q += 128.0f;
+                        q = fminf(fmaxf(q, 0.f), 255.f);
+                        bytes[dx * 3 + k] = (unsigned)(int)q;
+                    }
+#pragma unroll
+                for (int h = 0; h < 3; ++h) q16[h] = (unsigned short)(bytes[2 * h] | (bytes[2 * h + 1] << 8));
+                if (p.rgb_u8 != nullptr && lh == 0 && ok) {
+                    unsigned short* dst = reinterpret_cast<unsigned short*>(p.rgb_u8 + (((size_t)t.b0 * R + oy + dy) * R + ox) * 3);
+                    dst[0] = q16[0];
+                    dst[1] = q16[1];
+                    dst[2] = q16[2];
+                }
+            }
+        } else {
         const bool full = p.epilogue == kEpilogueFull;
         const int c_stride_bytes = (int)p.out_c_stride * 4;
         const __amdgpu_buffer_rsrc_t o_rsrc = __builtin_amdgcn_make_buffer_rsrc(
@@ -325,6 +442,7 @@ __global__ __launch_bounds__(256, 1) void winograd_conv_kernel(const ConvArgs p)
                     __builtin_amdgcn_raw_buffer_store_b64(pair, o_rsrc, voff0 + dy * p.out_row_stride * 4, soff, 0);
                 }
             }
+        }
         }
 #pragma unroll
         for (int q = 0; q < 16; ++q)
@@ -462,11 +580,13 @@ bool winograd_supported(int cin, int cout, int H, int W) {
     return cin % kWKC == 0 && cin <= 512 && cout % kWBM == 0 && H % kWTH == 0 && W % kWTW == 0 && cin / kWKC >= kWNBUF;
 }
 
-hipError_t launch_winograd_conv(const ConvArgs& args, hipStream_t stream) {
+template <bool RGB>
+static hipError_t launch_winograd(const ConvArgs& args, hipStream_t stream) {
+    auto kernel = winograd_conv_kernel<RGB>;
     static int resident_blocks = 0;  // one block per CU (512 registers per wave), a multiple of 8 (XCDs)
     if (resident_blocks == 0) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(winograd_conv_kernel),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)winograd_lds_bytes());
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (int)winograd_lds_bytes());
         if (e != hipSuccess) return e;
         int device = 0, cus = 0;
         if ((e = hipGetDevice(&device)) != hipSuccess) return e;
@@ -480,8 +600,14 @@ hipError_t launch_winograd_conv(const ConvArgs& args, hipStream_t stream) {
     a.total_chunks = a.Cin / kWKC;
     a.total_tiles = a.m_tiles * a.tiles_x * a.tiles_y * a.B;
     const int blocks = std::min(a.total_tiles, resident_blocks);
-    hipLaunchKernelGGL(winograd_conv_kernel, dim3(blocks), dim3(256), winograd_lds_bytes(), stream, a);
+    hipLaunchKernelGGL(kernel, dim3(blocks), dim3(256), winograd_lds_bytes(), stream, a);
     return hipGetLastError();
+}
+
+hipError_t launch_winograd_conv(const ConvArgs& args, hipStream_t stream) {
+    // kEpilogueRgb: the fused last layer (Cout = 32 = one block's channels)
+    if (args.epilogue == kEpilogueRgb) return args.Cout == kWBM ? launch_winograd<true>(args, stream) : hipErrorInvalidValue;
+    return launch_winograd<false>(args, stream);
 }
 
 }  // namespace gance

@@ -118,6 +118,19 @@ def test_config_f_1024_frame_matches_oracle(library) -> None:
     _check_frames(frames, image, ref.synthesize_z(z, variables, resolution, truncation_psi=1.2))
 
 
+def test_config_f_1024_with_every_eligible_layer_in_winograd_form(library) -> None:
+    """The 64^2 ... 1024^2 stride-1 layers all in Winograd form, the last one fused with its ToRGB."""
+    resolution = 1024
+    variables = sg2_spec.make_random_variables(resolution, seed=0, perturb=True)
+    z = np.random.RandomState(2).randn(2, 512).astype(np.float32)
+    engine = hip_lib.Engine(variables, resolution, max_batch=2, conv_form="winograd")
+    try:
+        frames, image = engine.synthesize_z(z, truncation_psi=1.2, want_float=True)
+    finally:
+        engine.close()
+    _check_frames(frames[:1], image[:1], ref.synthesize_z(z[:1], variables, resolution, truncation_psi=1.2))
+
+
 def test_full_size_properties_batch_of_8(library) -> None:
     """
     Size-independent properties at the benchmark's batch: frames do not depend on their position
