@@ -442,8 +442,10 @@ int synthesize_from_dlat(gance_engine* e, const float* d_dlat, int B, uint8_t* d
             static const int env_mode = [] { const char* v = std::getenv("GANCE_TUNE_WINOGRAD"); return v ? std::atoi(v) : -1; }();
             const int wino_mode = env_mode >= 0 ? env_mode
                                                 : ((e->cfg.flags & GANCE_FLAG_DIRECT_CONV) ? 0 : ((e->cfg.flags & GANCE_FLAG_FORCE_WINOGRAD) ? 2 : 1));
-            const bool winograd = p.nsplit == 1 && wino_mode != 0 && e->wino_w[li] != SIZE_MAX &&
-                                  (wino_mode == 2 || (long long)(c.cout / 32) * (res / 8) * (res / 64) * B >= 256);
+            // (tiles of 8 x 64 pixels, or 16 x 32 on the 32-pixel-wide layer; the kernel has no split-K)
+            const long long wino_tiles = (long long)(c.cout / 32) * (res % 64 == 0 ? (res / 8) * (res / 64) : (res / 16) * (res / 32)) * B;
+            const bool winograd = wino_mode != 0 && e->wino_w[li] != SIZE_MAX &&
+                                  (wino_mode == 2 || (p.nsplit == 1 && wino_tiles >= 256));
             // the fused last layer stays in direct form unless Winograd is forced: its Winograd variant
             // (built, parity-green) is register-starved in the fused epilogue and measured no faster
             // (4.83 ms against 5.01 ms direct, 3.94 + 0.93 ms unfused); GANCE_TUNE_WINOGRAD_RGB=1 selects it
@@ -458,7 +460,7 @@ int synthesize_from_dlat(gance_engine* e, const float* d_dlat, int B, uint8_t* d
                                   out_b, out_c, 0, 0, B, stream, name, &rgb, winograd_last);
                 if (rc) return rc;
                 ycur = 1 - ycur;
-            } else if (p.nsplit == 1) {
+            } else if (p.nsplit == 1 || winograd) {
                 if (winograd) std::snprintf(name, sizeof(name), "convW%d_%dx%d_%d->%d", c.layer_idx, res, res, c.cin, c.cout);
                 int rc = run_conv(e, c, li, p, x_in, x_b_stride, res, res, x_out,
                                   gance::kEpilogueFull, res + 8, 1, 4, out_b, out_c, 0, 0, B, stream,

@@ -35,7 +35,10 @@ typedef __attribute__((address_space(3))) void* lds_ptr_t;
 namespace {
 
 constexpr int kWBM = 32;             // output channels per block
-constexpr int kWTH = 8, kWTW = 64;   // output pixels per block (4 x 32 tiles)
+// output pixels per block: 8 x 64 (4 x 32 tiles, wave = tile row) or, for the 32-pixel-wide layer,
+// 16 x 32 (8 x 16 tiles, wave = two tile rows); both have a 720-float patch per channel (10x72 / 18x40)
+constexpr int kWTH = 8, kWTW = 64;
+constexpr int kWTHn = 16, kWTWn = 32;
 #ifndef GANCE_WINO_KC
 #define GANCE_WINO_KC 8
 #endif
@@ -44,6 +47,8 @@ constexpr int kWTH = 8, kWTW = 64;   // output pixels per block (4 x 32 tiles)
 #endif
 constexpr int kWKC = GANCE_WINO_KC;  // input channels per chunk
 constexpr int kWPH = kWTH + 2, kWPW = kWTW + 8;
+constexpr int kWPHn = kWTHn + 2, kWPWn = kWTWn + 8;
+static_assert(kWPH * kWPW == kWPHn * kWPWn, "both geometries share the ring-slot layout");
 constexpr int kWNBUF = GANCE_WINO_NBUF;  // ring depth: NBUF-1 chunks in flight ahead of the one being multiplied
 constexpr int kWWlFloats = 16 * kWKC * kWBM;              // 1 KiB DMA pieces
 constexpr int kWPlFloats = kWKC * kWPH * kWPW;            // 2880
@@ -86,6 +91,7 @@ __device__ __forceinline__ void wino_load_a(const float* __restrict__ U, int kk,
 #pragma unroll
     for (int q = 0; q < 16; ++q) o.a[q] = U[(q * kWKC + cl) * kWBM + l31];
 }
+template <int PW>
 __device__ __forceinline__ void wino_load(const float* __restrict__ P, const float* __restrict__ s_chunk, int kk, int poff,
                                           int lh, WinoRaw& r) {
     const int cl = 2 * kk + lh;
@@ -97,10 +103,10 @@ __device__ __forceinline__ void wino_load(const float* __restrict__ P, const flo
     lds_cfloat pc = (lds_cfloat)(uintptr_t)window;
 #pragma unroll
     for (int y = 0; y < 4; ++y) {
-        r.d[y][0] = pc[y * kWPW];
-        r.d[y][1] = pc[y * kWPW + 1];
-        r.d[y][2] = pc[y * kWPW + 2];
-        r.d[y][3] = pc[y * kWPW + 3];
+        r.d[y][0] = pc[y * PW];
+        r.d[y][1] = pc[y * PW + 1];
+        r.d[y][2] = pc[y * PW + 2];
+        r.d[y][3] = pc[y * PW + 3];
     }
     r.s = s_chunk[cl];
 }
@@ -131,8 +137,11 @@ __device__ __forceinline__ void wino_transform(const WinoRaw& r, WinoOps& o) {
 
 // RGB = the network's last layer: the epilogue feeds the activation straight to its ToRGB, adds the
 // upsampled skip image and stores uint8 (kEpilogueRgb, as in conv_mfma.hip), no activation is written.
-template <bool RGB>
+template <bool RGB, bool WIDE>
 __global__ __launch_bounds__(256, 1) void winograd_conv_kernel(const ConvArgs p) {
+    constexpr int TH = WIDE ? kWTH : kWTHn, TW = WIDE ? kWTW : kWTWn;
+    constexpr int PH = TH + 2, PW = TW + 8;
+    static_assert(!RGB || WIDE, "the fused last layer uses the 8 x 64 geometry");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* const buf0 = smem;
     // two sets of per-tile constants (tile parity), in 64-dword DMA pieces: style [512] | demod [64] | bias [64]
@@ -162,9 +171,9 @@ __global__ __launch_bounds__(256, 1) void winograd_conv_kernel(const ConvArgs p)
         Tile t;
         t.m_tile = id % p.m_tiles;
         id /= p.m_tiles;
-        t.x0 = (id % p.tiles_x) * kWTW;
+        t.x0 = (id % p.tiles_x) * TW;
         id /= p.tiles_x;
-        t.y0 = (id % p.tiles_y) * kWTH;
+        t.y0 = (id % p.tiles_y) * TH;
         t.b0 = id / p.tiles_y;
         return t;
     };
@@ -195,10 +204,10 @@ __global__ __launch_bounds__(256, 1) void winograd_conv_kernel(const ConvArgs p)
             int i = wave + 4 * (r - kWWlPerWave);
             if (i >= kWPlInstr) i -= kWPlInstr;
             const int f = min(i * 64 + lane, kWPlF4 - 1);  // tail lanes of the last piece repeat its last float4
-            const int q = f % (kWPW / 4);
-            int rr = f / (kWPW / 4);
-            const int py = rr % kWPH;
-            const int c = rr / kWPH;
+            const int q = f % (PW / 4);
+            int rr = f / (PW / 4);
+            const int py = rr % PH;
+            const int c = rr / PH;
             voff_lds[r * 256 + tid] = ((c * Hp + py) * Wp + 4 * q) * 4;
             dma_lds[r] = kWWlFloats + i * 256;
         }
@@ -293,8 +302,9 @@ __global__ __launch_bounds__(256, 1) void winograd_conv_kernel(const ConvArgs p)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[q][r] = 0.f;
 
-    // tile (wave, l31): input window rows 2*wave .. 2*wave+3, columns 2*l31+3 .. 2*l31+6 of the patch
-    const int poff = (2 * wave) * kWPW + 2 * l31 + 3;
+    // a lane's tile (tile row tr, tile column tc): input window rows 2 tr .. 2 tr + 3, columns 2 tc + 3 .. 2 tc + 6
+    const int tr = WIDE ? wave : 2 * wave + (l31 >> 4), tc = WIDE ? l31 : (l31 & 15);
+    const int poff = (2 * tr) * PW + 2 * tc + 3;
     constexpr int KS = kWKC / 2;  // k-steps per chunk
     static_assert(KS % 2 == 0 && KS >= 2, "the pipeline's register parity is per chunk");
     static_assert(kWNBUF >= 2 && (kWNBUF - 1) * kWPiecesPerWave + 7 <= 63, "ring depth vmcnt can express");
@@ -309,7 +319,7 @@ __global__ __launch_bounds__(256, 1) void winograd_conv_kernel(const ConvArgs p)
         // hipcc would spill it to scratch (a scratch reload is a vector-memory operation: it drains the ring)
         int l31 = l31_k, lh = lh_k;
         asm volatile("" : "+v"(l31), "+v"(lh));
-        const int oy = t.y0 + 2 * wave, ox = t.x0 + 2 * l31;
+        const int oy = t.y0 + 2 * (WIDE ? wave : 2 * wave + (l31 >> 4)), ox = t.x0 + 2 * (WIDE ? l31 : (l31 & 15));
         const bool ok = t.b0 < p.B && oy < p.OH && ox < p.OW;
         float nz[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
         if (p.noise != nullptr && ok) {
@@ -463,8 +473,8 @@ __global__ __launch_bounds__(256, 1) void winograd_conv_kernel(const ConvArgs p)
     wait_vmcnt<(kWNBUF - 1) * kWPiecesPerWave>();
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
-    wino_load(buf0 + kWWlFloats, const0, 0, poff, lh, raw[0]);
-    wino_load(buf0 + kWWlFloats, const0, 1, poff, lh, raw[1]);
+    wino_load<PW>(buf0 + kWWlFloats, const0, 0, poff, lh, raw[0]);
+    wino_load<PW>(buf0 + kWWlFloats, const0, 1, poff, lh, raw[1]);
     wino_load_a(buf0, 0, l31, lh, ops[0]);
     wino_transform(raw[0], ops[0]);
 
@@ -511,9 +521,9 @@ __global__ __launch_bounds__(256, 1) void winograd_conv_kernel(const ConvArgs p)
                 // above) have long returned: refill its slot, the DMA issues woven between the MFMAs
                 if (j + 1 == KS && !(p.debug_flags & 10)) stage_next();
                 if (j + 2 < KS)
-                    wino_load(Uc + kWWlFloats, s_c, j + 2, poff, lh, raw[j & 1]);
+                    wino_load<PW>(Uc + kWWlFloats, s_c, j + 2, poff, lh, raw[j & 1]);
                 else
-                    wino_load(Un + kWWlFloats, s_n, j + 2 - KS, poff, lh, raw[j & 1]);
+                    wino_load<PW>(Un + kWWlFloats, s_n, j + 2 - KS, poff, lh, raw[j & 1]);
                 if (j + 1 < KS)
                     wino_load_a(Uc, j + 1, l31, lh, ops[(j + 1) & 1]);
                 else
@@ -541,7 +551,7 @@ __global__ __launch_bounds__(256, 1) void winograd_conv_kernel(const ConvArgs p)
 #pragma unroll
         for (int j = 0; j < KS; ++j) {
             __builtin_amdgcn_sched_barrier(0);
-            if (j + 2 < KS) wino_load(Uc + kWWlFloats, s_c, j + 2, poff, lh, raw[j & 1]);
+            if (j + 2 < KS) wino_load<PW>(Uc + kWWlFloats, s_c, j + 2, poff, lh, raw[j & 1]);
             if (j + 1 < KS) {
                 wino_load_a(Uc, j + 1, l31, lh, ops[(j + 1) & 1]);
                 wino_transform(raw[(j + 1) & 1], ops[(j + 1) & 1]);
@@ -577,12 +587,13 @@ void winograd_transform_weights(const float* w_in, int cin, int cout, float* w_o
 }
 
 bool winograd_supported(int cin, int cout, int H, int W) {
-    return cin % kWKC == 0 && cin <= 512 && cout % kWBM == 0 && H % kWTH == 0 && W % kWTW == 0 && cin / kWKC >= kWNBUF;
+    const bool wide = H % kWTH == 0 && W % kWTW == 0, narrow = H % kWTHn == 0 && W % kWTWn == 0;
+    return cin % kWKC == 0 && cin <= 512 && cout % kWBM == 0 && (wide || narrow) && cin / kWKC >= kWNBUF;
 }
 
-template <bool RGB>
+template <bool RGB, bool WIDE>
 static hipError_t launch_winograd(const ConvArgs& args, hipStream_t stream) {
-    auto kernel = winograd_conv_kernel<RGB>;
+    auto kernel = winograd_conv_kernel<RGB, WIDE>;
     static int resident_blocks = 0;  // one block per CU (512 registers per wave), a multiple of 8 (XCDs)
     if (resident_blocks == 0) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -594,8 +605,8 @@ static hipError_t launch_winograd(const ConvArgs& args, hipStream_t stream) {
         resident_blocks = std::max(8, cus / 8 * 8);
     }
     ConvArgs a = args;
-    a.tiles_x = a.W / kWTW;
-    a.tiles_y = a.H / kWTH;
+    a.tiles_x = a.W / (WIDE ? kWTW : kWTWn);
+    a.tiles_y = a.H / (WIDE ? kWTH : kWTHn);
     a.m_tiles = a.Cout / kWBM;
     a.total_chunks = a.Cin / kWKC;
     a.total_tiles = a.m_tiles * a.tiles_x * a.tiles_y * a.B;
@@ -606,8 +617,9 @@ static hipError_t launch_winograd(const ConvArgs& args, hipStream_t stream) {
 
 hipError_t launch_winograd_conv(const ConvArgs& args, hipStream_t stream) {
     // kEpilogueRgb: the fused last layer (Cout = 32 = one block's channels)
-    if (args.epilogue == kEpilogueRgb) return args.Cout == kWBM ? launch_winograd<true>(args, stream) : hipErrorInvalidValue;
-    return launch_winograd<false>(args, stream);
+    const bool wide = args.H % kWTH == 0 && args.W % kWTW == 0;
+    if (args.epilogue == kEpilogueRgb) return args.Cout == kWBM && wide ? launch_winograd<true, true>(args, stream) : hipErrorInvalidValue;
+    return wide ? launch_winograd<false, true>(args, stream) : launch_winograd<false, false>(args, stream);
 }
 
 }  // namespace gance

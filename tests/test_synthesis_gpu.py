@@ -47,7 +47,7 @@ def library():
 
 
 @pytest.mark.parametrize(
-    "resolution,batch,conv_form", [(8, 1, "auto"), (32, 3, "auto"), (64, 9, "direct"), (64, 9, "winograd"), (128, 3, "winograd")]
+    "resolution,batch,conv_form", [(8, 1, "auto"), (32, 3, "auto"), (32, 5, "winograd"), (64, 9, "direct"), (64, 9, "winograd"), (128, 3, "winograd")]
 )
 def test_layerwise_activations_match_oracle(library, resolution: int, batch: int, conv_form: str) -> None:
     """
