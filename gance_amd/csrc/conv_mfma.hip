@@ -22,9 +22,13 @@
 // can be copied by LDS-DMA, AND every 32-pixel output segment is one aligned 128-B line. Weights are pre-arranged per (m tile, K chunk) as the exact LDS image
 // [tap][KC][BM], so their staging is a linear copy.
 //
-// Pipeline: a ring of 3 LDS buffers; `buffer_load_dwordx4 ... lds` of chunks k+1 and k+2 are in
-// flight while the MFMAs of chunk k run; per chunk one counted `s_waitcnt vmcnt(N)` + one raw
-// s_barrier. All LDS is one dynamic array; no ordinary global load sits inside the K loop.
+// Pipeline: two LDS buffers (a third, with counted `s_waitcnt vmcnt(N)`, is a template parameter that
+// measured slower: it costs a resident block per CU); the `buffer_load_dwordx4 ... lds` of chunk k+1
+// is in flight while the MFMAs of chunk k run; per chunk one `s_waitcnt vmcnt` + one raw s_barrier.
+// All LDS is one dynamic array; no ordinary global load sits inside the K loop.
+//
+// The stride-1 layers at >= 32x32 normally run in Winograd form instead (winograd_conv.hip); this
+// kernel keeps the small layers, every transposed conv, and the last layer fused with its ToRGB.
 
 #include <hip/hip_runtime.h>
 
