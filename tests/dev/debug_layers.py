@@ -11,7 +11,7 @@ from pathlib import Path
 import numpy as np
 import torch
 
-sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent.parent))
 
 from gance_amd import hip_lib  # noqa: E402
 from gance_amd.stylegan2 import spec as sg2_spec  # noqa: E402
