@@ -34,7 +34,7 @@ from gance_amd.vector_sources.vector_types import SingleMatrix, SingleVector, is
 
 NETWORK_SUFFIX = ".pkl"  # network_functions.py:38
 TRUNCATION_PSI = 1.2  # network_functions.py:124,155
-DEFAULT_MAX_BATCH = 16  # frames per engine call of the batched entry points (about 1.3 GB of workspace per frame at 1024^2)
+DEFAULT_MAX_BATCH = 16  # frames per engine call of the batched entry points (about 0.8 GB of workspace per frame at 1024^2)
 DEFAULT_DEVICE = 0
 
 
