@@ -206,6 +206,8 @@ struct gance_engine {
     size_t avg_off = 0, const_off = 0, A_off = 0, bias1_off = 0, w2_off = 0;
     std::vector<size_t> conv_w, conv_bias, conv_noise;
     std::vector<size_t> wino_w;  // Winograd-domain weights of the stride-1 layers that support them (else SIZE_MAX)
+    std::vector<size_t> upfir_w;  // fused transposed-conv + FIR kernel's weight image of the up layers that support it (else SIZE_MAX)
+    int num_cus = 256;
     std::vector<float> conv_ns;
     std::vector<int> conv_s_off, conv_d_off;
     std::vector<size_t> rgb_w, rgb_bias;
@@ -481,6 +483,48 @@ int synthesize_from_dlat(gance_engine* e, const float* d_dlat, int B, uint8_t* d
             }
         } else {
             const int H = res / 2, W = res / 2;
+            // the fused kernel (transposed conv + FIR in one launch) where it is supported and fills the chip;
+            // GANCE_TUNE_UPFIR = 0 / 1 / 2 overrides the engine flags (never / auto / always)
+            static const int upfir_env = [] { const char* v = std::getenv("GANCE_TUNE_UPFIR"); return v ? std::atoi(v) : -1; }();
+            const int upfir_mode = upfir_env >= 0 ? upfir_env
+                                                  : ((e->cfg.flags & GANCE_FLAG_SPLIT_UPFIR) ? 0 : ((e->cfg.flags & GANCE_FLAG_FORCE_FUSED_UPFIR) ? 2 : 1));
+            if (upfir_mode != 0 && e->upfir_w[li] != SIZE_MAX) {
+                gance::UpFirArgs u{};
+                u.Cin = c.cin;
+                gance::upfir_plan(B, c.cout, H, W, e->num_cus, &u);
+                const int steps_per_seg = u.rows_per_seg / 8;
+                if (upfir_mode == 2 || (u.total_blocks >= e->num_cus * 3 / 4 && (u.segs == 1 || steps_per_seg >= 4))) {
+                    u.x = x_in;
+                    u.w = e->pool + e->upfir_w[li];
+                    u.s = e->styles + e->conv_s_off[li];
+                    u.d = e->demod + e->conv_d_off[li];
+                    u.noise = noise;
+                    u.bias = bias;
+                    u.out = x_out;
+                    u.B = B;
+                    u.Cin = c.cin;
+                    u.Cout = c.cout;
+                    u.H = H;
+                    u.W = W;
+                    u.s_stride = e->ctot;
+                    u.d_stride = e->dtot;
+                    u.noise_strength = e->conv_ns[li];
+                    u.x_b_stride = x_b_stride;
+                    std::snprintf(name, sizeof(name), "convTF%d_%dx%d_%d->%d", c.layer_idx, res, res, c.cin, c.cout);
+                    {
+                        const double flops = 2.0 * 9 * (double)c.cin * c.cout * H * W * B;
+                        const double bytes = 4.0 * ((double)B * c.cin * H * W + (double)B * c.cout * res * res + 9.0 * c.cin * c.cout);
+                        StepScope scope(e, stream, name, flops, bytes);
+                        GANCE_HIP_CHECK(gance::launch_upfir_fused(u, stream));
+                    }
+                    x_in = x_out;
+                    x_b_stride = out_b;
+                    e->last_act_layer = li;
+                    e->last_act_c = c.cout;
+                    e->last_act_side = res;
+                    continue;
+                }
+            }
             const long long tc = (long long)t_plane(H);
             const long long unit = tc * c.cout;
             const long long cls_stride = unit * e->t_units[li];
@@ -594,9 +638,12 @@ int gance_engine_create(const gance_engine_config* config, const float* host_wei
     if (config->device < 0 || config->device >= device_count)
         return fail(GANCE_ERR_INVALID_ARGUMENT, "device ordinal out of range");
     GANCE_HIP_CHECK(hipSetDevice(config->device));
+    int num_cus = 0;
+    GANCE_HIP_CHECK(hipDeviceGetAttribute(&num_cus, hipDeviceAttributeMultiprocessorCount, config->device));
 
     gance_engine* e = new gance_engine();
     e->cfg = *config;
+    e->num_cus = num_cus > 0 ? num_cus : 256;
     e->res_log2 = res_log2;
     e->num_rows = res_log2 * 2 - 2;
     build_spec(res_log2, &e->convs, &e->rgbs);
@@ -694,6 +741,13 @@ int gance_engine_create(const gance_engine_config* config, const float* host_wei
             for (size_t j = 0; j < wn; ++j) scaled[j] = src[j] * coef;
             e->wino_w[i] = reserve(gance::winograd_weight_floats(c.cin, c.cout));
             gance::winograd_transform_weights(scaled.data(), c.cin, c.cout, &pool[e->wino_w[i]]);
+        }
+        e->upfir_w.push_back(SIZE_MAX);
+        if (c.up && gance::upfir_supported(c.cin, c.cout, (1 << c.res_log2) / 2, (1 << c.res_log2) / 2)) {
+            std::vector<float> scaled(wn);
+            for (size_t j = 0; j < wn; ++j) scaled[j] = src[j] * coef;
+            e->upfir_w[i] = reserve(gance::upfir_weight_floats(c.cin, c.cout));
+            gance::upfir_arrange_weights(scaled.data(), c.cin, c.cout, kUpTapWeight, &pool[e->upfir_w[i]]);
         }
         src += wn;
         demod_layers[i] = {(long long)w2_cursor, e->conv_s_off[i], e->conv_d_off[i], c.cin, c.cout};

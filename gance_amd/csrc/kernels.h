@@ -75,6 +75,30 @@ size_t winograd_weight_floats(int cin, int cout);
 void winograd_transform_weights(const float* w_in /*[9][cin][cout]*/, int cin, int cout, float* w_out);
 hipError_t launch_winograd_conv(const ConvArgs& args, hipStream_t stream);
 
+// Conv0_up as ONE kernel (upfir_fused.hip): transposed conv on the matrix cores + [1,3,3,1]^2 FIR + noise +
+// bias + leaky ReLU, for inputs >= 64 wide. Blocks sweep 64-column strips in steps of 8 position rows.
+struct UpFirArgs {
+    const float* x;      // zero-bordered [B][Cin][H+2][W+8]
+    const float* w;      // [m tile of 32][chunk of 4][tap slot 0..8][4][32], runtime-scaled
+    const float* s;      // style: s[b * s_stride + ci]
+    const float* d;      // demodulation: d[b * d_stride + co]
+    const float* noise;  // [2H][2W] or nullptr
+    const float* bias;   // [Cout]
+    float* out;          // zero-bordered [B][Cout][2H+2][2W+8]
+    int B, Cin, Cout, H, W;
+    int s_stride, d_stride;
+    float noise_strength;
+    int m_tiles, strips, segs, rows_per_seg, total_blocks;  // set by upfir_plan
+    int stagger_phases, stagger_ticks;                       // set by upfir_plan: start delay (phase * ticks of 10 ns)
+    int debug_flags;  // timing ablations (GANCE_DEBUG_UPFIR): 1 no stores, 2 no epilogue at all, 4 no MFMA, 8 no DMA after the first chunk
+    long long x_b_stride;
+};
+bool upfir_supported(int cin, int cout, int H, int W);
+size_t upfir_weight_floats(int cin, int cout);
+void upfir_arrange_weights(const float* w_in /*[9][cin][cout] scaled*/, int cin, int cout, const int* up_tap_weight, float* w_out);
+void upfir_plan(int B, int cout, int H, int W, int num_cus, UpFirArgs* args);
+hipError_t launch_upfir_fused(const UpFirArgs& args, hipStream_t stream);
+
 // ---- aux_kernels.hip ----
 
 // Mapping network: one dense 512->512 layer with lrelu*sqrt2 (G_mapping DenseN).

@@ -28,6 +28,8 @@ GANCE_OK = 0
 GANCE_FLAG_PROFILE_STEPS = 1
 GANCE_FLAG_DIRECT_CONV = 2
 GANCE_FLAG_FORCE_WINOGRAD = 4
+GANCE_FLAG_SPLIT_UPFIR = 8
+GANCE_FLAG_FORCE_FUSED_UPFIR = 16
 
 STATUS_NAMES = {
     1: "GANCE_ERR_INVALID_ARGUMENT",
@@ -243,8 +245,12 @@ class Engine:
         device: int = 0,
         profile: bool = False,
         conv_form: str = "auto",
+        up_form: str = "auto",
     ) -> None:
         """
+        :param up_form: Conv0_up layers with an input >= 64 wide: "auto" = one fused kernel (transposed conv +
+        FIR + noise + bias + leaky ReLU) when the launch fills the chip, else two passes; "split" = always two
+        passes; "fused" = the fused kernel whatever the batch.
         :param conv_form: "auto" = Winograd F(2x2,3x3) for the stride-1 convs of the >= 64x64 layers
         when a launch has at least one block per CU, else the direct form; "direct" = never Winograd;
         "winograd" = Winograd on every layer that supports it, whatever the batch.
@@ -254,6 +260,7 @@ class Engine:
         spec = sg2_spec.make_spec(resolution)
         blob = sg2_spec.pack_variables(variables, spec)
         form_flags = {"auto": 0, "direct": GANCE_FLAG_DIRECT_CONV, "winograd": GANCE_FLAG_FORCE_WINOGRAD}[conv_form]
+        form_flags |= {"auto": 0, "split": GANCE_FLAG_SPLIT_UPFIR, "fused": GANCE_FLAG_FORCE_FUSED_UPFIR}[up_form]
         config = EngineConfig(resolution, max_batch, device, (GANCE_FLAG_PROFILE_STEPS if profile else 0) | form_flags)
         _check(
             self._lib,

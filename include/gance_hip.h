@@ -53,6 +53,12 @@ typedef struct gance_engine_config {
  * block-count condition (small batches: slower, used by the parity tests). */
 #define GANCE_FLAG_DIRECT_CONV 2
 #define GANCE_FLAG_FORCE_WINOGRAD 4
+/* Conv0_up of the layers whose input is >= 64 wide runs as ONE kernel (transposed conv + FIR + noise + bias +
+ * leaky ReLU, the (2H+1)^2 intermediate stays on chip) whenever the launch gives every CU a block without
+ * cutting the image into row segments shorter than 4 steps. SPLIT_UPFIR keeps the two-pass form
+ * (transposed conv, then FIR pass); FORCE_FUSED_UPFIR drops the block-count condition (parity tests). */
+#define GANCE_FLAG_SPLIT_UPFIR 8
+#define GANCE_FLAG_FORCE_FUSED_UPFIR 16
 
 /*
  * Load a network. Replaces load_network_network + wrap_loaded_network

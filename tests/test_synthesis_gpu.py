@@ -156,6 +156,82 @@ def test_full_size_properties_batch_of_8(library) -> None:
     assert frames.std() > 10  # not a constant image
 
 
+@pytest.mark.parametrize("resolution,batch", [(128, 3), (256, 2)])
+def test_fused_upsampling_layer_matches_oracle_layerwise(library, resolution: int, batch: int) -> None:
+    """
+    Conv0_up as ONE kernel (upfir_fused.hip: transposed conv + FIR + noise + bias + leaky ReLU), forced
+    at a small batch: the planner then cuts the image into row segments (priming steps), 256^2 has
+    two 64-column strips (recomputed halo columns) and 8 channel tiles; every term is switched on.
+    """
+    spec = sg2_spec.make_spec(resolution)
+    variables = sg2_spec.make_random_variables(resolution, seed=3, perturb=True)
+    dlatents = np.random.RandomState(5).randn(batch, spec.num_layers, 512).astype(np.float32)
+    engine = hip_lib.Engine(variables, resolution, max_batch=batch, up_form="fused")
+    try:
+        for n, conv in enumerate(spec.convs, start=1):
+            if not (conv.up and 2 ** conv.res_log2 >= 128):
+                continue
+            got = engine.debug_activation_after(dlatents, n)
+            with torch.no_grad():
+                want = ref.g_synthesis(torch.from_numpy(dlatents).double(), variables, resolution, stop_after=n).numpy()
+            rel = np.abs(got - want).max() / np.abs(want).max()
+            assert rel < 2e-5, f"conv layer {n} ({conv.scope}): rel err {rel}"
+    finally:
+        engine.close()
+
+
+@pytest.mark.parametrize("up_form", ["fused", "split"])
+def test_matrix_path_512_both_upsampling_forms(library, up_form: str) -> None:
+    """512^2, every term on: the fused up kernel (4 strips at 256 -> 512) and the two-pass form against the oracle."""
+    resolution, batch = 512, 2
+    spec = sg2_spec.make_spec(resolution)
+    variables = sg2_spec.make_random_variables(resolution, seed=4, perturb=True)
+    dlatents = np.random.RandomState(9).randn(batch, spec.num_layers, 512).astype(np.float32)
+    engine = hip_lib.Engine(variables, resolution, max_batch=batch, up_form=up_form)
+    try:
+        frames, image = engine.synthesize_w(dlatents, want_float=True)
+    finally:
+        engine.close()
+    _check_frames(frames, image, ref.synthesize_w(dlatents, variables, resolution))
+
+
+@pytest.mark.parametrize("conv_form,up_form", [("auto", "auto"), ("direct", "split"), ("auto", "fused")])
+def test_config_f_1024_every_term_on_default_kernels(library, conv_form: str, up_form: str) -> None:
+    """
+    1024^2 with non-zero noise strengths and biases through the kernels that ship by default: the last
+    conv in direct form fused with its ToRGB + uint8 (conv_mfma.hip emit_rgb, reached only at Cout = 32 =
+    1024^2), with and without Winograd / the fused up kernel on the layers below.
+    """
+    resolution = 1024
+    variables = sg2_spec.make_random_variables(resolution, seed=0, perturb=True)
+    z = np.random.RandomState(2).randn(1, 512).astype(np.float32)
+    engine = hip_lib.Engine(variables, resolution, max_batch=1, conv_form=conv_form, up_form=up_form)
+    try:
+        frames, image = engine.synthesize_z(z, truncation_psi=1.2, want_float=True)
+    finally:
+        engine.close()
+    _check_frames(frames, image, ref.synthesize_z(z, variables, resolution, truncation_psi=1.2))
+
+
+def test_bench_configuration_batch_32_matches_oracle_and_single_calls(library) -> None:
+    """
+    The configuration bench.py times (1024^2, 32 frames per call, auto kernel selection: Winograd layers,
+    fused up kernels, fused last layer): frames 0 and 31 against the oracle, and against the same z alone.
+    """
+    resolution, batch = 1024, 32
+    variables = sg2_spec.make_random_variables(resolution, seed=0, perturb=True)
+    z = np.random.RandomState(1).randn(batch, 512).astype(np.float32)
+    engine = hip_lib.Engine(variables, resolution, max_batch=batch)
+    try:
+        frames, image = engine.synthesize_z(z, truncation_psi=1.2, want_float=True)
+        alone = [engine.synthesize_z(z[i : i + 1], truncation_psi=1.2) for i in (0, 31)]
+    finally:
+        engine.close()
+    for k, i in enumerate((0, 31)):
+        _check_frames(frames[i : i + 1], image[i : i + 1], ref.synthesize_z(z[i : i + 1], variables, resolution, truncation_psi=1.2))
+        _assert_same_frames(alone[k][0], frames[i])
+
+
 def test_calls_are_validated(library) -> None:
     variables = sg2_spec.make_random_variables(8, seed=0)
     engine = hip_lib.Engine(variables, 8, max_batch=2)
