@@ -4,7 +4,7 @@ audio -> latent -> StyleGAN2 frame synthesis.
 
 The package mirrors the reference's module names for that path only
 (`network_interface`, `vector_sources`, `apply_spectrogram`,
-`data_into_network_visualization`) and sits on a C-ABI HIP library
+`data_into_network_visualization`, `projection`, `overlay`) and sits on a C-ABI HIP library
 (`gance_amd/csrc`, header `include/gance_hip.h`).
 """
 

@@ -410,6 +410,124 @@ __global__ __launch_bounds__(512) void roll_blend_kernel(const BlendArgs a) {
     }
 }
 
+
+// ------------------------------------------------------------------------------------------
+// stand-alone forms of the stages (gance_vec_* entry points): the same arithmetic as above on
+// caller-shaped arrays, for gance_amd/apply_spectrogram.py and gance_amd/vector_sources/*
+// ------------------------------------------------------------------------------------------
+
+// scipy.signal.resample of a real line, n_in -> n_out, as the matrix M[n][j] (y = x M), following the
+// library's own steps: keep min(n_in, n_out)//2 + 1 rfft terms, double (down-sampling) or halve (up-sampling)
+// the term at N/2 when N is even, irfft to n_out points (whose own Nyquist term is real and counted once),
+// scale by n_out / n_in.
+static std::vector<double> fourier_resample_matrix(int n_in, int n_out) {
+    std::vector<double> M((size_t)n_in * n_out);
+    const long double two_pi = 6.283185307179586476925286766559005768L;
+    const int N = n_in < n_out ? n_in : n_out;
+    const int nyq = N / 2 + 1;
+    for (int n = 0; n < n_in; ++n)
+        for (int j = 0; j < n_out; ++j) {
+            long double acc = 1.0L;  // k = 0
+            for (int k = 1; k < nyq; ++k) {
+                // X_k = exp(-2 pi i k n / n_in); the output term is Re(Y_k exp(+2 pi i k j / n_out)), twice unless
+                // k is the irfft's own Nyquist bin
+                long double re = cosl(two_pi * k * n / n_in), im = -sinl(two_pi * k * n / n_in);
+                if (N % 2 == 0 && k == N / 2) {
+                    if (n_out < n_in) { re *= 2.0L; im *= 2.0L; }
+                    else if (n_in < n_out) { re *= 0.5L; im *= 0.5L; }
+                }
+                const long double c = cosl(two_pi * k * j / n_out), sn = sinl(two_pi * k * j / n_out);
+                const bool out_nyquist = (n_out % 2 == 0) && (k == n_out / 2);
+                acc += out_nyquist ? re * c : 2.0L * (re * c - im * sn);
+            }
+            M[(size_t)n * n_out + j] = (double)(acc / n_in);
+        }
+    return M;
+}
+
+__global__ void vec_savgol_kernel(const double* __restrict__ in, int N, int L, int axis, const double* __restrict__ table, int w,
+                                  double* __restrict__ out) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)N * L) return;
+    const int t = (int)(i / L), j = (int)(i % L);
+    if (axis == 0) {
+        auto x = [&](int tt) { return in[(size_t)tt * L + j]; };
+        out[i] = savgol_at(x, t, N, table, w);
+    } else {
+        auto x = [&](int jj) { return in[(size_t)t * L + jj]; };
+        out[i] = savgol_at(x, j, L, table, w);
+    }
+}
+
+__global__ void vec_resample_kernel(const double* __restrict__ in, int N, int Lin, int Lout, const double* __restrict__ M,
+                                    double* __restrict__ out) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)N * Lout) return;
+    const int t = (int)(i / Lout), j = (int)(i % Lout);
+    double acc = 0.0;
+    for (int n = 0; n < Lin; ++n) acc = fma(in[(size_t)t * Lin + n], M[(size_t)n * Lout + j], acc);
+    out[i] = acc;
+}
+
+// 20 log10(|X| / max |X|), written transposed: [bins][N] like the reference's array
+__global__ void vec_db_transpose_kernel(const double* __restrict__ mag, int N, int bins, const unsigned long long* __restrict__ max_key,
+                                        double* __restrict__ out) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)N * bins) return;
+    const int t = (int)(i / bins), k = (int)(i % bins);
+    out[(size_t)k * N + t] = 20.0 * log10(mag[i] / key_value(*max_key));
+}
+
+__global__ void vec_minmax_reduce_kernel(const double* __restrict__ data, size_t count, unsigned long long* keys /*[0] min, [1] max*/) {
+    double lo = INFINITY, hi = -INFINITY;
+    bool bad = false;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (size_t)gridDim.x * blockDim.x) {
+        const double v = data[i];
+        if (!isfinite(v)) bad = true;
+        lo = fmin(lo, v);
+        hi = fmax(hi, v);
+    }
+    if (bad) atomicMin(&keys[0], order_key(-INFINITY));
+    if (lo <= hi) {
+        atomicMin(&keys[0], order_key(lo));
+        atomicMax(&keys[1], order_key(hi));
+    }
+}
+
+// sklearn.preprocessing.minmax_scale on the whole array: X * scale + (lo - min * scale)
+__global__ void vec_minmax_apply_kernel(double* __restrict__ data, size_t count, const unsigned long long* __restrict__ keys,
+                                        double amp_lo, double amp_hi) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    const double dmin = key_value(keys[0]), dmax = key_value(keys[1]);
+    double range = dmax - dmin;
+    if (range == 0.0) range = 1.0;
+    const double scale = (amp_hi - amp_lo) / range;
+    const double offset = amp_lo - dmin * scale;
+    data[i] = __dadd_rn(__dmul_rn(data[i], scale), offset);
+}
+
+// scipy.interpolate.interp1d (linear, two knots): slope * (x - x_lo) + y_lo
+__global__ void vec_remap_kernel(const double* __restrict__ in, size_t count, double x_lo, double x_hi, double y_lo, double y_hi,
+                                 double* __restrict__ out) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    const double slope = __ddiv_rn(__dsub_rn(y_hi, y_lo), __dsub_rn(x_hi, x_lo));
+    out[i] = __dadd_rn(__dmul_rn(slope, __dsub_rn(in[i], x_lo)), y_lo);
+}
+
+// quantize_results_layers on an arbitrary series: remap [min, max] -> [0, K-1], round half to even
+__global__ void vec_quantize_kernel(const double* __restrict__ in, int n, int num_indices, long long* __restrict__ out) {
+    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    double lo = INFINITY, hi = -INFINITY;
+    for (int i = 0; i < n; ++i) {
+        lo = fmin(lo, in[i]);
+        hi = fmax(hi, in[i]);
+    }
+    const double slope = __ddiv_rn((double)(num_indices - 1), __dsub_rn(hi, lo));
+    for (int i = 0; i < n; ++i) out[i] = (long long)rint(__dadd_rn(__dmul_rn(slope, __dsub_rn(in[i], lo)), 0.0));
+}
+
 }  // namespace gance_audio
 
 // ------------------------------------------------------------------------------------------
@@ -483,7 +601,8 @@ int gance_blend_create(const gance_blend_config* config, int32_t device, gance_b
     if (count_err != hipSuccess || device_count < 1)
         return audio_fail(GANCE_ERR_NO_DEVICE, "no HIP device visible; libgance_hip has no CPU path");
     if (device < 0 || device >= device_count) return audio_fail(GANCE_ERR_INVALID_ARGUMENT, "device ordinal out of range");
-    GANCE_AUDIO_CHECK(hipSetDevice(device));
+    gance::DeviceGuard guard(device);
+    GANCE_AUDIO_CHECK(guard.status());
 
     gance_blend* b = new gance_blend();
     b->cfg = c;
@@ -584,7 +703,8 @@ int gance_blend_run(gance_blend* b, const float* d_audio, uint64_t num_samples, 
     const int L = c.vector_length, N = c.num_frames, m = b->m, bins = b->bins;
     if (num_samples < (uint64_t)N * L)
         return audio_fail(GANCE_ERR_INVALID_ARGUMENT, "audio has fewer than num_frames * vector_length samples");
-    GANCE_AUDIO_CHECK(hipSetDevice(b->device));
+    gance::DeviceGuard guard(b->device);
+    GANCE_AUDIO_CHECK(guard.status());
     hipStream_t stream = (hipStream_t)stream_;
     const unsigned long long init_keys[3] = {0ull, ~0ull, 0ull};
     GANCE_AUDIO_CHECK(hipMemcpyAsync(b->keys, init_keys, sizeof(init_keys), hipMemcpyHostToDevice, stream));
@@ -654,7 +774,8 @@ int gance_blend_read_stage(gance_blend* b, int32_t stage, void* h_out, uint64_t 
         case GANCE_STAGE_MINMAX: {
             if (num_bytes != 24) return audio_fail(GANCE_ERR_INVALID_ARGUMENT, "GANCE_STAGE_MINMAX holds 24 bytes");
             unsigned long long keys[3];
-            GANCE_AUDIO_CHECK(hipSetDevice(b->device));
+            gance::DeviceGuard stage_guard(b->device);
+            GANCE_AUDIO_CHECK(stage_guard.status());
             GANCE_AUDIO_CHECK(hipDeviceSynchronize());
             GANCE_AUDIO_CHECK(hipMemcpy(keys, b->keys, sizeof(keys), hipMemcpyDeviceToHost));
             double* out = (double*)h_out;
@@ -670,9 +791,204 @@ int gance_blend_read_stage(gance_blend* b, int32_t stage, void* h_out, uint64_t 
     if (num_bytes != bytes)
         return audio_fail(GANCE_ERR_INVALID_ARGUMENT, "stage holds " + std::to_string(bytes) + " bytes, buffer has " +
                                                           std::to_string(num_bytes));
-    GANCE_AUDIO_CHECK(hipSetDevice(b->device));
+    gance::DeviceGuard guard(b->device);
+    GANCE_AUDIO_CHECK(guard.status());
     GANCE_AUDIO_CHECK(hipDeviceSynchronize());
     GANCE_AUDIO_CHECK(hipMemcpy(h_out, src, bytes, hipMemcpyDeviceToHost));
+    return GANCE_OK;
+}
+
+// ---- stand-alone stages (include/gance_hip.h: gance_vec_*) ----
+
+namespace {
+struct DeviceBuffer {  // freed on every return path
+    void* ptr = nullptr;
+    ~DeviceBuffer() { hipFree(ptr); }
+    hipError_t alloc(size_t bytes) { return hipMalloc(&ptr, bytes ? bytes : 8); }
+};
+int vec_begin(const void* pointer, hipStream_t* stream, void* stream_) {
+    int device_count = 0;
+    if (hipGetDeviceCount(&device_count) != hipSuccess || device_count == 0)
+        return audio_fail(GANCE_ERR_NO_DEVICE, "no HIP device visible; libgance_hip has no CPU path");
+    (void)pointer;
+    *stream = (hipStream_t)stream_;
+    return GANCE_OK;
+}
+}  // namespace
+
+int gance_vec_savgol_f64(const double* d_in, int32_t num_vectors, int32_t vector_length, int32_t axis, int32_t window_length,
+                         int32_t polyorder, double* d_out, void* stream_) {
+    if (d_in == nullptr || d_out == nullptr || d_in == d_out) return audio_fail(GANCE_ERR_INVALID_ARGUMENT, "NULL or aliased argument to gance_vec_savgol_f64");
+    if (num_vectors < 1 || vector_length < 1 || (axis != 0 && axis != 1)) return audio_fail(GANCE_ERR_INVALID_ARGUMENT, "bad shape or axis");
+    const int line = axis == 0 ? num_vectors : vector_length;
+    // scipy.signal.savgol_filter's own argument checks (mode="interp")
+    if (window_length < 1 || window_length % 2 == 0) return audio_fail(GANCE_ERR_INVALID_ARGUMENT, "window_length must be a positive odd integer.");
+    if (polyorder < 0 || polyorder >= window_length) return audio_fail(GANCE_ERR_INVALID_ARGUMENT, "polyorder must be less than window_length.");
+    if (polyorder > 3) return audio_fail(GANCE_ERR_INVALID_ARGUMENT, "polyorder above 3 is not supported");
+    if (window_length > line)
+        return audio_fail(GANCE_ERR_INVALID_ARGUMENT, "If mode is 'interp', window_length must be less than or equal to the size of x.");
+    hipStream_t stream;
+    if (int rc = vec_begin(d_in, &stream, stream_)) return rc;
+    gance::DeviceGuard guard(gance::device_of_pointer(d_in));
+    GANCE_AUDIO_CHECK(guard.status());
+    const std::vector<double> table = gance_audio::savgol_table(window_length, polyorder);
+    DeviceBuffer d_table;
+    GANCE_AUDIO_CHECK(d_table.alloc(table.size() * sizeof(double)));
+    GANCE_AUDIO_CHECK(hipMemcpyAsync(d_table.ptr, table.data(), table.size() * sizeof(double), hipMemcpyHostToDevice, stream));
+    const size_t total = (size_t)num_vectors * vector_length;
+    hipLaunchKernelGGL(gance_audio::vec_savgol_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, d_in, num_vectors,
+                       vector_length, axis, (const double*)d_table.ptr, window_length, d_out);
+    GANCE_AUDIO_CHECK(hipGetLastError());
+    GANCE_AUDIO_CHECK(hipStreamSynchronize(stream));  // the table dies here
+    return GANCE_OK;
+}
+
+int gance_vec_fourier_resample_f64(const double* d_in, int32_t num_vectors, int32_t in_length, int32_t out_length, double* d_out,
+                                   void* stream_) {
+    if (d_in == nullptr || d_out == nullptr || d_in == d_out) return audio_fail(GANCE_ERR_INVALID_ARGUMENT, "NULL or aliased argument to gance_vec_fourier_resample_f64");
+    if (num_vectors < 1 || in_length < 1 || out_length < 1 || in_length > 8192 || out_length > 65536)
+        return audio_fail(GANCE_ERR_INVALID_ARGUMENT, "bad vector count or length");
+    hipStream_t stream;
+    if (int rc = vec_begin(d_in, &stream, stream_)) return rc;
+    gance::DeviceGuard guard(gance::device_of_pointer(d_in));
+    GANCE_AUDIO_CHECK(guard.status());
+    const std::vector<double> M = gance_audio::fourier_resample_matrix(in_length, out_length);
+    DeviceBuffer d_M;
+    GANCE_AUDIO_CHECK(d_M.alloc(M.size() * sizeof(double)));
+    GANCE_AUDIO_CHECK(hipMemcpyAsync(d_M.ptr, M.data(), M.size() * sizeof(double), hipMemcpyHostToDevice, stream));
+    const size_t total = (size_t)num_vectors * out_length;
+    hipLaunchKernelGGL(gance_audio::vec_resample_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, d_in, num_vectors,
+                       in_length, out_length, (const double*)d_M.ptr, d_out);
+    GANCE_AUDIO_CHECK(hipGetLastError());
+    GANCE_AUDIO_CHECK(hipStreamSynchronize(stream));
+    return GANCE_OK;
+}
+
+int gance_debug_fourier_resample_matrix(int32_t in_length, int32_t out_length, double* h_out) {
+    if (h_out == nullptr || in_length < 1 || out_length < 1) return audio_fail(GANCE_ERR_INVALID_ARGUMENT, "bad argument");
+    const std::vector<double> M = gance_audio::fourier_resample_matrix(in_length, out_length);
+    std::memcpy(h_out, M.data(), M.size() * sizeof(double));
+    return GANCE_OK;
+}
+
+int gance_vec_spectrogram_f64(const float* d_audio, uint64_t num_samples, int32_t num_frequency_bins, double* d_out, void* stream_) {
+    if (d_audio == nullptr || d_out == nullptr) return audio_fail(GANCE_ERR_INVALID_ARGUMENT, "NULL argument to gance_vec_spectrogram_f64");
+    const int L = num_frequency_bins, m = L - 2, bins = m / 2;  // apply_spectrogram.py:68 (operator precedence) and :76
+    if (L < 4 || m % 2 != 0 || num_samples < (uint64_t)m) return audio_fail(GANCE_ERR_INVALID_ARGUMENT, "num_frequency_bins must be even and >= 4, with at least one window of samples");
+    const int N = (int)((num_samples - m) / L + 1);  // view_as_windows(window m, step L)
+    hipStream_t stream;
+    if (int rc = vec_begin(d_audio, &stream, stream_)) return rc;
+    gance::DeviceGuard guard(gance::device_of_pointer(d_audio));
+    GANCE_AUDIO_CHECK(guard.status());
+    std::vector<double> tables((size_t)3 * m);
+    const long double two_pi = 6.283185307179586476925286766559005768L;
+    for (int n = 0; n < m; ++n) {
+        tables[n] = (double)(0.5L - 0.5L * cosl(two_pi * n / m));
+        tables[(size_t)m + n] = (double)cosl(two_pi * n / m);
+        tables[(size_t)2 * m + n] = (double)sinl(two_pi * n / m);
+    }
+    DeviceBuffer d_tables, d_mag, d_key;
+    GANCE_AUDIO_CHECK(d_tables.alloc(tables.size() * sizeof(double)));
+    GANCE_AUDIO_CHECK(d_mag.alloc((size_t)N * bins * sizeof(double)));
+    GANCE_AUDIO_CHECK(d_key.alloc(sizeof(unsigned long long)));
+    GANCE_AUDIO_CHECK(hipMemcpyAsync(d_tables.ptr, tables.data(), tables.size() * sizeof(double), hipMemcpyHostToDevice, stream));
+    GANCE_AUDIO_CHECK(hipMemsetAsync(d_key.ptr, 0, sizeof(unsigned long long), stream));
+    hipLaunchKernelGGL(gance_audio::dft_magnitude_kernel, dim3(N), dim3(256), 3 * (size_t)m * sizeof(double), stream, d_audio, L, m,
+                       (const double*)d_tables.ptr, (const double*)d_tables.ptr + m, (double*)d_mag.ptr, (unsigned long long*)d_key.ptr);
+    const size_t total = (size_t)N * bins;
+    hipLaunchKernelGGL(gance_audio::vec_db_transpose_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream,
+                       (const double*)d_mag.ptr, N, bins, (const unsigned long long*)d_key.ptr, d_out);
+    GANCE_AUDIO_CHECK(hipGetLastError());
+    GANCE_AUDIO_CHECK(hipStreamSynchronize(stream));
+    return GANCE_OK;
+}
+
+int gance_vec_minmax_scale_f64(double* d_data, uint64_t count, double lo, double hi, void* stream_) {
+    if (d_data == nullptr || count < 1) return audio_fail(GANCE_ERR_INVALID_ARGUMENT, "NULL or empty argument to gance_vec_minmax_scale_f64");
+    if (!(lo < hi)) return audio_fail(GANCE_ERR_INVALID_ARGUMENT, "Minimum of desired feature range must be smaller than maximum.");
+    hipStream_t stream;
+    if (int rc = vec_begin(d_data, &stream, stream_)) return rc;
+    gance::DeviceGuard guard(gance::device_of_pointer(d_data));
+    GANCE_AUDIO_CHECK(guard.status());
+    DeviceBuffer d_keys;
+    GANCE_AUDIO_CHECK(d_keys.alloc(2 * sizeof(unsigned long long)));
+    const unsigned long long init_keys[2] = {~0ull, 0ull};
+    GANCE_AUDIO_CHECK(hipMemcpyAsync(d_keys.ptr, init_keys, sizeof(init_keys), hipMemcpyHostToDevice, stream));
+    hipLaunchKernelGGL(gance_audio::vec_minmax_reduce_kernel, dim3(256), dim3(256), 0, stream, (const double*)d_data, (size_t)count,
+                       (unsigned long long*)d_keys.ptr);
+    unsigned long long keys[2];
+    GANCE_AUDIO_CHECK(hipMemcpyAsync(keys, d_keys.ptr, sizeof(keys), hipMemcpyDeviceToHost, stream));
+    GANCE_AUDIO_CHECK(hipStreamSynchronize(stream));
+    {   // sklearn raises on non-finite input ("Input contains infinity ..."): a silent window's log10(0) = -inf
+        const unsigned long long k = keys[0];
+        const unsigned long long bits = (k >> 63) ? (k & 0x7fffffffffffffffull) : ~k;
+        double dmin;
+        std::memcpy(&dmin, &bits, 8);
+        if (!std::isfinite(dmin)) return audio_fail(GANCE_ERR_INVALID_ARGUMENT, "Input contains infinity or a value too large for dtype('float64').");
+    }
+    hipLaunchKernelGGL(gance_audio::vec_minmax_apply_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, stream, d_data,
+                       (size_t)count, (const unsigned long long*)d_keys.ptr, lo, hi);
+    GANCE_AUDIO_CHECK(hipGetLastError());
+    GANCE_AUDIO_CHECK(hipStreamSynchronize(stream));
+    return GANCE_OK;
+}
+
+int gance_vec_remap_f64(const double* d_in, uint64_t count, double in_lo, double in_hi, double out_lo, double out_hi, double* d_out,
+                        void* stream_) {
+    if (d_in == nullptr || d_out == nullptr || count < 1) return audio_fail(GANCE_ERR_INVALID_ARGUMENT, "NULL or empty argument to gance_vec_remap_f64");
+    hipStream_t stream;
+    if (int rc = vec_begin(d_in, &stream, stream_)) return rc;
+    gance::DeviceGuard guard(gance::device_of_pointer(d_in));
+    GANCE_AUDIO_CHECK(guard.status());
+    hipLaunchKernelGGL(gance_audio::vec_remap_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, stream, d_in, (size_t)count,
+                       in_lo, in_hi, out_lo, out_hi, d_out);
+    GANCE_AUDIO_CHECK(hipGetLastError());
+    return GANCE_OK;
+}
+
+int gance_vec_rms_rolling_average(const float* d_audio, uint64_t num_samples, int32_t vector_length, int32_t rolling_window,
+                                  int32_t savgol_window_length, int32_t savgol_polyorder, float* d_rms, double* d_rolling,
+                                  double* d_smoothed, int32_t num_values, void* stream_) {
+    if (d_audio == nullptr || d_rms == nullptr || d_rolling == nullptr || d_smoothed == nullptr)
+        return audio_fail(GANCE_ERR_INVALID_ARGUMENT, "NULL argument to gance_vec_rms_rolling_average");
+    const int L = vector_length;
+    if (L < 1 || num_samples < (uint64_t)L) return audio_fail(GANCE_ERR_INVALID_ARGUMENT, "fewer samples than one frame");
+    const int n = (int)(1 + (num_samples - L) / 512);  // librosa's default hop of 512 whatever the frame length
+    if (num_values != n) return audio_fail(GANCE_ERR_INVALID_ARGUMENT, "num_values must be 1 + (num_samples - vector_length) // 512 = " + std::to_string(n));
+    if (rolling_window < 1) return audio_fail(GANCE_ERR_INVALID_ARGUMENT, "rolling window must be >= 1");
+    if (savgol_window_length < 1 || savgol_window_length % 2 == 0) return audio_fail(GANCE_ERR_INVALID_ARGUMENT, "window_length must be a positive odd integer.");
+    if (savgol_polyorder < 0 || savgol_polyorder >= savgol_window_length) return audio_fail(GANCE_ERR_INVALID_ARGUMENT, "polyorder must be less than window_length.");
+    if (savgol_polyorder > 3) return audio_fail(GANCE_ERR_INVALID_ARGUMENT, "polyorder above 3 is not supported");
+    if (savgol_window_length > n)
+        return audio_fail(GANCE_ERR_INVALID_ARGUMENT, "If mode is 'interp', window_length must be less than or equal to the size of x.");
+    hipStream_t stream;
+    if (int rc = vec_begin(d_audio, &stream, stream_)) return rc;
+    gance::DeviceGuard guard(gance::device_of_pointer(d_audio));
+    GANCE_AUDIO_CHECK(guard.status());
+    const std::vector<double> table = gance_audio::savgol_table(savgol_window_length, savgol_polyorder);
+    DeviceBuffer d_table, d_values;
+    GANCE_AUDIO_CHECK(d_table.alloc(table.size() * sizeof(double)));
+    GANCE_AUDIO_CHECK(d_values.alloc((size_t)n * sizeof(int)));
+    GANCE_AUDIO_CHECK(hipMemcpyAsync(d_table.ptr, table.data(), table.size() * sizeof(double), hipMemcpyHostToDevice, stream));
+    hipLaunchKernelGGL(gance_audio::rms_kernel, dim3((n + 63) / 64), dim3(64), 0, stream, d_audio, (size_t)num_samples, L, n, d_rms);
+    gance_audio::ChainArgs chain{d_rms, n, rolling_window, (const double*)d_table.ptr, savgol_window_length, 2, 0,
+                                 d_rolling, d_smoothed, (int*)d_values.ptr, nullptr};
+    gance_audio::ChainArgs none{};
+    hipLaunchKernelGGL(gance_audio::reduce_chain_kernel, dim3(1), dim3(64), 0, stream, chain, none);
+    GANCE_AUDIO_CHECK(hipGetLastError());
+    GANCE_AUDIO_CHECK(hipStreamSynchronize(stream));
+    return GANCE_OK;
+}
+
+int gance_vec_quantize_f64(const double* d_in, int32_t count, int32_t num_indices, int64_t* d_out, void* stream_) {
+    if (d_in == nullptr || d_out == nullptr || count < 1 || num_indices < 1)
+        return audio_fail(GANCE_ERR_INVALID_ARGUMENT, "bad argument to gance_vec_quantize_f64");
+    hipStream_t stream;
+    if (int rc = vec_begin(d_in, &stream, stream_)) return rc;
+    gance::DeviceGuard guard(gance::device_of_pointer(d_in));
+    GANCE_AUDIO_CHECK(guard.status());
+    hipLaunchKernelGGL(gance_audio::vec_quantize_kernel, dim3(1), dim3(64), 0, stream, d_in, count, num_indices, (long long*)d_out);
+    GANCE_AUDIO_CHECK(hipGetLastError());
     return GANCE_OK;
 }
 

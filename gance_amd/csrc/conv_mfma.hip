@@ -734,18 +734,23 @@ template <int BM, int TB, int TH, int TW, int KC, int WM, int WN, bool UP, int N
 static hipError_t launch_one(const ConvArgs& args, int total_blocks, hipStream_t stream) {
     using T = ConvTile<BM, TB, TH, TW, KC, WM, WN, UP, NBUF, RT, PERSIST>;
     auto kernel = modconv_mfma_kernel<BM, TB, TH, TW, KC, WM, WN, UP, NBUF, RT, PERSIST>;
-    static int resident_blocks = 0;  // persistent launch size: what fits the chip at once, a multiple of 8 (XCDs)
-    if (resident_blocks == 0) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           (int)T::lds_bytes(512));
-        if (e != hipSuccess) return e;
-        int device = 0, cus = 0, per_cu = 0;
-        if ((e = hipGetDevice(&device)) != hipSuccess) return e;
-        if ((e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device)) != hipSuccess) return e;
-        if ((e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 256, T::lds_bytes(512))) != hipSuccess) return e;
-        resident_blocks = std::max(8, cus * std::max(per_cu, 1) / 8 * 8);
-    }
+    // per device: the dynamic-LDS opt-in of this kernel variant and the persistent launch size (what fits the
+    // chip at once, a multiple of 8 = XCDs)
+    static PerDeviceInt resident;
+    int resident_blocks = 0;
+    hipError_t e = resident.get(
+        [&](int device, int* value) {
+            hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                 (int)T::lds_bytes(512));
+            if (err != hipSuccess) return err;
+            int cus = 0, per_cu = 0;
+            if ((err = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device)) != hipSuccess) return err;
+            if ((err = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 256, T::lds_bytes(512))) != hipSuccess) return err;
+            *value = std::max(8, cus * std::max(per_cu, 1) / 8 * 8);
+            return hipSuccess;
+        },
+        &resident_blocks);
+    if (e != hipSuccess) return e;
     ConvArgs a = args;
     a.total_tiles = total_blocks;
     int grid = total_blocks;

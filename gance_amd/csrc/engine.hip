@@ -241,6 +241,7 @@ namespace {
 
 void free_engine(gance_engine* e) {
     if (!e) return;
+    gance::DeviceGuard guard(e->cfg.device);
     for (auto& s : e->steps) {
         hipEventDestroy(s.start);
         hipEventDestroy(s.stop);
@@ -637,7 +638,8 @@ int gance_engine_create(const gance_engine_config* config, const float* host_wei
                         "); libgance_hip has no CPU path");
     if (config->device < 0 || config->device >= device_count)
         return fail(GANCE_ERR_INVALID_ARGUMENT, "device ordinal out of range");
-    GANCE_HIP_CHECK(hipSetDevice(config->device));
+    gance::DeviceGuard guard(config->device);  // the caller's current device is restored on return
+    GANCE_HIP_CHECK(guard.status());
     int num_cus = 0;
     GANCE_HIP_CHECK(hipDeviceGetAttribute(&num_cus, hipDeviceAttributeMultiprocessorCount, config->device));
 
@@ -882,7 +884,8 @@ int32_t gance_engine_max_batch(const gance_engine* engine) { return engine ? eng
 int gance_synthesize_w(gance_engine* engine, const float* d_dlatents, int32_t batch,
                        uint8_t* d_out_u8, float* d_out_f32, void* stream) {
     if (int rc = check_call(engine, d_dlatents, batch)) return rc;
-    GANCE_HIP_CHECK(hipSetDevice(engine->cfg.device));
+    gance::DeviceGuard guard(engine->cfg.device);
+    GANCE_HIP_CHECK(guard.status());
     // filtered profiling keeps its records across calls (bench.py averages them); else one call's worth
     if (engine->profile_only.empty() || engine->steps_used >= 4096) engine->steps_used = 0;
     return synthesize_from_dlat(engine, d_dlatents, batch, d_out_u8, d_out_f32, (hipStream_t)stream);
@@ -891,7 +894,8 @@ int gance_synthesize_w(gance_engine* engine, const float* d_dlatents, int32_t ba
 int gance_synthesize_z(gance_engine* engine, const float* d_z, int32_t batch, float truncation_psi,
                        uint8_t* d_out_u8, float* d_out_f32, void* stream_) {
     if (int rc = check_call(engine, d_z, batch)) return rc;
-    GANCE_HIP_CHECK(hipSetDevice(engine->cfg.device));
+    gance::DeviceGuard guard(engine->cfg.device);
+    GANCE_HIP_CHECK(guard.status());
     hipStream_t stream = (hipStream_t)stream_;
     // filtered profiling keeps its records across calls (bench.py averages them); else one call's worth
     if (engine->profile_only.empty() || engine->steps_used >= 4096) engine->steps_used = 0;
@@ -917,7 +921,8 @@ int gance_synthesize_z(gance_engine* engine, const float* d_z, int32_t batch, fl
 static int host_call(gance_engine* e, const float* h_in, size_t in_floats, int batch, bool is_z,
                      float psi, uint8_t* h_u8, float* h_f32) {
     if (int rc = check_call(e, h_in, batch)) return rc;
-    GANCE_HIP_CHECK(hipSetDevice(e->cfg.device));
+    gance::DeviceGuard guard(e->cfg.device);
+    GANCE_HIP_CHECK(guard.status());
     const size_t px = (size_t)e->cfg.resolution * e->cfg.resolution * 3;
     float* d_in = is_z ? e->z_in : e->dlat;
     GANCE_HIP_CHECK(hipMemcpy(d_in, h_in, in_floats * sizeof(float), hipMemcpyHostToDevice));
@@ -988,6 +993,8 @@ int gance_engine_debug_read_activation(gance_engine* engine, int32_t batch, floa
                                        int32_t* out_side) {
     if (engine == nullptr || h_out == nullptr)
         return fail(GANCE_ERR_INVALID_ARGUMENT, "NULL argument");
+    gance::DeviceGuard guard(engine->cfg.device);
+    GANCE_HIP_CHECK(guard.status());
     const int C = engine->last_act_c, R = engine->last_act_side;
     const size_t n = (size_t)batch * C * R * R;
     if (n == 0 || n > max_floats) return fail(GANCE_ERR_INVALID_ARGUMENT, "activation does not fit");
@@ -1009,6 +1016,8 @@ int gance_resize_bicubic_u8(const uint8_t* d_in, int32_t batch, int32_t src_side
                             int32_t dst_side, void* stream) {
     if (d_in == nullptr || d_out == nullptr || batch < 1 || src_side < 1 || dst_side < 1)
         return fail(GANCE_ERR_INVALID_ARGUMENT, "bad argument to gance_resize_bicubic_u8");
+    gance::DeviceGuard guard(gance::device_of_pointer(d_in));  // launch where the frames live
+    GANCE_HIP_CHECK(guard.status());
     GANCE_HIP_CHECK(gance::launch_resize_bicubic_u8(d_in, batch, src_side, d_out, dst_side, (hipStream_t)stream));
     return GANCE_OK;
 }

@@ -6,9 +6,67 @@
 #include <stddef.h>
 #include <stdint.h>
 
+#include <mutex>
 #include <string>
 
 namespace gance {
+
+// Entry points run on the device their engine / buffers live on and hand the caller's current device back
+// (a torch process may have another one current).
+class DeviceGuard {
+  public:
+    explicit DeviceGuard(int device) {
+        if (hipGetDevice(&previous_) != hipSuccess) previous_ = -1;
+        status_ = (device >= 0 && device != previous_) ? hipSetDevice(device) : hipSuccess;
+        switched_ = status_ == hipSuccess && device >= 0 && device != previous_;
+    }
+    ~DeviceGuard() {
+        if (switched_ && previous_ >= 0) (void)hipSetDevice(previous_);
+    }
+    DeviceGuard(const DeviceGuard&) = delete;
+    DeviceGuard& operator=(const DeviceGuard&) = delete;
+    hipError_t status() const { return status_; }
+
+  private:
+    int previous_ = -1;
+    bool switched_ = false;
+    hipError_t status_ = hipSuccess;
+};
+
+// device ordinal a device pointer belongs to (-1 if it cannot be told)
+inline int device_of_pointer(const void* ptr) {
+    hipPointerAttribute_t attr;
+    if (ptr == nullptr || hipPointerGetAttributes(&attr, ptr) != hipSuccess) {
+        (void)hipGetLastError();
+        return -1;
+    }
+    return attr.device;
+}
+
+// One lazily computed int per device (kernel attributes such as the dynamic-LDS opt-in are per device):
+// `init(device, &value)` runs once per device, under a lock.
+constexpr int kMaxDevices = 64;
+struct PerDeviceInt {
+    std::mutex mutex;
+    bool ready[kMaxDevices] = {};
+    int value[kMaxDevices] = {};
+    template <typename Init>
+    hipError_t get(Init init, int* out) {
+        int device = 0;
+        hipError_t e = hipGetDevice(&device);
+        if (e != hipSuccess) return e;
+        if (device < 0 || device >= kMaxDevices) return hipErrorInvalidDevice;
+        std::lock_guard<std::mutex> lock(mutex);
+        if (!ready[device]) {
+            int v = 0;
+            if ((e = init(device, &v)) != hipSuccess) return e;
+            value[device] = v;
+            ready[device] = true;
+        }
+        *out = value[device];
+        return hipSuccess;
+    }
+};
 
 // records the message gance_last_error() returns (thread local) and hands `code` back
 int set_last_error(int code, const std::string& message);

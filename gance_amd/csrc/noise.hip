@@ -163,6 +163,8 @@ extern "C" int gance_gaussian_noise(const float* d_randn, int32_t num_vectors, i
     if (hipGetDeviceCount(&device_count) != hipSuccess || device_count == 0)
         return fail(GANCE_ERR_NO_DEVICE, "no HIP device visible; libgance_hip has no CPU path");
 
+    gance::DeviceGuard guard(gance::device_of_pointer(d_randn));  // launch where the draws live
+    if (guard.status() != hipSuccess) return fail(GANCE_ERR_HIP, std::string("hipSetDevice: ") + hipGetErrorString(guard.status()));
     hipStream_t stream = (hipStream_t)stream_ptr;
     const long long total = (long long)num_vectors * vector_length;
     int radius_across = 0, radius_within = 0;

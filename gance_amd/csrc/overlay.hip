@@ -231,6 +231,8 @@ int gance_phash_crops_u8(const uint8_t* d_frames, int32_t num_frames, int32_t si
     int device_count = 0;
     if (hipGetDeviceCount(&device_count) != hipSuccess || device_count == 0)
         return fail(GANCE_ERR_NO_DEVICE, "no HIP device visible; libgance_hip has no CPU path");
+    gance::DeviceGuard guard(gance::device_of_pointer(d_frames));  // launch where the frames live
+    if (guard.status() != hipSuccess) return fail(GANCE_ERR_HIP, std::string("hipSetDevice: ") + hipGetErrorString(guard.status()));
     // PIL: ksize = ceil(support) * 2 + 1 with support = 3 * max(scale, 1)
     const int max_in = std::max(max_w, max_h);
     const double filterscale = std::max(1.0, (double)max_in / kHashSide);
@@ -267,6 +269,8 @@ int gance_overlay_boxes_u8(const uint8_t* d_foreground, const uint8_t* d_backgro
     int device_count = 0;
     if (hipGetDeviceCount(&device_count) != hipSuccess || device_count == 0)
         return fail(GANCE_ERR_NO_DEVICE, "no HIP device visible; libgance_hip has no CPU path");
+    gance::DeviceGuard guard(gance::device_of_pointer(d_out));  // launch where the frames live
+    if (guard.status() != hipSuccess) return fail(GANCE_ERR_HIP, std::string("hipSetDevice: ") + hipGetErrorString(guard.status()));
     // the mask rectangle of overlay_common._draw_mask (:104-137): pads scale with the frame,
     // PIL truncates the float corners toward zero and draws the polygon's edges
     std::vector<int> rects((size_t)std::max(num_boxes, 1) * 5);

@@ -28,6 +28,9 @@ constexpr double kPi = 3.14159265358979323846;
 
 __global__ void resample_kernel(const float* __restrict__ in, long long num_in, float* __restrict__ out, long long num_out,
                                 double ratio, double scale, int half_width, double inv_i0_beta) {
+    // resampy's published design (`sinc_window` + `resample_f`): with x = (position - index) * min(1, ratio),
+    // weight = rolloff * sinc(rolloff * x) * kaiser(x / zero_crossings) * min(1, ratio) for |x| < zero_crossings:
+    // the roll-off narrows the sinc only, the Kaiser taper spans the un-scaled 64 crossings
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= num_out) return;
     const double position = (double)i / ratio;
@@ -39,10 +42,10 @@ __global__ void resample_kernel(const float* __restrict__ in, long long num_in, 
         const double offset = (position - (double)index) * scale;
         const double window_arg = offset / kZeroCrossings;
         if (fabs(window_arg) >= 1.0) continue;
-        const double px = kPi * offset;
+        const double px = kPi * kRolloff * offset;
         const double sinc = offset == 0.0 ? 1.0 : sin(px) / px;
         const double kaiser = cyl_bessel_i0(kKaiserBeta * sqrt(fmax(1.0 - window_arg * window_arg, 0.0))) * inv_i0_beta;
-        acc += (double)in[index] * (sinc * kaiser * scale);
+        acc += (double)in[index] * (sinc * kaiser * (kRolloff * scale));
     }
     out[i] = (float)acc;
 }
@@ -66,8 +69,10 @@ extern "C" int gance_resample_audio_f32(const float* d_in, uint64_t num_in, doub
     int device_count = 0;
     if (hipGetDeviceCount(&device_count) != hipSuccess || device_count == 0)
         return fail(GANCE_ERR_NO_DEVICE, "no HIP device visible; libgance_hip has no CPU path");
+    gance::DeviceGuard guard(gance::device_of_pointer(d_in));  // launch where the samples live
+    if (guard.status() != hipSuccess) return fail(GANCE_ERR_HIP, std::string("hipSetDevice: ") + hipGetErrorString(guard.status()));
     hipStream_t stream = (hipStream_t)stream_ptr;
-    const double scale = (ratio < 1.0 ? ratio : 1.0) * kRolloff;  // cut-off relative to the lower Nyquist
+    const double scale = ratio < 1.0 ? ratio : 1.0;  // the filter is stretched to the lower of the two Nyquist rates
     const int half_width = (int)std::ceil(kZeroCrossings / scale);
     // I0(beta) from the same device routine as the taps, so the window is exactly 1 at its centre
     double* d_norm = nullptr;

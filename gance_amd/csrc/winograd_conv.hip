@@ -594,16 +594,21 @@ bool winograd_supported(int cin, int cout, int H, int W) {
 template <bool RGB, bool WIDE>
 static hipError_t launch_winograd(const ConvArgs& args, hipStream_t stream) {
     auto kernel = winograd_conv_kernel<RGB, WIDE>;
-    static int resident_blocks = 0;  // one block per CU (512 registers per wave), a multiple of 8 (XCDs)
-    if (resident_blocks == 0) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           (int)winograd_lds_bytes());
-        if (e != hipSuccess) return e;
-        int device = 0, cus = 0;
-        if ((e = hipGetDevice(&device)) != hipSuccess) return e;
-        if ((e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device)) != hipSuccess) return e;
-        resident_blocks = std::max(8, cus / 8 * 8);
-    }
+    // per device: the dynamic-LDS opt-in and the launch size = one block per CU (512 registers per wave), a multiple of 8 (XCDs)
+    static PerDeviceInt resident;
+    int resident_blocks = 0;
+    hipError_t e = resident.get(
+        [&](int device, int* value) {
+            hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                 (int)winograd_lds_bytes());
+            if (err != hipSuccess) return err;
+            int cus = 0;
+            if ((err = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device)) != hipSuccess) return err;
+            *value = std::max(8, cus / 8 * 8);
+            return hipSuccess;
+        },
+        &resident_blocks);
+    if (e != hipSuccess) return e;
     ConvArgs a = args;
     a.tiles_x = a.W / (WIDE ? kWTW : kWTWn);
     a.tiles_y = a.H / (WIDE ? kWTH : kWTHn);

@@ -153,6 +153,26 @@ SIGNATURES = {
         ],
     ),
     "gance_blend_read_stage": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p, ctypes.c_uint64]),
+    "gance_vec_savgol_f64": (
+        ctypes.c_int,
+        [ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p],
+    ),
+    "gance_vec_fourier_resample_f64": (
+        ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p]
+    ),
+    "gance_vec_spectrogram_f64": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p]),
+    "gance_vec_minmax_scale_f64": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_double, ctypes.c_double, ctypes.c_void_p]),
+    "gance_vec_remap_f64": (
+        ctypes.c_int,
+        [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_void_p, ctypes.c_void_p],
+    ),
+    "gance_vec_rms_rolling_average": (
+        ctypes.c_int,
+        [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p,
+         ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p],
+    ),
+    "gance_vec_quantize_f64": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p]),
+    "gance_debug_fourier_resample_matrix": (ctypes.c_int, [ctypes.c_int32, ctypes.c_int32, ctypes.POINTER(ctypes.c_double)]),
     "gance_resize_bicubic_u8": (
         ctypes.c_int,
         [ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p],
@@ -280,8 +300,23 @@ class Engine:
     def close(self) -> None:
         """Free the engine's HBM. Idempotent."""
         if self._handle:
+            if getattr(self, "_op_handle", None) is not None:
+                from gance_amd import torch_ops  # pylint: disable=import-outside-toplevel
+
+                torch_ops.unregister(self._op_handle)
+                self._op_handle = None
             self._lib.gance_engine_destroy(self._handle)
             self._handle = ctypes.c_void_p()
+
+    @property
+    def op_handle(self) -> int:
+        """Integer handle of this engine for the `torch.ops.gance.*` custom ops (gance_amd/torch_ops.py)."""
+        self._require_open()
+        if getattr(self, "_op_handle", None) is None:
+            from gance_amd import torch_ops  # pylint: disable=import-outside-toplevel
+
+            self._op_handle = torch_ops.register_engine(self)
+        return self._op_handle
 
     def __del__(self) -> None:
         try:
@@ -613,3 +648,130 @@ def resample_audio_device(d_in: int, num_in: int, sr_orig: float, sr_new: float,
     """Band-limited resampling of a mono float32 signal in HBM (raw device pointers); num_out = int(num_in * sr_new / sr_orig)."""
     lib = load_library()
     _check(lib, lib.gance_resample_audio_f32(d_in, num_in, float(sr_orig), float(sr_new), d_out, num_out, stream or None))
+
+
+# ---- stand-alone stages of the audio -> latent chain (gance_vec_*): numpy in, numpy out ------------
+# The arrays involved are a few MB; every call uploads, runs one stage on the GPU and downloads. The
+# fused pipeline (`Blend`) is what the hot path uses; these exist so that a caller of the reference's
+# stand-alone functions finds each of them (gance_amd/apply_spectrogram.py, gance_amd/vector_sources/*).
+
+
+def _value_error_on_invalid_argument(lib: ctypes.CDLL, status: int) -> None:
+    """The argument checks restate scipy / sklearn ValueErrors; everything else stays a GanceHipError."""
+    if status == 1:
+        raise ValueError(lib.gance_last_error().decode("utf-8", "replace"))
+    _check(lib, status)
+
+
+def _cuda(device: int) -> "torch.device":
+    if not torch.cuda.is_available():
+        raise RuntimeError("gance_amd needs an MI355X: there is no CPU fallback for the audio stages")
+    return torch.device("cuda", device)
+
+
+def vec_savgol(data: np.ndarray, axis: int, window_length: int, polyorder: int, device: int = 0) -> np.ndarray:
+    """scipy.signal.savgol_filter (mode "interp") along `axis` of a 2-D float64 array, on the GPU."""
+    lib = load_library()
+    host = np.ascontiguousarray(data, dtype=np.float64)
+    d_in = torch.from_numpy(host).to(_cuda(device))
+    d_out = torch.empty_like(d_in)
+    stream = torch.cuda.current_stream(d_in.device).cuda_stream
+    _value_error_on_invalid_argument(
+        lib,
+        lib.gance_vec_savgol_f64(d_in.data_ptr(), host.shape[0], host.shape[1], axis, int(window_length), int(polyorder), d_out.data_ptr(), stream or None),
+    )
+    return d_out.cpu().numpy()
+
+
+def vec_fourier_resample(data: np.ndarray, out_length: int, device: int = 0) -> np.ndarray:
+    """scipy.signal.resample of every row of a 2-D float64 array to `out_length` points, on the GPU."""
+    lib = load_library()
+    host = np.ascontiguousarray(data, dtype=np.float64)
+    d_in = torch.from_numpy(host).to(_cuda(device))
+    d_out = torch.empty((host.shape[0], int(out_length)), dtype=torch.float64, device=d_in.device)
+    stream = torch.cuda.current_stream(d_in.device).cuda_stream
+    _value_error_on_invalid_argument(
+        lib, lib.gance_vec_fourier_resample_f64(d_in.data_ptr(), host.shape[0], host.shape[1], int(out_length), d_out.data_ptr(), stream or None)
+    )
+    return d_out.cpu().numpy()
+
+
+def vec_spectrogram(audio: np.ndarray, num_frequency_bins: int, device: int = 0) -> np.ndarray:
+    """compute_spectrogram: float32 mono samples -> float64 [(bins - 2) // 2][frames] dB magnitudes."""
+    lib = load_library()
+    host = np.ascontiguousarray(audio, dtype=np.float32)
+    window = num_frequency_bins - 2
+    if host.shape[0] < window:
+        raise ValueError("fewer samples than one window")
+    frames = (host.shape[0] - window) // num_frequency_bins + 1
+    d_audio = torch.from_numpy(host).to(_cuda(device))
+    d_out = torch.empty((window // 2, frames), dtype=torch.float64, device=d_audio.device)
+    stream = torch.cuda.current_stream(d_audio.device).cuda_stream
+    _value_error_on_invalid_argument(
+        lib, lib.gance_vec_spectrogram_f64(d_audio.data_ptr(), ctypes.c_uint64(host.shape[0]), int(num_frequency_bins), d_out.data_ptr(), stream or None)
+    )
+    return d_out.cpu().numpy()
+
+
+def vec_minmax_scale(data: np.ndarray, feature_range: Tuple[float, float], device: int = 0) -> np.ndarray:
+    """sklearn.preprocessing.minmax_scale of a whole array (any shape), on the GPU."""
+    lib = load_library()
+    host = np.ascontiguousarray(data, dtype=np.float64)
+    d_data = torch.from_numpy(host).to(_cuda(device))
+    stream = torch.cuda.current_stream(d_data.device).cuda_stream
+    _value_error_on_invalid_argument(
+        lib, lib.gance_vec_minmax_scale_f64(d_data.data_ptr(), ctypes.c_uint64(host.size), float(feature_range[0]), float(feature_range[1]), stream or None)
+    )
+    return d_data.cpu().numpy()
+
+
+def vec_remap(data: np.ndarray, input_range: Tuple[float, float], output_range: Tuple[float, float], device: int = 0) -> np.ndarray:
+    """scipy.interpolate.interp1d(input_range, output_range) applied to every value, on the GPU."""
+    lib = load_library()
+    host = np.ascontiguousarray(data, dtype=np.float64)
+    d_in = torch.from_numpy(host).to(_cuda(device))
+    d_out = torch.empty_like(d_in)
+    stream = torch.cuda.current_stream(d_in.device).cuda_stream
+    _value_error_on_invalid_argument(
+        lib,
+        lib.gance_vec_remap_f64(
+            d_in.data_ptr(), ctypes.c_uint64(host.size), float(input_range[0]), float(input_range[1]), float(output_range[0]),
+            float(output_range[1]), d_out.data_ptr(), stream or None,
+        ),
+    )
+    return d_out.cpu().numpy()
+
+
+def vec_rms_rolling_average(
+    audio: np.ndarray, vector_length: int, rolling_window: int, savgol_window_length: int, savgol_polyorder: int, device: int = 0
+) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
+    """(raw RMS float32, rolling mean float64, Savitzky-Golay smoothed float64), one value per hop of 512 samples."""
+    lib = load_library()
+    host = np.ascontiguousarray(audio, dtype=np.float32)
+    if host.shape[0] < vector_length:
+        raise ValueError("fewer samples than one frame")
+    count = 1 + (host.shape[0] - vector_length) // 512
+    d_audio = torch.from_numpy(host).to(_cuda(device))
+    d_rms = torch.empty((count,), dtype=torch.float32, device=d_audio.device)
+    d_rolling = torch.empty((count,), dtype=torch.float64, device=d_audio.device)
+    d_smoothed = torch.empty((count,), dtype=torch.float64, device=d_audio.device)
+    stream = torch.cuda.current_stream(d_audio.device).cuda_stream
+    _value_error_on_invalid_argument(
+        lib,
+        lib.gance_vec_rms_rolling_average(
+            d_audio.data_ptr(), ctypes.c_uint64(host.shape[0]), int(vector_length), int(rolling_window), int(savgol_window_length),
+            int(savgol_polyorder), d_rms.data_ptr(), d_rolling.data_ptr(), d_smoothed.data_ptr(), count, stream or None,
+        ),
+    )
+    return d_rms.cpu().numpy(), d_rolling.cpu().numpy(), d_smoothed.cpu().numpy()
+
+
+def vec_quantize(data: np.ndarray, num_indices: int, device: int = 0) -> np.ndarray:
+    """Remap [min, max] of a series onto [0, num_indices - 1] and round half to even -> int64."""
+    lib = load_library()
+    host = np.ascontiguousarray(data, dtype=np.float64)
+    d_in = torch.from_numpy(host).to(_cuda(device))
+    d_out = torch.empty((host.size,), dtype=torch.int64, device=d_in.device)
+    stream = torch.cuda.current_stream(d_in.device).cuda_stream
+    _value_error_on_invalid_argument(lib, lib.gance_vec_quantize_f64(d_in.data_ptr(), host.size, int(num_indices), d_out.data_ptr(), stream or None))
+    return d_out.cpu().numpy()

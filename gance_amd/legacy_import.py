@@ -28,7 +28,19 @@ import numpy as np
 
 from gance_amd.stylegan2 import spec as sg2_spec
 
-_ALLOWED_MODULE_PREFIXES = ("numpy", "collections", "builtins", "copyreg", "_codecs")
+# Exact (module, name) pairs a network pickle may reference: numpy array / scalar reconstruction, plain
+# containers and value types. Nothing callable with side effects (`builtins.eval`, `os.system`, ...) resolves.
+_NUMPY_CORE = ("numpy.core.multiarray", "numpy._core.multiarray")
+_ALLOWED_GLOBALS = frozenset(
+    [(module, name) for module in _NUMPY_CORE for name in ("_reconstruct", "scalar")]
+    + [("numpy", "ndarray"), ("numpy", "dtype"), ("numpy.core.numeric", "_frombuffer"), ("numpy._core.numeric", "_frombuffer")]
+    + [("collections", "OrderedDict"), ("_codecs", "encode"), ("copyreg", "_reconstructor"), ("copy_reg", "_reconstructor")]
+    + [
+        (module, name)
+        for module in ("builtins", "__builtin__")
+        for name in ("set", "frozenset", "dict", "list", "tuple", "int", "float", "bool", "str", "bytes", "bytearray", "complex", "object", "slice", "range")
+    ]
+)
 
 
 class LegacyNetworkState:
@@ -58,7 +70,7 @@ class _EasyDict(dict):
 
 
 class _RestrictedUnpickler(pickle.Unpickler):
-    """Resolves only what a Network state needs; never imports or executes pickled code paths."""
+    """Resolves only what a Network state needs (exact allow-list); nothing else a pickle names is imported."""
 
     def find_class(self, module: str, name: str) -> Any:
         if module.split(".")[0] == "dnnlib":
@@ -67,9 +79,19 @@ class _RestrictedUnpickler(pickle.Unpickler):
             if name == "EasyDict":
                 return _EasyDict
             raise pickle.UnpicklingError(f"refusing to load {module}.{name} from a network pickle")
-        if module.split(".")[0] in _ALLOWED_MODULE_PREFIXES:
+        if (module, name) in _ALLOWED_GLOBALS:
             return super().find_class(module, name)
         raise pickle.UnpicklingError(f"refusing to load {module}.{name} from a network pickle")
+
+
+def restricted_load(network_path: Path) -> Any:
+    """
+    Unpickle a network file with the allow-list above: this implementation's own format (a dict of numpy
+    arrays) and legacy (G, D, Gs) pickles both go through it; a payload that names anything else
+    (`builtins.eval`, `os.system`, a reduce into arbitrary modules) raises pickle.UnpicklingError.
+    """
+    with open(str(network_path), "rb") as file:
+        return _RestrictedUnpickler(io.BytesIO(file.read())).load()
 
 
 def _resolution_of(names) -> int:
@@ -101,8 +123,11 @@ def load_legacy_network(network_path: Path):
     `gance_amd.stylegan2.spec.variable_shapes`.
     :raises ValueError: the pickle is not a config-f skip-architecture StyleGAN2 generator.
     """
-    with open(str(network_path), "rb") as file:
-        content = _RestrictedUnpickler(io.BytesIO(file.read())).load()
+    return legacy_network_from_content(restricted_load(network_path))
+
+
+def legacy_network_from_content(content: Any):
+    """`load_legacy_network` on an already (restricted-)unpickled object."""
     if not isinstance(content, (tuple, list)) or len(content) < 3 or not isinstance(content[2], LegacyNetworkState):
         raise ValueError("expected a pickled (G, D, Gs) tuple of dnnlib Networks")
     raw = extract_generator_variables(content[2])

@@ -5,7 +5,7 @@ The reference loads a TF1 StyleGAN2 pickle and takes element [2], `Gs`
 (gance/network_interface/network_functions.py:108-110). Unpickling that needs TensorFlow 1.x and
 the un-vendored dnnlib, neither of which exists here, so this implementation stores a generator as
 a plain pickle of numpy arrays under the SAME TF variable names (gance_amd/stylegan2/spec.py): a
-legacy importer only has to copy arrays by name (not built yet). The file suffix
+legacy importer only has to copy arrays by name (gance_amd/legacy_import.py). The file suffix
 stays `.pkl` so `sorted_networks_in_directory` / `parse_network_paths` behave identically.
 """
 
@@ -43,15 +43,13 @@ def load_network(path: Path) -> NetworkFile:
     """
     from gance_amd import legacy_import  # pylint: disable=import-outside-toplevel
 
+    # Network files are downloaded artefacts: both formats are read through ONE restricted unpickler
+    # (exact allow-list of numpy / container globals, legacy_import.py); plain pickle.load never runs.
     try:
-        with open(str(path), "rb") as file:
-            content = pickle.load(file)
-    except (pickle.UnpicklingError, ModuleNotFoundError, AttributeError, EOFError, ImportError, ValueError, IndexError) as error:
-        content = error  # not one of ours: maybe a legacy TF pickle (needs dnnlib to unpickle normally)
-    if isinstance(content, dict) and content.get("format") == FORMAT:
-        return NetworkFile(int(content["resolution"]), content["variables"])
-    try:
-        resolution, variables = legacy_import.load_legacy_network(path)
+        content = legacy_import.restricted_load(path)
+        if isinstance(content, dict) and content.get("format") == FORMAT:
+            return NetworkFile(int(content["resolution"]), content["variables"])
+        resolution, variables = legacy_import.legacy_network_from_content(content)
     except Exception as error:  # pylint: disable=broad-except
         raise RuntimeError(
             f"{path} is neither a gance_amd network file (format tag {FORMAT!r}) nor an importable "

@@ -22,7 +22,7 @@ import pandas as pd
 import torch
 import torch.distributed as dist
 
-from gance_amd import divisor, frame_sharding, hip_lib
+from gance_amd import divisor, frame_sharding, hip_lib, torch_ops  # noqa: F401  (torch_ops registers torch.ops.gance.*)
 from gance_amd.data_into_network_visualization import visualization_inputs
 from gance_amd.data_into_network_visualization.visualization_common import DataLabel, ResultLayers
 from gance_amd.logger_common import LOGGER
@@ -31,6 +31,21 @@ from gance_amd.projection import projection_file_reader
 from gance_amd.overlay import overlay_common, overlay_eye_tracking
 from gance_amd.vector_sources import music, vector_reduction
 from gance_amd.vector_sources.vector_sources_common import underlying_length
+
+
+def _common_output_side(networks: MultiNetwork, indices: np.ndarray, output_side_length: Optional[int]) -> int:
+    """
+    Side of the frames a run produces: `output_side_length`, or the networks' own resolution, which must then
+    be the same for every network the indices select (the reference resizes to one side before writing,
+    video_common.py:416-429; without a target side there is nothing to resize mismatching networks to).
+    :raises ValueError: networks of different resolutions and no `output_side_length`.
+    """
+    if output_side_length is not None:
+        return int(output_side_length)
+    sides = {int(networks._network_at(int(index)).engine.resolution) for index in np.unique(indices)}  # pylint: disable=protected-access
+    if len(sides) > 1:
+        raise ValueError(f"networks of different resolutions {sorted(sides)} need an output_side_length to resize to")
+    return sides.pop() if sides else 0
 
 
 def synthesize_device_frames(  # pylint: disable=too-many-locals
@@ -49,35 +64,21 @@ def synthesize_device_frames(  # pylint: disable=too-many-locals
     the reference's `create_image_generic`.
     """
     indices = network_indices.cpu().numpy()
-    stream = torch.cuda.current_stream(dlatents.device).cuda_stream
+    out_side = _common_output_side(networks, indices, output_side_length)
     for start in range(0, dlatents.shape[0], batch):
         stop = min(dlatents.shape[0], start + batch)
         chunk = indices[start:stop]
-        frames: Optional[torch.Tensor] = None
+        frames = torch.empty((stop - start, out_side, out_side, 3), dtype=torch.uint8, device=dlatents.device)
         for network_index in np.unique(chunk):
-            network = networks._network_at(int(network_index))  # pylint: disable=protected-access
-            engine = network.engine
+            engine = networks._network_at(int(network_index)).engine  # pylint: disable=protected-access
             members = torch.from_numpy(np.nonzero(chunk == network_index)[0] + start).to(dlatents.device)
-            side = engine.resolution
-            images = torch.empty((len(members), side, side, 3), dtype=torch.uint8, device=dlatents.device)
             if dlatents.dim() == 2:
-                selected = dlatents.index_select(0, members).contiguous()
-                engine.synthesize_z_device(selected.data_ptr(), len(members), TRUNCATION_PSI, images.data_ptr(), 0, stream)
+                images = torch.ops.gance.synthesize_z(dlatents.index_select(0, members), engine.op_handle, TRUNCATION_PSI)
             else:
-                selected = dlatents.index_select(0, members)[:, : engine.num_layers, :].contiguous()
-                engine.synthesize_w_device(selected.data_ptr(), len(members), images.data_ptr(), 0, stream)
-            if frames is None:
-                frames = torch.empty((stop - start, side, side, 3), dtype=torch.uint8, device=dlatents.device)
+                images = torch.ops.gance.synthesize_w(dlatents.index_select(0, members)[:, : engine.num_layers, :], engine.op_handle)
+            if engine.resolution != out_side:
+                images = torch.ops.gance.resize_bicubic(images, out_side)
             frames.index_copy_(0, members - start, images)
-        assert frames is not None
-        if output_side_length is not None and output_side_length != frames.shape[1]:
-            resized = torch.empty(
-                (frames.shape[0], output_side_length, output_side_length, 3), dtype=torch.uint8, device=frames.device
-            )
-            hip_lib.resize_bicubic_u8_device(
-                frames.data_ptr(), frames.shape[0], frames.shape[1], resized.data_ptr(), output_side_length, stream
-            )
-            frames = resized
         yield frames
 
 
@@ -97,15 +98,12 @@ def synthesize_device_frames_network_major(  # pylint: disable=too-many-locals
     """
     device = dlatents.device
     indices = network_indices.cpu().numpy()
-    stream = torch.cuda.current_stream(device).cuda_stream
     num_frames = int(dlatents.shape[0])
-    out: Optional[torch.Tensor] = None
+    out_side = _common_output_side(networks, indices, output_side_length)
+    out = torch.empty((num_frames, out_side, out_side, 3), dtype=torch.uint8, device=device)
     for network_index in np.unique(indices):
         engine = networks._network_at(int(network_index)).engine  # pylint: disable=protected-access
         side = engine.resolution
-        out_side = output_side_length if output_side_length is not None else side
-        if out is None:
-            out = torch.empty((num_frames, out_side, out_side, 3), dtype=torch.uint8, device=device)
         frames_of_network = np.nonzero(indices == network_index)[0]
         for start in range(0, len(frames_of_network), batch):
             host_members = frames_of_network[start : start + batch]
@@ -119,21 +117,18 @@ def synthesize_device_frames_network_major(  # pylint: disable=too-many-locals
             )
             if dlatents.dim() == 2:
                 selected = dlatents[first : first + count] if in_place else dlatents.index_select(0, members)
-                engine.synthesize_z_device(selected.contiguous().data_ptr(), count, TRUNCATION_PSI, native.data_ptr(), 0, stream)
+                torch.ops.gance.synthesize_z_out(selected, engine.op_handle, TRUNCATION_PSI, native)
             else:
                 selected = (dlatents[first : first + count] if in_place else dlatents.index_select(0, members))[:, : engine.num_layers, :]
-                engine.synthesize_w_device(selected.contiguous().data_ptr(), count, native.data_ptr(), 0, stream)
+                torch.ops.gance.synthesize_w_out(selected, engine.op_handle, native)
             if out_side != side:
                 target = out[first : first + count] if in_place else torch.empty(
                     (count, out_side, out_side, 3), dtype=torch.uint8, device=device
                 )
-                hip_lib.resize_bicubic_u8_device(native.data_ptr(), count, side, target.data_ptr(), out_side, stream)
+                torch.ops.gance.resize_bicubic_out(native, target)
                 native = target
             if not in_place:
                 out.index_copy_(0, members, native)
-    if out is None:
-        side = output_side_length if output_side_length is not None else 0
-        out = torch.empty((0, side, side, 3), dtype=torch.uint8, device=device)
     return out
 
 

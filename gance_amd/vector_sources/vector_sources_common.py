@@ -1,16 +1,16 @@
 """
 Array plumbing on "concatenated vectors" (no arithmetic: pure reshapes, repeats and gathers).
 Same names and semantics as gance/vector_sources/vector_sources_common.py (line numbers cited per
-function). The arithmetic members of that module (savgol smoothing, Fourier resampling) are not
-re-exposed one vector at a time: on this path they run fused inside libgance_hip's blend kernels
-(gance_amd/csrc/audio.hip).
+function). The arithmetic members (Savitzky-Golay smoothing, Fourier resampling, range remap) run on
+the GPU through the `gance_vec_*` entry points of libgance_hip (gance_amd/csrc/audio.hip), one stage per
+call; the hot path runs the same arithmetic fused inside `gance_blend_run`.
 """
 
-from typing import Union
+from typing import Iterable, List, Tuple, Union
 
 import numpy as np
 
-from gance_amd import divisor
+from gance_amd import divisor, hip_lib
 from gance_amd.vector_sources.vector_types import (
     ConcatenatedMatrices,
     ConcatenatedVectors,
@@ -25,6 +25,47 @@ from gance_amd.vector_sources.vector_types import (
 def pad_array(array: np.ndarray, size: int) -> np.ndarray:
     """Zero-pad a 1-D array at the end to `size` (vsc:32-41)."""
     return np.concatenate([array, np.zeros(size - len(array), dtype=array.dtype)])
+
+
+def remap_values_into_range(
+    data: Iterable[Union[float, int]],
+    input_range: Tuple[Union[float, int], Union[float, int]],
+    output_range: Tuple[Union[float, int], Union[float, int]],
+) -> List[float]:
+    """
+    Linear map of values from one range into another (vsc:44-61: `interp1d(input_range, output_range)`
+    applied per value by a multiprocessing Pool; here one kernel).
+    :raises ValueError: a value lies outside `input_range` (interp1d's bounds error).
+    """
+    values = np.asarray(list(data), dtype=np.float64)
+    lo, hi = float(min(input_range)), float(max(input_range))
+    if values.size and (values.min() < lo or values.max() > hi):
+        raise ValueError("A value in x_new is outside the interpolation range.")
+    if values.size == 0:
+        return []
+    return list(hip_lib.vec_remap(values, input_range, output_range))
+
+
+def smooth_across_vectors(data: ConcatenatedVectors, vector_length: int, window_length: int = 7, polyorder: int = 3) -> ConcatenatedVectors:
+    """
+    Savitzky-Golay along TIME for each position of the vector (vsc:136-166): makes one vector similar to
+    the next. `scipy.signal.savgol_filter` defaults (mode "interp").
+    :raises ValueError: scipy's own argument errors (window longer than the number of vectors, ...).
+    """
+    vectors = np.ascontiguousarray(sub_vectors(data, vector_length), dtype=np.float64)
+    return ConcatenatedVectors(hip_lib.vec_savgol(vectors, 0, window_length, polyorder).reshape(-1))
+
+
+def smooth_each_vector(data: ConcatenatedVectors, vector_length: int, window_length: int = 51, polyorder: int = 2) -> ConcatenatedVectors:
+    """Savitzky-Golay within each vector, vectors independent of one another (vsc:169-188)."""
+    vectors = np.ascontiguousarray(sub_vectors(data, vector_length), dtype=np.float64)
+    return ConcatenatedVectors(hip_lib.vec_savgol(vectors, 1, window_length, polyorder).reshape(-1))
+
+
+def scale_vectors_to_length_resample(data: ConcatenatedVectors, original_vector_length: int, output_vector_length: int) -> ConcatenatedVectors:
+    """Every vector Fourier-resampled (`scipy.signal.resample`) to a new length (vsc:211-230)."""
+    vectors = np.ascontiguousarray(sub_vectors(data, original_vector_length), dtype=np.float64)
+    return ConcatenatedVectors(hip_lib.vec_fourier_resample(vectors, output_vector_length).reshape(-1))
 
 
 def sub_vectors(

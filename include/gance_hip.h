@@ -19,7 +19,7 @@
 extern "C" {
 #endif
 
-#define GANCE_ABI_VERSION 2
+#define GANCE_ABI_VERSION 3
 
 enum gance_status {
     GANCE_OK = 0,
@@ -210,6 +210,39 @@ enum gance_blend_stage {
 };
 /* Synchronises the device and copies one stage of the LAST run to host memory. */
 int gance_blend_read_stage(gance_blend* blend, int32_t stage, void* h_out, uint64_t num_bytes);
+
+/* ---- stand-alone forms of the audio -> latent stages -------------------------------------------
+ * The reference exposes every stage of the chain as its own function; gance_blend_run fuses them, these
+ * entry points run one stage on a caller-shaped array (all pointers device pointers, float64 where the
+ * reference computes in float64). Each returns after `stream` has drained unless noted.
+ *
+ * gance_vec_savgol_f64            smooth_across_vectors (axis 0) / smooth_each_vector (axis 1)
+ *                                 (gance/vector_sources/vector_sources_common.py:136-188): scipy.signal.savgol_filter,
+ *                                 mode "interp", along one axis of [num_vectors][vector_length]; polyorder <= 3
+ * gance_vec_fourier_resample_f64  scale_vectors_to_length_resample (:211-230): scipy.signal.resample per vector
+ * gance_vec_spectrogram_f64       compute_spectrogram (gance/apply_spectrogram.py:49-82): periodic-Hann windows of
+ *                                 num_frequency_bins - 2 samples, hop num_frequency_bins, 20 log10(|X| / max |X|);
+ *                                 d_out is [(bins - 2) / 2][frames] like the reference's array
+ * gance_vec_minmax_scale_f64      sklearn minmax_scale of the whole array, in place (apply_spectrogram.py:43)
+ * gance_vec_remap_f64             remap_values_into_range (:44-61): interp1d through two points (asynchronous)
+ * gance_vec_rms_rolling_average   reduce_vector_rms_rolling_average (gance/vector_sources/vector_reduction.py:102-124):
+ *                                 librosa RMS (hop 512) -> pandas rolling mean, NaN head = series mean -> savgol;
+ *                                 num_values = 1 + (num_samples - vector_length) / 512 entries per output
+ * gance_vec_quantize_f64          quantize_results_layers (:161-194): remap [min, max] -> [0, K - 1], np.rint (asynchronous)
+ * gance_debug_fourier_resample_matrix  host only: the [in_length][out_length] operator the resample kernel applies */
+int gance_vec_savgol_f64(const double* d_in, int32_t num_vectors, int32_t vector_length, int32_t axis, int32_t window_length,
+                         int32_t polyorder, double* d_out, void* stream);
+int gance_vec_fourier_resample_f64(const double* d_in, int32_t num_vectors, int32_t in_length, int32_t out_length, double* d_out,
+                                   void* stream);
+int gance_vec_spectrogram_f64(const float* d_audio, uint64_t num_samples, int32_t num_frequency_bins, double* d_out, void* stream);
+int gance_vec_minmax_scale_f64(double* d_data, uint64_t count, double lo, double hi, void* stream);
+int gance_vec_remap_f64(const double* d_in, uint64_t count, double in_lo, double in_hi, double out_lo, double out_hi, double* d_out,
+                        void* stream);
+int gance_vec_rms_rolling_average(const float* d_audio, uint64_t num_samples, int32_t vector_length, int32_t rolling_window,
+                                  int32_t savgol_window_length, int32_t savgol_polyorder, float* d_rms, double* d_rolling,
+                                  double* d_smoothed, int32_t num_values, void* stream);
+int gance_vec_quantize_f64(const double* d_in, int32_t count, int32_t num_indices, int64_t* d_out, void* stream);
+int gance_debug_fourier_resample_matrix(int32_t in_length, int32_t out_length, double* h_out);
 
 /* ------------------------------------------------------------------------------------------ */
 /* Post-synthesis resize (next row f-2)                                                        */

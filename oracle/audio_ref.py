@@ -371,7 +371,10 @@ def resample_audio(samples: np.ndarray, sr_orig: float, sr_new: float) -> np.nda
     if ratio == 1.0:
         return np.array(samples[:count], copy=True)
     x = np.asarray(samples, dtype=np.float64)
-    scale = min(1.0, ratio) * ROLLOFF  # cut-off relative to the lower Nyquist
+    # resampy's published design (`sinc_window`, `resample_f`): with x = (position - index) * min(1, ratio),
+    # weight = rolloff * sinc(rolloff * x) * kaiser(x / crossings) * min(1, ratio) for |x| < crossings; the roll-off
+    # narrows the sinc only, the taper spans the un-scaled 64 zero crossings
+    scale = min(1.0, ratio)
     half_width = int(np.ceil(SINC_ZERO_CROSSINGS / scale))
     out = np.empty(count, dtype=np.float64)
     taps = np.arange(-half_width, half_width + 1)
@@ -383,7 +386,7 @@ def resample_audio(samples: np.ndarray, sr_orig: float, sr_new: float) -> np.nda
         window_arg = offset / SINC_ZERO_CROSSINGS
         inside = np.abs(window_arg) < 1.0
         kaiser = np.i0(KAISER_BETA * np.sqrt(np.clip(1.0 - window_arg * window_arg, 0.0, None))) / np.i0(KAISER_BETA)
-        kernel = np.where(inside, np.sinc(offset) * kaiser, 0.0) * scale
+        kernel = np.where(inside, np.sinc(ROLLOFF * offset) * kaiser, 0.0) * (ROLLOFF * scale)
         valid = (index >= 0) & (index < len(x))
         out[start : start + len(positions)] = np.sum(np.where(valid, x[np.clip(index, 0, len(x) - 1)], 0.0) * kernel, axis=1)
     return out.astype(samples.dtype if np.issubdtype(samples.dtype, np.floating) else np.float32)

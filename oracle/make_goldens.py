@@ -226,10 +226,63 @@ def unit_cases() -> None:
     print("wrote vector_helpers.npz")
 
 
+def standalone_cases() -> None:
+    """
+    The stand-alone stage functions, called one by one on the REFERENCE with small inputs: the cases of its
+    own unit test (test/test_vector_sources_common.py:16-63) and non-default parameters of each function.
+    """
+    from gance import apply_spectrogram  # pylint: disable=import-outside-toplevel,import-error
+    from gance.vector_sources import vector_reduction, vector_sources_common as vsc  # pylint: disable=import-outside-toplevel,import-error
+
+    arrays = {}
+    for original, count, output in ((10, 2, 50), (10, 1, 1000)):  # the reference's own parametrisation
+        total = original * count
+        unscaled = np.sin(np.linspace(start=0, stop=total - 1, num=total))
+        arrays[f"scale_{original}x{count}_to_{output}"] = vsc.scale_vectors_to_length_resample(
+            data=unscaled, original_vector_length=original, output_vector_length=output
+        )
+    rng = np.random.RandomState(77)
+    vectors = rng.randn(11 * 24)
+    arrays["vectors_11x24"] = vectors
+    arrays["scale_24_to_9"] = vsc.scale_vectors_to_length_resample(vectors, 24, 9)  # down-sampling, even -> odd
+    arrays["scale_24_to_16"] = vsc.scale_vectors_to_length_resample(vectors, 24, 16)  # even -> even (Nyquist doubled)
+    arrays["across_5_2"] = vsc.smooth_across_vectors(vectors, 24, window_length=5, polyorder=2)
+    arrays["across_default"] = vsc.smooth_across_vectors(vectors, 24)
+    arrays["each_9_3"] = vsc.smooth_each_vector(vectors, 24, window_length=9, polyorder=3)
+    arrays["each_3_1"] = vsc.smooth_each_vector(vectors, 24, window_length=3, polyorder=1)
+    remap_in = rng.rand(37) * 7.0 - 2.0
+    arrays["remap_in"] = remap_in
+    arrays["remap_out"] = np.array(vsc.remap_values_into_range(remap_in, (-2.0, 5.0), (10.0, -3.0)))
+    num_frames, L = 40, 512
+    audio = synthetic.synthetic_audio(num_frames, L, seed=9)
+    arrays["audio_frames_seed"] = np.array([num_frames, 9], dtype=np.int64)
+    db = apply_spectrogram.compute_spectrogram(audio, L)
+    arrays["db"] = db
+    arrays["vectors_no_range"] = apply_spectrogram.reshape_spectrogram_to_vectors(db, L, None)
+    arrays["vectors_range_0_3"] = apply_spectrogram.reshape_spectrogram_to_vectors(db, L, (0, 3))
+    arrays["smooth_scale_m2_2"] = apply_spectrogram.compute_spectrogram_smooth_scale(audio, L, (-2, 2))
+    stereo = np.stack([audio, audio[::-1]], axis=1)
+    arrays["db_stereo"] = apply_spectrogram.compute_spectrogram(stereo, L)
+    layers = vector_reduction.reduce_vector_rms_rolling_average(audio, L, rolling_average_window=5, savgol_window_length=9, savgol_polyorder=2)
+    arrays["rms_raw"] = np.asarray(layers.layers[1].data)
+    arrays["rms_rolling_5"] = np.asarray(layers.layers[0].data)
+    arrays["rms_smoothed_9_2"] = np.asarray(layers.result.data)
+    arrays["rms_labels"] = np.array([layers.result.label, layers.layers[0].label, layers.layers[1].label])
+    quantized = vector_reduction.quantize_results_layers(layers, [0, 1, 2, 3])
+    arrays["rms_quantized_4"] = np.asarray(quantized.result.data).astype(np.int64)
+    arrays["rms_quantized_label"] = np.array([quantized.result.label])
+    np.savez_compressed(GOLDEN_DIR / "standalone_api.npz", **arrays)
+    print("wrote standalone_api.npz")
+
+
 def main() -> None:
     ref_stubs.install()
     GOLDEN_DIR.mkdir(parents=True, exist_ok=True)
+    if len(sys.argv) > 1 and sys.argv[1] == "standalone":
+        standalone_cases()
+        return
     unit_cases()
+    standalone_cases()
     blend_case("blend_n60_seed0_roll_k3", 60, 0, True, 3, 13)
     blend_case("blend_n60_seed1_noroll_k1", 60, 1, False, 1, 13)
     blend_case("blend_n60_seed2_roll_k1", 60, 2, True, 1, 13)

@@ -90,3 +90,35 @@ def test_other_architectures_and_foreign_pickles_are_refused(tmp_path: Path) -> 
         pickle.dump((1, 2, Path("/tmp")), file)  # pathlib is not on the allow-list
     with pytest.raises(pickle.UnpicklingError, match="refusing to load"):
         legacy_import.load_legacy_network(evil)
+
+
+@pytest.mark.parametrize(
+    "payload",
+    [
+        b"cbuiltins\neval\n(S'__import__(\"os\").getpid()'\ntR.",
+        b"cos\nsystem\n(S'true'\ntR.",
+        b"cposix\nsystem\n(S'true'\ntR.",
+        b"cbuiltins\nexec\n(S'pass'\ntR.",
+        b"cbuiltins\ngetattr\n(cbuiltins\nobject\nS'__subclasses__'\ntR.",
+        b"cnumpy\nload\n(S'/etc/hostname'\ntR.",
+    ],
+)
+def test_code_executing_payloads_are_refused_through_load_network(tmp_path: Path, payload: bytes) -> None:
+    """A network file is a downloaded artefact: nothing outside the exact allow-list may resolve, on EITHER format's path."""
+    path = tmp_path / "evil.pkl"
+    path.write_bytes(payload)
+    with pytest.raises(pickle.UnpicklingError):
+        legacy_import.restricted_load(path)
+    with pytest.raises(RuntimeError, match="refusing to load"):
+        network_file.load_network(path)
+
+
+def test_native_network_file_loads_through_the_restricted_unpickler(tmp_path: Path) -> None:
+    path = tmp_path / "native.pkl"
+    network_file.write_random_network(path, 8, seed=3)
+    loaded = network_file.load_network(path)
+    assert loaded.resolution == 8
+    want = sg2_spec.make_random_variables(8, seed=3)
+    assert set(loaded.variables) == set(want)
+    for name, value in want.items():
+        assert np.array_equal(loaded.variables[name], value)
