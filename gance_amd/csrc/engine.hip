@@ -15,7 +15,11 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
+#include <memory>
+#include <mutex>
 #include <string>
+#include <tuple>
 #include <vector>
 
 #include "../../include/gance_hip.h"
@@ -191,6 +195,41 @@ struct StepRecord {
 
 }  // namespace
 
+// Per-call scratch (activations, parity planes, split-K slabs, skip images, styles ...): about 0.8 GB per frame
+// of batch capacity at 1024^2 against 135 MB of weights per network. It holds nothing between calls except its
+// zero borders, which depend only on the resolution, so every engine of one (device, resolution, max_batch)
+// shares ONE workspace: 20 resident networks cost 20 x weights + 1 x workspace. Calls that share it are ordered
+// by an event (a call waits for the previous user's last kernel, on whatever stream that ran).
+struct gance_workspace {
+    int device = 0, resolution = 0, max_batch = 0;
+    float *dlat = nullptr, *map_a = nullptr, *map_b_buf = nullptr, *z_in = nullptr;
+    float *styles = nullptr, *demod = nullptr;
+    std::vector<float*> act;      // per conv layer: zero-bordered output [Bmax][cout][res+2][res+8]
+    std::vector<float*> tplanes;  // per up layer: [4 cls][max_units][cout][H+3][W+8] (else nullptr)
+    float* slabs = nullptr;       // split-K scratch of the small stride-1 convs (dense)
+    float* ybuf[2] = {nullptr, nullptr};
+    uint8_t* u8buf = nullptr;  // staging for the host-buffer entry points
+    hipEvent_t last_use = nullptr;
+    bool used = false;
+    size_t bytes = 0;
+    ~gance_workspace() {
+        gance::DeviceGuard guard(device);
+        hipFree(dlat);
+        hipFree(map_a);
+        hipFree(map_b_buf);
+        hipFree(z_in);
+        hipFree(styles);
+        hipFree(demod);
+        for (float* ptr : act) hipFree(ptr);
+        for (float* ptr : tplanes) hipFree(ptr);
+        hipFree(slabs);
+        hipFree(ybuf[0]);
+        hipFree(ybuf[1]);
+        hipFree(u8buf);
+        if (last_use) hipEventDestroy(last_use);
+    }
+};
+
 struct gance_engine {
     gance_engine_config cfg{};
     int res_log2 = 0;
@@ -216,15 +255,9 @@ struct gance_engine {
     int* blk_row = nullptr;
     gance::DemodLayer* demod_layers = nullptr;
 
-    // workspace
-    float *dlat = nullptr, *map_a = nullptr, *map_b_buf = nullptr, *z_in = nullptr;
-    float *styles = nullptr, *demod = nullptr;
-    std::vector<float*> act;      // per conv layer: zero-bordered output [Bmax][cout][res+2][res+4]
-    std::vector<float*> tplanes;  // per up layer: [4 cls][max_units][cout][H+3][W+8] (else nullptr)
-    std::vector<int> t_units;     // max_units of that layer
-    float* slabs = nullptr;       // split-K scratch of the small stride-1 convs (dense)
-    float* ybuf[2] = {nullptr, nullptr};
-    uint8_t* u8buf = nullptr;  // staging for the host-buffer entry points
+    // workspace (shared with the other engines of the same device, resolution and max_batch)
+    std::shared_ptr<gance_workspace> ws;
+    std::vector<int> t_units;     // max_units of each up layer's parity planes
     size_t slab_floats = 0, y_floats = 0;
 
     // profiling / debug
@@ -249,18 +282,8 @@ void free_engine(gance_engine* e) {
     hipFree(e->pool);
     hipFree(e->blk_row);
     hipFree(e->demod_layers);
-    hipFree(e->dlat);
-    hipFree(e->map_a);
-    hipFree(e->map_b_buf);
-    hipFree(e->z_in);
-    hipFree(e->styles);
-    hipFree(e->demod);
-    for (float* ptr : e->act) hipFree(ptr);
-    for (float* ptr : e->tplanes) hipFree(ptr);
-    hipFree(e->slabs);
-    hipFree(e->ybuf[0]);
-    hipFree(e->ybuf[1]);
-    hipFree(e->u8buf);
+    if (e->ws && e->ws->used) hipEventSynchronize(e->ws->last_use);  // nothing of this engine still runs on the shared scratch
+    e->ws.reset();  // the last engine of a (device, resolution, max_batch) frees the workspace
     delete e;
 }
 
@@ -313,8 +336,8 @@ int run_conv(gance_engine* e, const ConvLayerHost& c, int li, const LayerPlan& p
     }
     a.x = x;
     a.w = e->pool + e->conv_w[li];
-    a.s = e->styles + e->conv_s_off[li];
-    a.d = e->demod + e->conv_d_off[li];
+    a.s = e->ws->styles + e->conv_s_off[li];
+    a.d = e->ws->demod + e->conv_d_off[li];
     const bool has_noise = e->conv_ns[li] != 0.0f;
     a.noise = has_noise ? e->pool + e->conv_noise[li] : nullptr;
     a.bias = e->pool + e->conv_bias[li];
@@ -401,13 +424,13 @@ int synthesize_from_dlat(gance_engine* e, const float* d_dlat, int B, uint8_t* d
         StepScope scope(e, stream, "styles", 2.0 * B * kDlatent * e->ctot,
                         4.0 * ((double)kDlatent * e->ctot + (double)B * e->ctot));
         GANCE_HIP_CHECK(gance::launch_styles(d_dlat, e->pool + e->A_off, e->pool + e->bias1_off,
-                                             e->blk_row, e->styles, B, e->num_rows, e->ctot,
+                                             e->blk_row, e->ws->styles, B, e->num_rows, e->ctot,
                                              stream));
     }
     {
         StepScope scope(e, stream, "demod", 0.0, 0.0);
-        GANCE_HIP_CHECK(gance::launch_demod(e->styles, e->pool + e->w2_off, e->demod_layers,
-                                            (int)e->convs.size(), e->demod, B, e->ctot, e->dtot,
+        GANCE_HIP_CHECK(gance::launch_demod(e->ws->styles, e->pool + e->w2_off, e->demod_layers,
+                                            (int)e->convs.size(), e->ws->demod, B, e->ctot, e->dtot,
                                             stream));
     }
 
@@ -423,7 +446,7 @@ int synthesize_from_dlat(gance_engine* e, const float* d_dlat, int B, uint8_t* d
         const ConvLayerHost& c = e->convs[li];
         const int res = 1 << c.res_log2;
         const LayerPlan p = plan_layer(c, B);
-        float* x_out = e->act[li];
+        float* x_out = e->ws->act[li];
         const long long out_c = (long long)act_plane(res);
         const long long out_b = out_c * c.cout;
         const bool has_noise = e->conv_ns[li] != 0.0f;
@@ -456,8 +479,8 @@ int synthesize_from_dlat(gance_engine* e, const float* d_dlat, int B, uint8_t* d
             const bool winograd_last = winograd && (wino_mode == 2 || wino_rgb);
             if (fused_rgb) {
                 const int ri = c.res_log2 - 2;
-                FusedRgb rgb{e->pool + e->rgb_w[ri], e->styles + e->rgb_s_off[ri], e->pool + e->rgb_bias[ri],
-                             e->ybuf[ycur], (d_f32 != nullptr || e->keep_skip_image) ? e->ybuf[1 - ycur] : nullptr, d_u8};
+                FusedRgb rgb{e->pool + e->rgb_w[ri], e->ws->styles + e->rgb_s_off[ri], e->pool + e->rgb_bias[ri],
+                             e->ws->ybuf[ycur], (d_f32 != nullptr || e->keep_skip_image) ? e->ws->ybuf[1 - ycur] : nullptr, d_u8};
                 std::snprintf(name, sizeof(name), "conv%s%d+torgb_%dx%d_%d->%d", winograd_last ? "W" : "", c.layer_idx, res, res, c.cin, c.cout);
                 int rc = run_conv(e, c, li, p, x_in, x_b_stride, res, res, x_out, gance::kEpilogueRgb, res + 8, 1, 4,
                                   out_b, out_c, 0, 0, B, stream, name, &rgb, winograd_last);
@@ -472,13 +495,13 @@ int synthesize_from_dlat(gance_engine* e, const float* d_dlat, int B, uint8_t* d
             } else {
                 const long long dense_c = (long long)res * res;
                 const long long slab = dense_c * c.cout * B;
-                int rc = run_conv(e, c, li, p, x_in, x_b_stride, res, res, e->slabs,
+                int rc = run_conv(e, c, li, p, x_in, x_b_stride, res, res, e->ws->slabs,
                                   gance::kEpilogueRaw, res, 0, 0, dense_c * c.cout, dense_c, slab, 0,
                                   B, stream, name);
                 if (rc) return rc;
                 std::snprintf(name, sizeof(name), "finish%d_%dx%d", c.layer_idx, res, res);
                 StepScope scope(e, stream, name, 0.0, 4.0 * (double)slab * (p.nsplit + 1));
-                GANCE_HIP_CHECK(gance::launch_splitk_finish(e->slabs, slab, p.nsplit, noise,
+                GANCE_HIP_CHECK(gance::launch_splitk_finish(e->ws->slabs, slab, p.nsplit, noise,
                                                             e->conv_ns[li], bias, x_out, B, c.cout,
                                                             res, res, stream));
             }
@@ -497,8 +520,8 @@ int synthesize_from_dlat(gance_engine* e, const float* d_dlat, int B, uint8_t* d
                 if (upfir_mode == 2 || (u.total_blocks >= e->num_cus * 3 / 4 && (u.segs == 1 || steps_per_seg >= 4))) {
                     u.x = x_in;
                     u.w = e->pool + e->upfir_w[li];
-                    u.s = e->styles + e->conv_s_off[li];
-                    u.d = e->demod + e->conv_d_off[li];
+                    u.s = e->ws->styles + e->conv_s_off[li];
+                    u.d = e->ws->demod + e->conv_d_off[li];
                     u.noise = noise;
                     u.bias = bias;
                     u.out = x_out;
@@ -531,12 +554,12 @@ int synthesize_from_dlat(gance_engine* e, const float* d_dlat, int B, uint8_t* d
             const long long cls_stride = unit * e->t_units[li];
             std::snprintf(name, sizeof(name), "convT%d_%dx%d_%d->%d", c.layer_idx, res, res, c.cin,
                           c.cout);
-            int rc = run_conv(e, c, li, p, x_in, x_b_stride, H, W, e->tplanes[li],
+            int rc = run_conv(e, c, li, p, x_in, x_b_stride, H, W, e->ws->tplanes[li],
                               gance::kEpilogueRaw, W + 8, 1, 4, unit, tc, unit * B, cls_stride, B,
                               stream, name);
             if (rc) return rc;
             gance::FirArgs f{};
-            f.t = e->tplanes[li];
+            f.t = e->ws->tplanes[li];
             f.cls_stride = cls_stride;
             f.unit_stride = unit;
             f.noise = noise;
@@ -566,10 +589,10 @@ int synthesize_from_dlat(gance_engine* e, const float* d_dlat, int B, uint8_t* d
             gance::ToRgbArgs t{};
             t.x = x_in;
             t.w = e->pool + e->rgb_w[ri];
-            t.s = e->styles + e->rgb_s_off[ri];
+            t.s = e->ws->styles + e->rgb_s_off[ri];
             t.bias = e->pool + e->rgb_bias[ri];
-            t.y_prev = have_y ? e->ybuf[ycur] : nullptr;
-            t.y = e->ybuf[have_y ? 1 - ycur : ycur];
+            t.y_prev = have_y ? e->ws->ybuf[ycur] : nullptr;
+            t.y = e->ws->ybuf[have_y ? 1 - ycur : ycur];
             const bool last = (c.res_log2 == e->res_log2);
             t.u8 = last ? d_u8 : nullptr;
             t.B = B;
@@ -586,11 +609,85 @@ int synthesize_from_dlat(gance_engine* e, const float* d_dlat, int B, uint8_t* d
     }
     if (d_f32 != nullptr && limit == num_convs) {
         const size_t bytes = (size_t)B * 3 * e->cfg.resolution * e->cfg.resolution * sizeof(float);
-        GANCE_HIP_CHECK(hipMemcpyAsync(d_f32, e->ybuf[ycur], bytes, hipMemcpyDeviceToDevice, stream));
+        GANCE_HIP_CHECK(hipMemcpyAsync(d_f32, e->ws->ybuf[ycur], bytes, hipMemcpyDeviceToDevice, stream));
     }
     e->last_stream = stream;
     return GANCE_OK;
 }
+
+// the workspaces alive in this process, by (device, resolution, max_batch)
+std::mutex g_workspace_mutex;
+std::map<std::tuple<int, int, int>, std::weak_ptr<gance_workspace>> g_workspaces;
+
+int acquire_workspace(gance_engine* e) {
+    const bool shared = !(e->cfg.flags & GANCE_FLAG_PRIVATE_WORKSPACE);
+    const auto key = std::make_tuple((int)e->cfg.device, (int)e->cfg.resolution, (int)e->cfg.max_batch);
+    std::lock_guard<std::mutex> lock(g_workspace_mutex);
+    if (shared) {
+        auto it = g_workspaces.find(key);
+        if (it != g_workspaces.end())
+            if (auto alive = it->second.lock()) {
+                e->ws = alive;
+                return GANCE_OK;
+            }
+    }
+    auto ws = std::make_shared<gance_workspace>();
+    ws->device = e->cfg.device;
+    ws->resolution = e->cfg.resolution;
+    ws->max_batch = e->cfg.max_batch;
+    const int nconv = (int)e->convs.size(), Bmax = e->cfg.max_batch;
+    ws->act.assign(nconv, nullptr);
+    ws->tplanes.assign(nconv, nullptr);
+    auto alloc = [&](void** ptr, size_t bytes, bool zero) {
+        hipError_t err = hipMalloc(ptr, bytes);
+        if (err == hipSuccess && zero) err = hipMemset(*ptr, 0, bytes);
+        if (err != hipSuccess) {
+            fail(err == hipErrorOutOfMemory ? GANCE_ERR_OUT_OF_MEMORY : GANCE_ERR_HIP,
+                 std::string("workspace allocation of ") + std::to_string(bytes) + " bytes: " + hipGetErrorString(err));
+            return false;
+        }
+        ws->bytes += bytes;
+        return true;
+    };
+    bool ok = alloc((void**)&ws->dlat, (size_t)Bmax * e->num_rows * kDlatent * sizeof(float), false) &&
+              alloc((void**)&ws->map_a, (size_t)Bmax * kDlatent * sizeof(float), false) &&
+              alloc((void**)&ws->map_b_buf, (size_t)Bmax * kDlatent * sizeof(float), false) &&
+              alloc((void**)&ws->z_in, (size_t)Bmax * kDlatent * sizeof(float), false) &&
+              alloc((void**)&ws->styles, (size_t)Bmax * e->ctot * sizeof(float), false) &&
+              alloc((void**)&ws->demod, (size_t)Bmax * e->dtot * sizeof(float), false);
+    for (int i = 0; ok && i < nconv; ++i) {
+        // every layer owns its zero-bordered output (and parity planes): kernels only ever write
+        // interiors, so the borders are zeroed exactly once, here
+        const ConvLayerHost& c = e->convs[i];
+        ok = alloc((void**)&ws->act[i], (size_t)Bmax * c.cout * act_plane(1 << c.res_log2) * sizeof(float), true);
+        if (ok && c.up)
+            ok = alloc((void**)&ws->tplanes[i], (size_t)4 * e->t_units[i] * c.cout * t_plane((1 << c.res_log2) / 2) * sizeof(float), true);
+    }
+    ok = ok && alloc((void**)&ws->slabs, e->slab_floats * sizeof(float), false) &&
+         alloc((void**)&ws->ybuf[0], e->y_floats * sizeof(float), false) && alloc((void**)&ws->ybuf[1], e->y_floats * sizeof(float), false) &&
+         alloc((void**)&ws->u8buf, e->y_floats, false);
+    if (ok && hipEventCreateWithFlags(&ws->last_use, hipEventDisableTiming) != hipSuccess) {
+        fail(GANCE_ERR_HIP, "hipEventCreate failed");
+        ok = false;
+    }
+    if (!ok) return GANCE_ERR_OUT_OF_MEMORY;  // (the partial workspace frees itself; the message is already recorded)
+    if (shared) g_workspaces[key] = ws;
+    e->ws = ws;
+    return GANCE_OK;
+}
+
+// calls that share a workspace run one after the other, whatever streams they were given
+struct WorkspaceTurn {
+    gance_workspace* ws;
+    hipStream_t stream;
+    WorkspaceTurn(gance_workspace* w, hipStream_t s) : ws(w), stream(s) {
+        if (ws->used) hipStreamWaitEvent(stream, ws->last_use, 0);
+    }
+    ~WorkspaceTurn() {
+        hipEventRecord(ws->last_use, stream);
+        ws->used = true;
+    }
+};
 
 int check_call(gance_engine* e, const void* in, int batch) {
     if (e == nullptr) return fail(GANCE_ERR_INVALID_ARGUMENT, "engine is NULL");
@@ -811,8 +908,6 @@ int gance_engine_create(const gance_engine_config* config, const float* host_wei
 
     // ---- workspace sizes ----
     const int Bmax = config->max_batch;
-    e->act.assign(nconv, nullptr);
-    e->tplanes.assign(nconv, nullptr);
     e->t_units.assign(nconv, 0);
     size_t slab_max = 4;
     for (int i = 0; i < nconv; ++i) {
@@ -846,30 +941,12 @@ int gance_engine_create(const gance_engine_config* config, const float* host_wei
     GANCE_CREATE_CHECK(hipMalloc((void**)&e->demod_layers, demod_layers.size() * sizeof(gance::DemodLayer)));
     GANCE_CREATE_CHECK(hipMemcpy(e->demod_layers, demod_layers.data(),
                                  demod_layers.size() * sizeof(gance::DemodLayer), hipMemcpyHostToDevice));
-    GANCE_CREATE_CHECK(hipMalloc((void**)&e->dlat, (size_t)Bmax * e->num_rows * kDlatent * sizeof(float)));
-    GANCE_CREATE_CHECK(hipMalloc((void**)&e->map_a, (size_t)Bmax * kDlatent * sizeof(float)));
-    GANCE_CREATE_CHECK(hipMalloc((void**)&e->map_b_buf, (size_t)Bmax * kDlatent * sizeof(float)));
-    GANCE_CREATE_CHECK(hipMalloc((void**)&e->z_in, (size_t)Bmax * kDlatent * sizeof(float)));
-    GANCE_CREATE_CHECK(hipMalloc((void**)&e->styles, (size_t)Bmax * ctot * sizeof(float)));
-    GANCE_CREATE_CHECK(hipMalloc((void**)&e->demod, (size_t)Bmax * dtot * sizeof(float)));
-    for (int i = 0; i < nconv; ++i) {
-        // every layer owns its zero-bordered output (and parity planes): kernels only ever write
-        // interiors, so the borders are zeroed exactly once, here
-        const ConvLayerHost& c = e->convs[i];
-        const size_t act_bytes = (size_t)Bmax * c.cout * act_plane(1 << c.res_log2) * sizeof(float);
-        GANCE_CREATE_CHECK(hipMalloc((void**)&e->act[i], act_bytes));
-        GANCE_CREATE_CHECK(hipMemset(e->act[i], 0, act_bytes));
-        if (c.up) {
-            const size_t t_bytes = (size_t)4 * e->t_units[i] * c.cout * t_plane((1 << c.res_log2) / 2) * sizeof(float);
-            GANCE_CREATE_CHECK(hipMalloc((void**)&e->tplanes[i], t_bytes));
-            GANCE_CREATE_CHECK(hipMemset(e->tplanes[i], 0, t_bytes));
-        }
-    }
-    GANCE_CREATE_CHECK(hipMalloc((void**)&e->slabs, e->slab_floats * sizeof(float)));
-    GANCE_CREATE_CHECK(hipMalloc((void**)&e->ybuf[0], e->y_floats * sizeof(float)));
-    GANCE_CREATE_CHECK(hipMalloc((void**)&e->ybuf[1], e->y_floats * sizeof(float)));
-    GANCE_CREATE_CHECK(hipMalloc((void**)&e->u8buf, e->y_floats));
 #undef GANCE_CREATE_CHECK
+    if (int rc = acquire_workspace(e)) {
+        const std::string message = g_last_error;
+        free_engine(e);
+        return fail(rc, message);
+    }
     *out_engine = e;
     return GANCE_OK;
 }
@@ -888,6 +965,7 @@ int gance_synthesize_w(gance_engine* engine, const float* d_dlatents, int32_t ba
     GANCE_HIP_CHECK(guard.status());
     // filtered profiling keeps its records across calls (bench.py averages them); else one call's worth
     if (engine->profile_only.empty() || engine->steps_used >= 4096) engine->steps_used = 0;
+    WorkspaceTurn turn(engine->ws.get(), (hipStream_t)stream);
     return synthesize_from_dlat(engine, d_dlatents, batch, d_out_u8, d_out_f32, (hipStream_t)stream);
 }
 
@@ -899,8 +977,9 @@ int gance_synthesize_z(gance_engine* engine, const float* d_z, int32_t batch, fl
     hipStream_t stream = (hipStream_t)stream_;
     // filtered profiling keeps its records across calls (bench.py averages them); else one call's worth
     if (engine->profile_only.empty() || engine->steps_used >= 4096) engine->steps_used = 0;
+    WorkspaceTurn turn(engine->ws.get(), stream);
     const float* in = d_z;
-    float* bufs[2] = {engine->map_a, engine->map_b_buf};
+    float* bufs[2] = {engine->ws->map_a, engine->ws->map_b_buf};
     for (int i = 0; i < kMappingLayers; ++i) {
         StepScope scope(engine, stream, "mapping_dense", 2.0 * batch * kDlatent * kDlatent,
                         4.0 * kDlatent * kDlatent);
@@ -912,10 +991,10 @@ int gance_synthesize_z(gance_engine* engine, const float* d_z, int32_t batch, fl
     {
         StepScope scope(engine, stream, "truncate", 0.0, 0.0);
         GANCE_HIP_CHECK(gance::launch_broadcast_truncate(in, engine->pool + engine->avg_off,
-                                                         truncation_psi, engine->dlat, batch,
+                                                         truncation_psi, engine->ws->dlat, batch,
                                                          engine->num_rows, stream));
     }
-    return synthesize_from_dlat(engine, engine->dlat, batch, d_out_u8, d_out_f32, stream);
+    return synthesize_from_dlat(engine, engine->ws->dlat, batch, d_out_u8, d_out_f32, stream);
 }
 
 static int host_call(gance_engine* e, const float* h_in, size_t in_floats, int batch, bool is_z,
@@ -924,21 +1003,22 @@ static int host_call(gance_engine* e, const float* h_in, size_t in_floats, int b
     gance::DeviceGuard guard(e->cfg.device);
     GANCE_HIP_CHECK(guard.status());
     const size_t px = (size_t)e->cfg.resolution * e->cfg.resolution * 3;
-    float* d_in = is_z ? e->z_in : e->dlat;
+    float* d_in = is_z ? e->ws->z_in : e->ws->dlat;
+    if (e->ws->used) GANCE_HIP_CHECK(hipEventSynchronize(e->ws->last_use));  // another engine's call may still read the shared scratch
     GANCE_HIP_CHECK(hipMemcpy(d_in, h_in, in_floats * sizeof(float), hipMemcpyHostToDevice));
     e->keep_skip_image = h_f32 != nullptr;
-    int rc = is_z ? gance_synthesize_z(e, d_in, batch, psi, e->u8buf, nullptr, nullptr)
-                  : gance_synthesize_w(e, d_in, batch, e->u8buf, nullptr, nullptr);
+    int rc = is_z ? gance_synthesize_z(e, d_in, batch, psi, e->ws->u8buf, nullptr, nullptr)
+                  : gance_synthesize_w(e, d_in, batch, e->ws->u8buf, nullptr, nullptr);
     e->keep_skip_image = false;
     if (rc) return rc;
     GANCE_HIP_CHECK(hipDeviceSynchronize());
     if (e->debug_stop_after > 0) return GANCE_OK;
-    if (h_u8) GANCE_HIP_CHECK(hipMemcpy(h_u8, e->u8buf, px * batch, hipMemcpyDeviceToHost));
+    if (h_u8) GANCE_HIP_CHECK(hipMemcpy(h_u8, e->ws->u8buf, px * batch, hipMemcpyDeviceToHost));
     if (h_f32) {
         // the final skip image is in whichever ybuf the last ToRGB wrote
         const int n_rgb = (int)e->rgbs.size();
         const int ycur = (n_rgb - 1) & 1;
-        GANCE_HIP_CHECK(hipMemcpy(h_f32, e->ybuf[ycur], px * batch * sizeof(float), hipMemcpyDeviceToHost));
+        GANCE_HIP_CHECK(hipMemcpy(h_f32, e->ws->ybuf[ycur], px * batch * sizeof(float), hipMemcpyDeviceToHost));
     }
     return GANCE_OK;
 }
@@ -1001,7 +1081,7 @@ int gance_engine_debug_read_activation(gance_engine* engine, int32_t batch, floa
     GANCE_HIP_CHECK(hipDeviceSynchronize());
     const size_t padded = (size_t)batch * C * act_plane(R);
     std::vector<float> tmp(padded);
-    GANCE_HIP_CHECK(hipMemcpy(tmp.data(), engine->act[engine->last_act_layer], padded * sizeof(float),
+    GANCE_HIP_CHECK(hipMemcpy(tmp.data(), engine->ws->act[engine->last_act_layer], padded * sizeof(float),
                               hipMemcpyDeviceToHost));
     for (size_t bc = 0; bc < (size_t)batch * C; ++bc)
         for (int y = 0; y < R; ++y)

@@ -30,6 +30,7 @@ GANCE_FLAG_DIRECT_CONV = 2
 GANCE_FLAG_FORCE_WINOGRAD = 4
 GANCE_FLAG_SPLIT_UPFIR = 8
 GANCE_FLAG_FORCE_FUSED_UPFIR = 16
+GANCE_FLAG_PRIVATE_WORKSPACE = 32
 
 STATUS_NAMES = {
     1: "GANCE_ERR_INVALID_ARGUMENT",
@@ -266,8 +267,12 @@ class Engine:
         profile: bool = False,
         conv_form: str = "auto",
         up_form: str = "auto",
+        private_workspace: bool = False,
     ) -> None:
         """
+        :param private_workspace: give this engine its own activation scratch instead of the one every engine of
+        the same (device, resolution, max_batch) shares (only needed to overlap calls of different engines on
+        different streams; costs ~0.8 GB per frame of max_batch at 1024^2).
         :param up_form: Conv0_up layers with an input >= 64 wide: "auto" = one fused kernel (transposed conv +
         FIR + noise + bias + leaky ReLU) when the launch fills the chip, else two passes; "split" = always two
         passes; "fused" = the fused kernel whatever the batch.
@@ -281,6 +286,8 @@ class Engine:
         blob = sg2_spec.pack_variables(variables, spec)
         form_flags = {"auto": 0, "direct": GANCE_FLAG_DIRECT_CONV, "winograd": GANCE_FLAG_FORCE_WINOGRAD}[conv_form]
         form_flags |= {"auto": 0, "split": GANCE_FLAG_SPLIT_UPFIR, "fused": GANCE_FLAG_FORCE_FUSED_UPFIR}[up_form]
+        if private_workspace:
+            form_flags |= GANCE_FLAG_PRIVATE_WORKSPACE
         config = EngineConfig(resolution, max_batch, device, (GANCE_FLAG_PROFILE_STEPS if profile else 0) | form_flags)
         _check(
             self._lib,

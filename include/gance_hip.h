@@ -59,6 +59,11 @@ typedef struct gance_engine_config {
  * (transposed conv, then FIR pass); FORCE_FUSED_UPFIR drops the block-count condition (parity tests). */
 #define GANCE_FLAG_SPLIT_UPFIR 8
 #define GANCE_FLAG_FORCE_FUSED_UPFIR 16
+/* The per-call scratch (activations etc.: ~0.8 GB per frame of batch capacity at 1024^2) is shared by every
+ * engine of one (device, resolution, max_batch): N resident networks cost N x 135 MB of weights + ONE workspace.
+ * Calls that share it are ordered by an event, on whatever streams they run. PRIVATE_WORKSPACE gives an engine
+ * its own (calls of different engines may then overlap on different streams). */
+#define GANCE_FLAG_PRIVATE_WORKSPACE 32
 
 /*
  * Load a network. Replaces load_network_network + wrap_loaded_network

@@ -275,14 +275,45 @@ def standalone_cases() -> None:
     print("wrote standalone_api.npz")
 
 
+def read_wav_cases() -> None:
+    """`read_wav_file` of the reference (music.py:172-209) on generated PCM files: int16 / int32 mono, int16 stereo, float32."""
+    import tempfile  # pylint: disable=import-outside-toplevel
+
+    from scipy.io import wavfile  # pylint: disable=import-outside-toplevel
+
+    from gance.vector_sources import music  # pylint: disable=import-outside-toplevel,import-error
+
+    rng = np.random.RandomState(21)
+    pcm16 = np.concatenate([np.array([-32768, 32767, 0, -1, 1], dtype=np.int16), rng.randint(-32768, 32768, size=1200).astype(np.int16)])
+    pcm32 = np.concatenate(
+        [np.array([-2147483648, 2147483647, 0, -1, 1], dtype=np.int32), rng.randint(-2147483648, 2147483647, size=900, dtype=np.int64).astype(np.int32)]
+    )
+    stereo16 = rng.randint(-32768, 32768, size=(700, 2)).astype(np.int16)
+    float32 = (rng.rand(500).astype(np.float32) * 2 - 1)
+    arrays = {"pcm16": pcm16, "pcm32": pcm32, "stereo16": stereo16, "float32": float32}
+    with tempfile.TemporaryDirectory() as directory:
+        for name, rate in (("pcm16", 44100), ("pcm32", 48000), ("stereo16", 22050), ("float32", 30720)):
+            path = Path(directory) / f"{name}_clip.wav"
+            wavfile.write(str(path), rate, arrays[name])
+            result = music.read_wav_file(path)
+            arrays[f"{name}_out"] = np.asarray(result.wav_data)
+            arrays[f"{name}_meta"] = np.array([str(result.sample_rate), result.name, str(np.asarray(result.wav_data).dtype)])
+    np.savez_compressed(GOLDEN_DIR / "read_wav.npz", **arrays)
+    print("wrote read_wav.npz")
+
+
 def main() -> None:
     ref_stubs.install()
     GOLDEN_DIR.mkdir(parents=True, exist_ok=True)
     if len(sys.argv) > 1 and sys.argv[1] == "standalone":
         standalone_cases()
         return
+    if len(sys.argv) > 1 and sys.argv[1] == "read_wav":
+        read_wav_cases()
+        return
     unit_cases()
     standalone_cases()
+    read_wav_cases()
     blend_case("blend_n60_seed0_roll_k3", 60, 0, True, 3, 13)
     blend_case("blend_n60_seed1_noroll_k1", 60, 1, False, 1, 13)
     blend_case("blend_n60_seed2_roll_k1", 60, 2, True, 1, 13)

@@ -76,3 +76,33 @@ def test_scale_for_video_modes_padding_mono_and_errors(tmp_path: Path) -> None:
     other = _write(tmp_path / "o.wav", 8000, mono)
     with pytest.raises(ValueError, match="Multiple sample rates"):
         music.read_wavs_scale_for_video([paths[0], other], L, frames_per_second=60)
+
+
+@pytest.mark.parametrize("case,rate", [("pcm16", 44100), ("pcm32", 48000), ("stereo16", 22050), ("float32", 30720)])
+def test_read_wav_file_matches_the_reference(tmp_path, golden_dir, case: str, rate: int) -> None:
+    """
+    `read_wav_file` against what the REFERENCE's own function returned (music.py:172-209 run by
+    oracle/make_goldens.py::read_wav_cases on the same generated PCM): sample values bit for bit, dtype,
+    sample rate and name. The reference maps every sample through interp1d in a process pool; here one
+    vectorised line.
+    """
+    from scipy.io import wavfile  # pylint: disable=import-outside-toplevel
+
+    golden = np.load(golden_dir / "read_wav.npz")
+    path = tmp_path / f"{case}_clip.wav"
+    wavfile.write(str(path), rate, golden[case])
+    result = music.read_wav_file(path)
+    want_rate, want_name, want_dtype = golden[f"{case}_meta"]
+    assert str(result.sample_rate) == want_rate and result.name == want_name and str(result.wav_data.dtype) == want_dtype
+    assert result.wav_data.shape == golden[f"{case}_out"].shape
+    assert np.array_equal(result.wav_data, golden[f"{case}_out"])
+
+
+def test_read_wav_file_rejects_8_bit_pcm_like_the_reference(tmp_path) -> None:
+    """scipy reads 8-bit PCM as uint8, which the reference's dtype switch does not list (music.py:188-201)."""
+    from scipy.io import wavfile  # pylint: disable=import-outside-toplevel
+
+    path = tmp_path / "eight.wav"
+    wavfile.write(str(path), 8000, np.arange(0, 200, dtype=np.uint8))
+    with pytest.raises(ValueError, match="unknown input format"):
+        music.read_wav_file(path)

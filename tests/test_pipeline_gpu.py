@@ -102,3 +102,108 @@ def test_blend_then_synthesis_with_network_switching(network_dir: Path) -> None:
         expected = stylegan2_ref.convert_images_to_uint8(image)[0]
         diff = np.abs(frames[frame_index].astype(int) - expected.astype(int))
         assert diff.max() <= 1 and (diff > 0).mean() < 1e-3
+
+
+def test_resident_networks_share_one_workspace() -> None:
+    """
+    Eight 1024^2 networks resident at 32 frames per call: weights per network (135 MB), ONE activation
+    workspace per (device, resolution, max_batch) -- under 35 GB in all where private workspaces took 8 x 26 GB.
+    Switching between them leaves every network's frames unchanged.
+    """
+    from gance_amd import hip_lib  # pylint: disable=import-outside-toplevel
+    from gance_amd.stylegan2 import spec as sg2_spec  # pylint: disable=import-outside-toplevel
+
+    resolution, batch = 1024, 32
+    torch.cuda.synchronize()
+    free_before, _ = torch.cuda.mem_get_info()
+    engines = [hip_lib.Engine(sg2_spec.make_random_variables(resolution, seed=seed), resolution, max_batch=batch) for seed in range(2)]
+    free_after_two, _ = torch.cuda.mem_get_info()
+    engines += [hip_lib.Engine(sg2_spec.make_random_variables(resolution, seed=seed), resolution, max_batch=batch) for seed in range(2, 8)]
+    free_after_eight, _ = torch.cuda.mem_get_info()
+    try:
+        assert free_before - free_after_eight < 35e9, f"8 resident networks took {(free_before - free_after_eight) / 1e9:.1f} GB"
+        assert (free_after_two - free_after_eight) / 6 < 0.4e9, "each further network should cost its weights only"
+        z = np.random.RandomState(3).randn(2, 512).astype(np.float32)
+        first = [engine.synthesize_z(z) for engine in engines[:3]]
+        assert not np.array_equal(first[0], first[1])  # different networks
+        for engine, want in zip(reversed(engines[:3]), reversed(first)):  # switch back and forth
+            assert np.array_equal(engine.synthesize_z(z), want)
+        # two engines driven from two streams, asynchronously, still take turns on the shared scratch
+        d_z = torch.from_numpy(z).cuda()
+        outs = [torch.empty((2, resolution, resolution, 3), dtype=torch.uint8, device="cuda") for _ in range(2)]
+        streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+        torch.cuda.synchronize()
+        for _ in range(3):
+            for engine, out, stream in zip(engines[:2], outs, streams):
+                engine.synthesize_z_device(d_z.data_ptr(), 2, 1.2, out.data_ptr(), 0, stream.cuda_stream)
+        torch.cuda.synchronize()
+        assert np.array_equal(outs[0].cpu().numpy(), first[0]) and np.array_equal(outs[1].cpu().numpy(), first[1])
+    finally:
+        for engine in engines:
+            engine.close()
+    torch.cuda.synchronize()
+    free_end, _ = torch.cuda.mem_get_info()
+    assert free_before - free_end < 1e9, "closing the last engine frees the shared workspace"
+
+
+def test_config_0_verbatim_256_random_z_through_the_network_interface(tmp_path: Path) -> None:
+    """
+    BASELINE.json configs[0] as stated: 256x256 random-init generator (seed 0), the 64
+    z vectors `np.random.RandomState(1234).randn(64, 512)` (the seed of gance/vector_sources/primatives.py:17),
+    each through `create_network_interface(path).create_image_vector` -- the reference's one-frame call form --
+    against the oracle on the same z.
+    """
+    resolution = 256
+    path = tmp_path / "config0.pkl"
+    network_file.write_random_network(path, resolution, seed=0)
+    vectors = np.random.RandomState(1234).randn(64, 512).astype(np.float32)
+    interface = network_functions.create_network_interface_process(path)
+    try:
+        network = interface.network_interface
+        assert network.expected_vector_length == 512
+        frames = np.stack([network.create_image_vector(vector) for vector in vectors])
+        generic = network.create_image_generic(vectors[5])
+    finally:
+        interface.stop_function()
+    assert frames.shape == (64, resolution, resolution, 3) and frames.dtype == np.uint8
+    assert np.array_equal(generic, frames[5])
+    variables = sg2_spec.make_random_variables(resolution, seed=0)
+    for start in (0, 56):  # the oracle (fp64 on the host cores) on the first and last eight; all 64 went through the GPU path
+        want = stylegan2_ref.convert_images_to_uint8(stylegan2_ref.synthesize_z(vectors[start : start + 8], variables, resolution, truncation_psi=1.2))
+        diff = np.abs(frames[start : start + 8].astype(np.int16) - want.astype(np.int16))
+        assert int(diff.max()) <= 1 and float((diff > 0).mean()) < 1e-3
+    assert len({frame.tobytes() for frame in frames}) == 64  # 64 different z vectors, 64 different frames
+    assert frames.sum() > 0  # the reference's own assertion at this boundary (test_network_functions.py:100-118)
+
+
+def test_legacy_tf_pickle_loads_into_a_network_and_renders(tmp_path: Path) -> None:
+    """
+    SURVEY.md §8 f-1 end to end: a (G, D, Gs) pickle in the published dnnlib Network state layout (fabricated:
+    no legacy pickle exists in the reference tree) -> restricted unpickler -> LoadedNetwork in HBM -> frame,
+    against the oracle on the variables the pickle was written from (every term on: noise strengths, biases,
+    stored noise buffers, dlatent_avg).
+    """
+    import importlib.util  # pylint: disable=import-outside-toplevel
+
+    helper_spec = importlib.util.spec_from_file_location("legacy_pickle_helper", Path(__file__).resolve().parent / "test_legacy_import.py")
+    helper = importlib.util.module_from_spec(helper_spec)
+    helper_spec.loader.exec_module(helper)
+
+    resolution = 64
+    variables = sg2_spec.make_random_variables(resolution, seed=11, perturb=True)
+    path = tmp_path / "legacy.pkl"
+    helper._write_legacy_pickle(path, variables)  # pylint: disable=protected-access
+    network = network_functions.LoadedNetwork(path, max_batch=2)
+    try:
+        rng = np.random.RandomState(12)
+        z = rng.randn(2, 512).astype(np.float32)
+        dlatents = rng.randn(1, network.engine.num_layers, 512).astype(np.float32)
+        from_z = network.create_images_vector(z)
+        from_w = network.create_image_matrix(dlatents[0].astype(np.float64))  # callers pass float64 (SURVEY §8b)
+    finally:
+        network.stop()
+    want_z = stylegan2_ref.convert_images_to_uint8(stylegan2_ref.synthesize_z(z, variables, resolution, truncation_psi=1.2))
+    want_w = stylegan2_ref.convert_images_to_uint8(stylegan2_ref.synthesize_w(dlatents, variables, resolution))
+    for got, want in ((from_z, want_z), (from_w[None], want_w)):
+        diff = np.abs(got.astype(np.int16) - want.astype(np.int16))
+        assert int(diff.max()) <= 1 and float((diff > 0).mean()) < 1e-3
