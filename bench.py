@@ -97,24 +97,27 @@ def cpu_baseline(resolution: int, variables, budget_seconds: float = 15.0) -> di
     }
 
 
-def blend_workload(args, device) -> int:
+def blend_measurement(resolution: int, batch: int, num_networks: int, output_side, device, with_cpu_baseline: bool) -> dict:
     """
     BASELINE.json configs[2] on one GPU: 30 s synthetic WAV (30 720 Hz) + 900 projected latents
     -> spectrogram, fft-roll, alpha blend (alpha 0.25, amplitude +-5, depth 12) -> 1800 frames at
-    1024^2, frames left in HBM. Timed: host audio array -> last uint8 frame in HBM.
+    1024^2, frames left in HBM. Timed: host audio array -> last uint8 frame in HBM. With `num_networks` > 1 the
+    RMS-driven index switches between resident networks (configs[4] without the overlay); `output_side` adds
+    the bicubic resize in HBM (configs[3] on one GPU).
     """
-    from gance_amd import synthetic  # pylint: disable=import-outside-toplevel
-    from gance_amd.data_into_network_visualization import visualization_inputs  # pylint: disable=import-outside-toplevel
-
     from types import SimpleNamespace  # pylint: disable=import-outside-toplevel
 
-    from gance_amd import projection_file_blend  # pylint: disable=import-outside-toplevel
+    from gance_amd import projection_file_blend, synthetic  # pylint: disable=import-outside-toplevel
+    from gance_amd.data_into_network_visualization import visualization_inputs  # pylint: disable=import-outside-toplevel
 
-    resolution, batch, num_frames, num_networks = args.resolution, args.batch, 1800, args.networks
+    num_frames = 1800
     engines = [
-        hip_lib.Engine(sg2_spec.make_random_variables(resolution, seed=seed), resolution, max_batch=batch, device=device.index)
+        hip_lib.Engine(sg2_spec.make_random_variables(resolution, seed=seed), resolution, max_batch=batch, device=device.index, profile=True)
         for seed in range(num_networks)
     ]
+    last_conv = "conv%d+torgb_%dx%d_" % (2 * int(np.log2(resolution)) - 4, resolution, resolution)
+    for engine in engines:
+        engine.set_profiling(False)
     audio, latents = synthetic.benchmark_blend_inputs(num_frames)
     frames = torch.empty((batch, resolution, resolution, 3), dtype=torch.uint8, device=device)
     stream = torch.cuda.current_stream(device)
@@ -131,14 +134,14 @@ def blend_workload(args, device) -> int:
         )
         torch.cuda.synchronize(device)
         t1 = time.perf_counter()
-        if num_networks == 1 and args.output_side is None:
+        if num_networks == 1 and output_side is None:
             dlat = blend.dlatents[:, :rows, :].contiguous()
             for start in range(0, num_frames, batch):
                 count = min(batch, num_frames - start)
                 engines[0].synthesize_w_device(dlat[start : start + count].data_ptr(), count, frames.data_ptr(), 0, stream.cuda_stream)
         else:  # the RMS-driven index switches networks; every network is resident, frames come back in order
             ordered = projection_file_blend.synthesize_device_frames_network_major(
-                blend.dlatents, blend.network_indices, resident, args.output_side, batch
+                blend.dlatents, blend.network_indices, resident, output_side, batch
             )
             assert ordered.shape[0] == num_frames
             chosen = blend.network_indices.cpu().numpy()
@@ -149,17 +152,75 @@ def blend_workload(args, device) -> int:
         return t1 - t0, t2 - t1
 
     run_once()  # warm-up (LDS attribute setup, allocator)
+    for engine in engines:
+        engine.set_profiling(True, only_step=last_conv)
     audio_s, synth_s = run_once()
-    print(json.dumps({
-        "metric": "projection-file-blend frames/sec at 1024x1024 (config 3), host audio -> frames in HBM",
+    timed = [s for engine in engines for s in engine.steps() if s.name.startswith(last_conv)]
+    # audio -> latents: algorithmic bytes = the samples read once + the per-frame latent rows written once
+    # (two distinct rows per frame) + the [N][L] float64 spectrogram written and read once per stage (5 stages)
+    audio_bytes = num_frames * 512 * 4 + num_frames * 18 * 512 * 4 + 5 * 2 * num_frames * 512 * 8
+    result = {
+        "metric": "projection-file-blend frames/sec at 1024x1024 (BASELINE.json configs[2]: 30 s WAV -> FFT + fft-roll -> alpha-blended latents -> synthesis), host audio -> frames in HBM",
         "value": round(num_frames / (audio_s + synth_s), 3), "unit": "frames/s", "n_gpus": 1,
         "frames": num_frames, "audio_to_latents_ms": round(audio_s * 1e3, 3), "synthesis_ms": round(synth_s * 1e3, 3),
         "frames_per_call": batch, "networks_resident": num_networks, "network_switches": switches,
-        "output_side_length": args.output_side or resolution,
+        "output_side_length": output_side or resolution,
         "dtype": "f64 (audio) / f32 (synthesis)", "data": "synthetic",
-    }), flush=True)
+        "roofline": {
+            "bound": "mfma",
+            "kernel": "modconv_mfma_kernel (%s)" % (timed[0].name if timed else last_conv),
+            "launches_averaged": len(timed),
+            "achieved": round(timed[0].flops / (sum(s.ms for s in timed) / len(timed) * 1e-3) / 1e12, 3) if timed else None,
+            "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(timed[0].flops / (sum(s.ms for s in timed) / len(timed) * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4) if timed else None,
+            "audio_stage": {
+                "bound": "hbm (launch-latency in practice: six kernels over < 60 MB)", "algorithmic_bytes": audio_bytes,
+                "achieved": round(audio_bytes / audio_s / 1e9, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(audio_bytes / audio_s / 1e9 / HBM_PEAK_GBS, 6),
+            },
+        },
+    }
+    if with_cpu_baseline:
+        from oracle import audio_ref  # pylint: disable=import-outside-toplevel
+
+        t0 = time.perf_counter()
+        audio_ref.alpha_blend_projection_file(latents, 0.25, True, (-5, 5), 12, audio, 512, list(range(num_networks)))
+        cpu_s = time.perf_counter() - t0
+        result["cpu_baseline"] = {
+            "value": round(cpu_s * 1e3, 1), "unit": "ms for audio -> latents of the same 1800 frames (lower is better)", "cores": 1, "kind": "port",
+            "sample": "oracle/audio_ref.alpha_blend_projection_file (numpy / scipy restatement of the reference's chain, its Python loops vectorised), the whole 30 s workload once, single thread; the GPU stage beside it: %.1f ms" % (audio_s * 1e3),
+        }
     for engine in engines:
         engine.close()
+    return result
+
+
+def one_frame_latency(resolution: int, device) -> dict:
+    """The reference's call pattern: one frame per call through the host-buffer entries (numpy in, numpy out, PCIe included)."""
+    engine = hip_lib.Engine(sg2_spec.make_random_variables(resolution, seed=0), resolution, max_batch=1, device=device.index)
+    rng = np.random.RandomState(0)
+    out = {}
+    for name, make, call in (
+        ("create_image_matrix", lambda: rng.randn(1, engine.num_layers, 512).astype(np.float32), engine.synthesize_w),
+        ("create_image_vector", lambda: rng.randn(1, 512).astype(np.float32), engine.synthesize_z),
+    ):
+        for _ in range(4):
+            call(make())
+        times = []
+        for _ in range(40):
+            data = make()
+            start = time.perf_counter()
+            call(data)
+            times.append(time.perf_counter() - start)
+        out[name] = {"median_ms": round(1e3 * float(np.median(times)), 4), "min_ms": round(1e3 * min(times), 4), "frames_per_s": round(1.0 / float(np.median(times)), 2)}
+    engine.close()
+    out["note"] = "one %dx%d frame per call, 74 KB of latents in, 3 MiB of pixels out over PCIe, synchronous; launch sequence replayed from a hipGraph" % (resolution, resolution)
+    return out
+
+
+def blend_workload(args, device) -> int:
+    """`--workload blend`: only the configs[2] line (with --networks / --output-side: configs[4] / configs[3] on one GPU)."""
+    print(json.dumps(blend_measurement(args.resolution, args.batch, args.networks, args.output_side, device, not args.no_cpu_baseline)), flush=True)
     return 0
 
 
@@ -171,6 +232,7 @@ def main() -> int:
     parser.add_argument("--batch", type=int, default=32, help="frames per step per GPU")
     parser.add_argument("--resolution", type=int, default=1024)
     parser.add_argument("--no-cpu-baseline", action="store_true")
+    parser.add_argument("--no-extras", action="store_true", help="skip the extra measurements (configs[2], 3 networks, 2160 output, one-frame latency) a 1-GPU run adds to the line")
     parser.add_argument("--print-steps", action="store_true", help="per-launch table on stderr")
     parser.add_argument(
         "--workload", choices=["synthesis", "blend"], default="synthesis",
@@ -336,9 +398,18 @@ def main() -> int:
         }
         if world_size == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(resolution, variables)
+    engine.close()
+    if rank == 0:
+        if world_size == 1 and not args.no_extras:
+            # measured beside the contract line, same process, same GPU (each is also reachable alone: --workload blend)
+            result["extras"] = {
+                "config_3_blend": blend_measurement(resolution, batch, 1, None, device, not args.no_cpu_baseline),
+                "config_5_three_resident_networks": blend_measurement(resolution, batch, 3, None, device, False),
+                "config_4_output_side_2160_one_gpu": blend_measurement(resolution, batch, 1, 2160, device, False),
+                "one_frame_latency": one_frame_latency(resolution, device),
+            }
         print(json.dumps(result), flush=True)
 
-    engine.close()
     if world_size > 1:
         dist.barrier()
         dist.destroy_process_group()

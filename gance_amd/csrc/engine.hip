@@ -212,8 +212,15 @@ struct gance_workspace {
     hipEvent_t last_use = nullptr;
     bool used = false;
     size_t bytes = 0;
+    // host-buffer entry points: their own stream and pinned staging (latents in, uint8 frames out)
+    hipStream_t host_stream = nullptr;
+    float* pinned_in = nullptr;
+    uint8_t* pinned_out = nullptr;
     ~gance_workspace() {
         gance::DeviceGuard guard(device);
+        if (host_stream) hipStreamDestroy(host_stream);
+        if (pinned_in) hipHostFree(pinned_in);
+        if (pinned_out) hipHostFree(pinned_out);
         hipFree(dlat);
         hipFree(map_a);
         hipFree(map_b_buf);
@@ -228,6 +235,11 @@ struct gance_workspace {
         hipFree(u8buf);
         if (last_use) hipEventDestroy(last_use);
     }
+};
+
+struct GraphEntry {
+    hipGraphExec_t exec = nullptr;
+    bool warmed = false;
 };
 
 struct gance_engine {
@@ -257,6 +269,8 @@ struct gance_engine {
 
     // workspace (shared with the other engines of the same device, resolution and max_batch)
     std::shared_ptr<gance_workspace> ws;
+    // captured launch sequences of the host-buffer entry points, by (batch, entry kind, psi bits, float image wanted)
+    std::map<std::tuple<int, int, unsigned, int>, GraphEntry> graphs;
     std::vector<int> t_units;     // max_units of each up layer's parity planes
     size_t slab_floats = 0, y_floats = 0;
 
@@ -283,6 +297,8 @@ void free_engine(gance_engine* e) {
     hipFree(e->blk_row);
     hipFree(e->demod_layers);
     if (e->ws && e->ws->used) hipEventSynchronize(e->ws->last_use);  // nothing of this engine still runs on the shared scratch
+    for (auto& kv : e->graphs)
+        if (kv.second.exec) hipGraphExecDestroy(kv.second.exec);
     e->ws.reset();  // the last engine of a (device, resolution, max_batch) frees the workspace
     delete e;
 }
@@ -666,8 +682,11 @@ int acquire_workspace(gance_engine* e) {
     ok = ok && alloc((void**)&ws->slabs, e->slab_floats * sizeof(float), false) &&
          alloc((void**)&ws->ybuf[0], e->y_floats * sizeof(float), false) && alloc((void**)&ws->ybuf[1], e->y_floats * sizeof(float), false) &&
          alloc((void**)&ws->u8buf, e->y_floats, false);
-    if (ok && hipEventCreateWithFlags(&ws->last_use, hipEventDisableTiming) != hipSuccess) {
-        fail(GANCE_ERR_HIP, "hipEventCreate failed");
+    if (ok && (hipEventCreateWithFlags(&ws->last_use, hipEventDisableTiming) != hipSuccess ||
+               hipStreamCreateWithFlags(&ws->host_stream, hipStreamNonBlocking) != hipSuccess ||
+               hipHostMalloc((void**)&ws->pinned_in, (size_t)Bmax * e->num_rows * kDlatent * sizeof(float), hipHostMallocDefault) != hipSuccess ||
+               hipHostMalloc((void**)&ws->pinned_out, e->y_floats, hipHostMallocDefault) != hipSuccess)) {
+        fail(GANCE_ERR_HIP, "stream / event / pinned staging creation failed");
         ok = false;
     }
     if (!ok) return GANCE_ERR_OUT_OF_MEMORY;  // (the partial workspace frees itself; the message is already recorded)
@@ -969,15 +988,9 @@ int gance_synthesize_w(gance_engine* engine, const float* d_dlatents, int32_t ba
     return synthesize_from_dlat(engine, d_dlatents, batch, d_out_u8, d_out_f32, (hipStream_t)stream);
 }
 
-int gance_synthesize_z(gance_engine* engine, const float* d_z, int32_t batch, float truncation_psi,
-                       uint8_t* d_out_u8, float* d_out_f32, void* stream_) {
-    if (int rc = check_call(engine, d_z, batch)) return rc;
-    gance::DeviceGuard guard(engine->cfg.device);
-    GANCE_HIP_CHECK(guard.status());
-    hipStream_t stream = (hipStream_t)stream_;
-    // filtered profiling keeps its records across calls (bench.py averages them); else one call's worth
-    if (engine->profile_only.empty() || engine->steps_used >= 4096) engine->steps_used = 0;
-    WorkspaceTurn turn(engine->ws.get(), stream);
+// mapping network + truncation + synthesis (no ordering against other users of the workspace: the callers do that)
+static int synthesize_from_z(gance_engine* engine, const float* d_z, int32_t batch, float truncation_psi, uint8_t* d_out_u8,
+                             float* d_out_f32, hipStream_t stream) {
     const float* in = d_z;
     float* bufs[2] = {engine->ws->map_a, engine->ws->map_b_buf};
     for (int i = 0; i < kMappingLayers; ++i) {
@@ -997,28 +1010,92 @@ int gance_synthesize_z(gance_engine* engine, const float* d_z, int32_t batch, fl
     return synthesize_from_dlat(engine, engine->ws->dlat, batch, d_out_u8, d_out_f32, stream);
 }
 
+int gance_synthesize_z(gance_engine* engine, const float* d_z, int32_t batch, float truncation_psi,
+                       uint8_t* d_out_u8, float* d_out_f32, void* stream_) {
+    if (int rc = check_call(engine, d_z, batch)) return rc;
+    gance::DeviceGuard guard(engine->cfg.device);
+    GANCE_HIP_CHECK(guard.status());
+    hipStream_t stream = (hipStream_t)stream_;
+    // filtered profiling keeps its records across calls (bench.py averages them); else one call's worth
+    if (engine->profile_only.empty() || engine->steps_used >= 4096) engine->steps_used = 0;
+    WorkspaceTurn turn(engine->ws.get(), stream);
+    return synthesize_from_z(engine, d_z, batch, truncation_psi, d_out_u8, d_out_f32, stream);
+}
+
+// The host-buffer entry (the reference's own call form: one frame per call, numpy in, numpy out,
+// network_functions.py:289-301). Latency path: pinned staging buffers, a private stream, and the ~50-launch
+// sequence of a (batch, entry, psi, outputs) combination captured ONCE into a hipGraph and replayed
+// (the first call of a combination runs eagerly: it also performs the launchers' one-time attribute setup,
+// which may not happen under capture). GANCE_TUNE_GRAPH=0 keeps every call eager.
 static int host_call(gance_engine* e, const float* h_in, size_t in_floats, int batch, bool is_z,
                      float psi, uint8_t* h_u8, float* h_f32) {
     if (int rc = check_call(e, h_in, batch)) return rc;
     gance::DeviceGuard guard(e->cfg.device);
     GANCE_HIP_CHECK(guard.status());
+    gance_workspace* ws = e->ws.get();
     const size_t px = (size_t)e->cfg.resolution * e->cfg.resolution * 3;
-    float* d_in = is_z ? e->ws->z_in : e->ws->dlat;
-    if (e->ws->used) GANCE_HIP_CHECK(hipEventSynchronize(e->ws->last_use));  // another engine's call may still read the shared scratch
-    GANCE_HIP_CHECK(hipMemcpy(d_in, h_in, in_floats * sizeof(float), hipMemcpyHostToDevice));
+    float* d_in = is_z ? ws->z_in : ws->dlat;
+    if (ws->used) GANCE_HIP_CHECK(hipEventSynchronize(ws->last_use));  // another engine's call may still read the shared scratch
+    hipStream_t hs = ws->host_stream;
+    std::memcpy(ws->pinned_in, h_in, in_floats * sizeof(float));
+    GANCE_HIP_CHECK(hipMemcpyAsync(d_in, ws->pinned_in, in_floats * sizeof(float), hipMemcpyHostToDevice, hs));
     e->keep_skip_image = h_f32 != nullptr;
-    int rc = is_z ? gance_synthesize_z(e, d_in, batch, psi, e->ws->u8buf, nullptr, nullptr)
-                  : gance_synthesize_w(e, d_in, batch, e->ws->u8buf, nullptr, nullptr);
+    auto run = [&]() {
+        return is_z ? synthesize_from_z(e, d_in, batch, psi, ws->u8buf, nullptr, hs)
+                    : synthesize_from_dlat(e, d_in, batch, ws->u8buf, nullptr, hs);
+    };
+    static const bool graphs_enabled = [] { const char* v = std::getenv("GANCE_TUNE_GRAPH"); return !(v && std::atoi(v) == 0); }();
+    const bool plain = !graphs_enabled || (e->cfg.flags & GANCE_FLAG_PROFILE_STEPS) || e->debug_stop_after > 0;
+    int rc = GANCE_OK;
+    if (plain) {
+        if (e->profile_only.empty() || e->steps_used >= 4096) e->steps_used = 0;
+        rc = run();
+    } else {
+        unsigned psi_bits = 0;
+        std::memcpy(&psi_bits, &psi, sizeof(psi_bits));
+        const auto key = std::make_tuple(batch, is_z ? 1 : 0, is_z ? psi_bits : 0u, h_f32 != nullptr ? 1 : 0);
+        GraphEntry& entry = e->graphs[key];
+        if (entry.exec != nullptr) {
+            GANCE_HIP_CHECK(hipGraphLaunch(entry.exec, hs));
+        } else if (!entry.warmed) {
+            rc = run();
+            entry.warmed = true;
+        } else {
+            hipGraph_t graph = nullptr;
+            GANCE_HIP_CHECK(hipStreamBeginCapture(hs, hipStreamCaptureModeThreadLocal));
+            rc = run();
+            const hipError_t end = hipStreamEndCapture(hs, &graph);
+            if (rc == GANCE_OK && end == hipSuccess && hipGraphInstantiate(&entry.exec, graph, nullptr, nullptr, 0) == hipSuccess) {
+                hipGraphDestroy(graph);
+                GANCE_HIP_CHECK(hipGraphLaunch(entry.exec, hs));
+            } else {
+                // capture refused (it never should): fall back to eager launches for this combination for good
+                if (graph != nullptr) hipGraphDestroy(graph);
+                (void)hipGetLastError();
+                entry.exec = nullptr;
+                entry.warmed = false;
+                rc = run();
+            }
+        }
+    }
     e->keep_skip_image = false;
     if (rc) return rc;
-    GANCE_HIP_CHECK(hipDeviceSynchronize());
-    if (e->debug_stop_after > 0) return GANCE_OK;
-    if (h_u8) GANCE_HIP_CHECK(hipMemcpy(h_u8, e->ws->u8buf, px * batch, hipMemcpyDeviceToHost));
+    if (e->debug_stop_after > 0) {
+        GANCE_HIP_CHECK(hipStreamSynchronize(hs));
+        hipEventRecord(ws->last_use, hs);
+        ws->used = true;
+        return GANCE_OK;
+    }
+    if (h_u8) GANCE_HIP_CHECK(hipMemcpyAsync(ws->pinned_out, ws->u8buf, px * batch, hipMemcpyDeviceToHost, hs));
+    hipEventRecord(ws->last_use, hs);
+    ws->used = true;
+    GANCE_HIP_CHECK(hipStreamSynchronize(hs));
+    if (h_u8) std::memcpy(h_u8, ws->pinned_out, px * batch);
     if (h_f32) {
         // the final skip image is in whichever ybuf the last ToRGB wrote
         const int n_rgb = (int)e->rgbs.size();
         const int ycur = (n_rgb - 1) & 1;
-        GANCE_HIP_CHECK(hipMemcpy(h_f32, e->ws->ybuf[ycur], px * batch * sizeof(float), hipMemcpyDeviceToHost));
+        GANCE_HIP_CHECK(hipMemcpy(h_f32, ws->ybuf[ycur], px * batch * sizeof(float), hipMemcpyDeviceToHost));
     }
     return GANCE_OK;
 }

@@ -165,7 +165,9 @@ class MultiNetwork:
     network files are resident at once; an index change is a dictionary lookup.
     """
 
-    def __init__(self: "MultiNetwork", network_paths: List[Path], load: bool = False) -> None:
+    def __init__(self: "MultiNetwork", network_paths: List[Path], load: bool = False, max_batch: int = DEFAULT_MAX_BATCH) -> None:
+        """`max_batch` (not in the reference): frames per engine call of the batched entry points."""
+        self._max_batch = max_batch
         self._network_paths: List[Path] = network_paths
         self._loaded: Optional[Dict[Path, LoadedNetwork]] = None
         self._expected_vector_length: Optional[int] = None
@@ -199,7 +201,7 @@ class MultiNetwork:
             for path in self._network_paths:
                 if path not in loaded:
                     LOGGER.info(f"Loading network: {path}")
-                    loaded[path] = LoadedNetwork(path)
+                    loaded[path] = LoadedNetwork(path, max_batch=self._max_batch)
         except Exception:
             for network in loaded.values():
                 network.stop()

@@ -8,8 +8,9 @@ constants of gance/projection/projector_file_writer.py:71-88,91-169.
 
 Two containers:
 * HDF5, the reference's own format (groups `final_latents/final_latents_{i}` of shape (1, W, L)
-  float32, `target_images/...`, attributes as file attrs, v1 -> v2 attribute rename) -- used when
-  `h5py` is importable (it is not in this image, so this branch is covered only structurally);
+  float32, gzip-9 + shuffle, `target_images/...`, attributes as file attrs, v1 -> v2 attribute rename),
+  read with h5py when it is importable and otherwise with this package's own pure-Python reader of the HDF5
+  subset the reference's writer produces (hdf5_lite.py; real h5py-written fixtures in tests/golden/);
 * `.npz`, this implementation's container for environments without h5py: arrays `final_latents`
   [F][W][L] float32, optional `target_images` / `final_images` [F][H][W][3] uint8 and a JSON
   string `attributes` with the same attribute names.
@@ -93,14 +94,16 @@ class ProjectionFileReader:
             self._npz = np.load(str(self._path), allow_pickle=False)
             self._projection_attributes = ProjectionAttributes.from_dict(json.loads(str(self._npz["attributes"])))
         else:
+            # h5py when it is installed; otherwise the pure-Python reader of the subset of HDF5 the reference's
+            # writer produces (gance_amd/projection/hdf5_lite.py, pinned by real h5py-written fixtures)
             try:
                 import h5py  # pylint: disable=import-outside-toplevel
-            except ImportError as error:
-                raise RuntimeError(
-                    f"{self._path}: reading the HDF5 projection format needs h5py, which is not installed; "
-                    "convert the file to the .npz container (see gance_amd.projection.projection_file_reader)"
-                ) from error
-            self._h5 = h5py.File(name=str(self._path), mode="r")
+
+                self._h5 = h5py.File(name=str(self._path), mode="r")
+            except ImportError:
+                from gance_amd.projection import hdf5_lite  # pylint: disable=import-outside-toplevel
+
+                self._h5 = hdf5_lite.File(self._path, mode="r")
             self._projection_attributes = ProjectionAttributes.from_dict(dict(self._h5.attrs))
 
     @property

@@ -242,6 +242,115 @@ def apply_eye_tracking_overlay(  # pylint: disable=too-many-arguments,too-many-l
     return overlay_common.write_boxes_onto_frames_device(foreground, synthesized, written)
 
 
+class _BlendInputs(NamedTuple):
+    """What rank 0 prepares before synthesis starts (everything is None / 0 on the other ranks)."""
+
+    dlatents: Optional[torch.Tensor]
+    indices: Optional[torch.Tensor]
+    num_frames: int
+    target_images: Optional[np.ndarray]
+    audio: Optional[np.ndarray]
+    frame_multiplier: int
+
+
+def _prepare_blend_inputs(  # pylint: disable=too-many-arguments,too-many-locals
+    wav: List[str],
+    networks: MultiNetwork,
+    frames_to_visualize: Optional[int],
+    output_fps: float,
+    alpha: float,
+    fft_roll_enabled: bool,
+    fft_amplitude_range: Tuple[int, int],
+    projection_file_path: str,
+    blend_depth: int,
+    want_target_images: bool,
+    device: torch.device,
+) -> _BlendInputs:
+    """Rank 0: projection file + WAV -> per-frame latent matrices and network indices in HBM (the reference's checks included)."""
+    vector_length = networks.expected_vector_length
+    target_images = None
+    # the audio -> latent stage has global dependencies over a few MB: once, on rank 0
+    with projection_file_reader.load_projection_file(Path(projection_file_path)) as reader:
+        final_latents = projection_file_reader.final_latents_matrices_label(reader)
+        attributes = reader.projection_attributes
+        if want_target_images:
+            target_images = np.stack(list(reader.target_images))
+    final_latents_in_file = underlying_length(final_latents.data) / vector_length
+    LOGGER.info(
+        f"Reading projection file. Complete: {attributes.complete}, "
+        f"Final Latent Count: {final_latents_in_file}, Processed Frames: {attributes.projection_frame_count}"
+    )
+    if not attributes.complete or abs(final_latents_in_file - attributes.projection_frame_count) > 2:
+        raise ValueError("Invalid Projection File, cannot continue.")
+    frame_multiplier = divisor.divide_no_remainder(numerator=output_fps, denominator=attributes.projection_fps)
+    num_output_frames = int(frame_multiplier * final_latents_in_file)
+    audio = music.read_wavs_scale_for_video(
+        wavs=[Path(path) for path in wav], vector_length=vector_length, target_num_vectors=num_output_frames
+    ).wav_data
+    blend = visualization_inputs.alpha_blend_projection_file_device(
+        final_latents.data, alpha, fft_roll_enabled, fft_amplitude_range, blend_depth, audio, vector_length,
+        len(networks.network_indices), device=device.index,
+    )
+    dlatents, indices = blend.dlatents, blend.network_indices
+    blend.blend.close()
+    if frames_to_visualize is not None:
+        dlatents, indices = dlatents[:frames_to_visualize], indices[:frames_to_visualize]
+    return _BlendInputs(dlatents, indices, int(dlatents.shape[0]), target_images, audio, int(frame_multiplier))
+
+
+def projection_file_blend_frame_chunks(  # pylint: disable=too-many-arguments,too-many-locals
+    wav: List[str],
+    network_paths: List[Path],
+    frames_to_visualize: Optional[int],
+    output_fps: float,
+    output_side_length: int,
+    alpha: float,
+    fft_roll_enabled: bool,
+    fft_amplitude_range: Tuple[int, int],
+    projection_file_path: str,
+    blend_depth: int,
+    frames_per_call: int = DEFAULT_MAX_BATCH,
+) -> Iterator[Tuple[int, int, np.ndarray]]:
+    """
+    The frame stream of the reference's pipeline (gance/projection_file_blend.py:343 hands an iterator of frames to
+    the video writer): a generator of (first_frame_index, total_frames, frames [n, S, S, 3] uint8) in frame order.
+    Nothing holds all frames: per chunk, every rank synthesises `frames_per_call` frames, one gather lands the chunk
+    in order on rank 0 while the next chunk is already being synthesised, and rank 0 drains it to a pinned host
+    ring (`frames` is a view of a ring slot: consume or copy it before advancing the generator twice more).
+    Collective under `torch.distributed`: every rank must exhaust the generator; only rank 0 receives chunks.
+    """
+    rank = dist.get_rank() if dist.is_initialized() else 0
+    world_size = dist.get_world_size() if dist.is_initialized() else 1
+    device = torch.device("cuda", torch.cuda.current_device())
+    networks = MultiNetwork(network_paths=network_paths, load=True, max_batch=frames_per_call)
+    try:
+        inputs = _BlendInputs(None, None, 0, None, None, 1)
+        if rank == 0:
+            inputs = _prepare_blend_inputs(
+                wav, networks, frames_to_visualize, output_fps, alpha, fft_roll_enabled, fft_amplitude_range,
+                projection_file_path, blend_depth, False, device,
+            )
+        num_frames = inputs.num_frames
+        if world_size > 1:
+            count = [num_frames]
+            dist.broadcast_object_list(count, src=0)
+            num_frames = count[0]
+        dlatents = frame_sharding.scatter_for_stream(inputs.dlatents, num_frames, frames_per_call, device)
+        indices = frame_sharding.scatter_for_stream(inputs.indices, num_frames, frames_per_call, device)
+        side = _common_output_side(networks, np.asarray(networks.network_indices), output_side_length)
+
+        def synthesize_piece(offset: int, count: int) -> torch.Tensor:
+            return synthesize_device_frames_network_major(
+                dlatents[offset : offset + count], indices[offset : offset + count], networks, side, frames_per_call
+            )
+
+        for first, frames in frame_sharding.ordered_frame_stream(synthesize_piece, num_frames, frames_per_call, (side, side, 3), device):
+            yield first, num_frames, frames
+        torch.cuda.synchronize(device)
+    finally:
+        networks.unload()
+
+
 def projection_file_blend_frames(  # pylint: disable=too-many-arguments,too-many-locals
     wav: List[str],
     network_paths: List[Path],
@@ -256,53 +365,43 @@ def projection_file_blend_frames(  # pylint: disable=too-many-arguments,too-many
     overlay: Optional[OverlayParameters] = None,
 ) -> Optional[np.ndarray]:
     """
-    The pipeline of `projection_file_blend_api`, returning the frames [N][S][S][3] uint8 (on rank
-    0; None on other ranks when running distributed). With `overlay`, rank 0 runs the
-    eye-tracking overlay on the gathered frames before they leave HBM.
+    The pipeline of `projection_file_blend_api`, returning ALL frames [N][S][S][3] uint8 at once (on rank 0;
+    None on other ranks when running distributed): the stream of `projection_file_blend_frame_chunks` collected
+    into one array. With `overlay`, rank 0 runs the eye-tracking overlay on the gathered frames before they
+    leave HBM (the run-length filter of the overlay needs every frame's gate decision before the first write,
+    so that path keeps the frames resident instead of streaming them).
     """
+    if overlay is None:
+        collected: Optional[np.ndarray] = None
+        for first, total, frames in projection_file_blend_frame_chunks(
+            wav, network_paths, frames_to_visualize, output_fps, output_side_length, alpha, fft_roll_enabled,
+            fft_amplitude_range, projection_file_path, blend_depth,
+        ):
+            if collected is None:
+                collected = np.empty((total, *frames.shape[1:]), dtype=np.uint8)
+            collected[first : first + len(frames)] = frames
+        rank = dist.get_rank() if dist.is_initialized() else 0
+        if rank == 0 and collected is None:
+            collected = np.empty((0, output_side_length, output_side_length, 3), dtype=np.uint8)
+        return collected
     rank = dist.get_rank() if dist.is_initialized() else 0
     device = torch.device("cuda", torch.cuda.current_device())
     networks = MultiNetwork(network_paths=network_paths, load=True)
     try:
-        vector_length = networks.expected_vector_length
-        dlatents = indices = None
-        num_frames = 0
-        target_images = audio = None
-        frame_multiplier = 1
+        inputs = _BlendInputs(None, None, 0, None, None, 1)
         if rank == 0:
-            # the audio -> latent stage has global dependencies over a few MB: once, on rank 0
-            with projection_file_reader.load_projection_file(Path(projection_file_path)) as reader:
-                final_latents = projection_file_reader.final_latents_matrices_label(reader)
-                attributes = reader.projection_attributes
-                if overlay is not None:
-                    target_images = np.stack(list(reader.target_images))
-            final_latents_in_file = underlying_length(final_latents.data) / vector_length
-            LOGGER.info(
-                f"Reading projection file. Complete: {attributes.complete}, "
-                f"Final Latent Count: {final_latents_in_file}, Processed Frames: {attributes.projection_frame_count}"
+            inputs = _prepare_blend_inputs(
+                wav, networks, frames_to_visualize, output_fps, alpha, fft_roll_enabled, fft_amplitude_range,
+                projection_file_path, blend_depth, True, device,
             )
-            if not attributes.complete or abs(final_latents_in_file - attributes.projection_frame_count) > 2:
-                raise ValueError("Invalid Projection File, cannot continue.")
-            frame_multiplier = divisor.divide_no_remainder(numerator=output_fps, denominator=attributes.projection_fps)
-            num_output_frames = int(frame_multiplier * final_latents_in_file)
-            audio = music.read_wavs_scale_for_video(
-                wavs=[Path(path) for path in wav], vector_length=vector_length, target_num_vectors=num_output_frames
-            ).wav_data
-            blend = visualization_inputs.alpha_blend_projection_file_device(
-                final_latents.data, alpha, fft_roll_enabled, fft_amplitude_range, blend_depth, audio, vector_length,
-                len(networks.network_indices), device=device.index,
-            )
-            dlatents, indices = blend.dlatents, blend.network_indices
-            blend.blend.close()
-            if frames_to_visualize is not None:
-                dlatents, indices = dlatents[:frames_to_visualize], indices[:frames_to_visualize]
-            num_frames = int(dlatents.shape[0])
         frames = shard_synthesize_gather(
-            dlatents, indices, num_frames, networks, output_side_length, device, keep_on_device=overlay is not None
+            inputs.dlatents, inputs.indices, inputs.num_frames, networks, output_side_length, device, keep_on_device=True
         )
-        if overlay is None or frames is None:
-            return frames
-        blended = apply_eye_tracking_overlay(frames, target_images, int(frame_multiplier), overlay, audio, vector_length)
+        if frames is None:
+            return None
+        blended = apply_eye_tracking_overlay(
+            frames, inputs.target_images, inputs.frame_multiplier, overlay, inputs.audio, networks.expected_vector_length
+        )
         return blended.cpu().numpy()
     finally:
         networks.unload()
@@ -352,6 +451,21 @@ def projection_file_blend_api(  # pylint: disable=too-many-arguments,too-many-lo
         if overlay_enabled
         else None
     )
+    if overlay is None:
+        # frame chunks go straight from the pinned ring into the (memory-mapped) output file: nothing holds the video
+        writer = None
+        for first, total, frames in projection_file_blend_frame_chunks(
+            wav, network_paths, frames_to_visualize, output_fps, output_side_length, alpha, fft_roll_enabled,
+            fft_amplitude_range, projection_file_path, blend_depth,
+        ):
+            if output_path is None:
+                continue
+            if writer is None:
+                writer = np.lib.format.open_memmap(output_path, mode="w+", dtype=np.uint8, shape=(total, *frames.shape[1:]))
+            writer[first : first + len(frames)] = frames
+        if writer is not None:
+            writer.flush()
+        return
     frames = projection_file_blend_frames(
         wav, network_paths, frames_to_visualize, output_fps, output_side_length, alpha, fft_roll_enabled,
         fft_amplitude_range, projection_file_path, blend_depth, overlay,

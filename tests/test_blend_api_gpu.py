@@ -182,3 +182,29 @@ def test_projection_file_blend_with_eye_tracking_overlay(tmp_path: Path) -> None
             [str(wav_path)], None, [network_path], None, fps_out, out_side, None, None, None, 0.25, True, (-5, 5),
             str(projection_path), 12, None, None, 10, 5.0, 3,
         )
+
+
+def test_blend_from_a_real_hdf5_projection_file(tmp_path: Path, golden_dir: Path) -> None:
+    """The reference's own container end to end: an h5py-written projection file (12 projected frames, 15 fps) -> 24 frames at 30 fps."""
+    L, fps_out, side = 512, 30.0, 64
+    expected = np.load(golden_dir / "projection_hdf5_expected.npz")
+    latents = np.concatenate(list(expected["projection_v2_latents"]), axis=-1)  # (18, F*L), what final_latents_matrices_label builds
+    num_frames = 24
+    audio = synthetic.synthetic_audio(num_frames, L, seed=71, frames_per_second=fps_out)
+    wav_path = tmp_path / "audio.wav"
+    wavfile.write(str(wav_path), int(L * fps_out), audio)
+    network_path = tmp_path / "net.pkl"
+    network_file.write_random_network(network_path, side, seed=3)
+    frames = projection_file_blend.projection_file_blend_frames(
+        wav=[str(wav_path)], network_paths=[network_path], frames_to_visualize=None, output_fps=fps_out, output_side_length=side,
+        alpha=0.25, fft_roll_enabled=True, fft_amplitude_range=(-5, 5), projection_file_path=str(golden_dir / "projection_v2.hdf5"),
+        blend_depth=12,
+    )
+    assert frames.shape == (num_frames, side, side, 3)
+    want_blend = audio_ref.alpha_blend_projection_file(latents, 0.25, True, (-5, 5), 12, audio, L, [0])
+    dlatents = audio_ref.sub_vectors(want_blend.combined, L).astype(np.float32)
+    rows = int(np.log2(side)) * 2 - 2
+    variables = network_file.load_network(network_path).variables
+    want = stylegan2_ref.convert_images_to_uint8(stylegan2_ref.synthesize_w(dlatents[:, :rows, :], variables, side))
+    diff = np.abs(frames.astype(np.int16) - want.astype(np.int16))
+    assert int(diff.max()) <= 1 and float((diff > 0).mean()) < 1e-3

@@ -77,3 +77,52 @@ def test_single_process_is_a_passthrough() -> None:
     frames = torch.zeros((5, 4, 4, 3), dtype=torch.uint8)
     out, work = frame_sharding.gather_frames(frames, 5)
     assert work is None and out.shape == (5, 4, 4, 3)
+
+
+def test_stream_orders_partition_the_frames() -> None:
+    for num_frames in (0, 1, 7, 23, 64, 1800):
+        for world_size in (1, 2, 3, 8):
+            for per_rank in (1, 4, 16):
+                seen = sorted(sum((frame_sharding.stream_order(num_frames, world_size, per_rank, r) for r in range(world_size)), []))
+                assert seen == list(range(num_frames))
+                chunks = frame_sharding.stream_chunks(num_frames, world_size, per_rank)
+                for chunk in range(chunks):  # a chunk's pieces, rank by rank, are consecutive frames
+                    pieces = [frame_sharding.stream_piece(num_frames, world_size, per_rank, chunk, r) for r in range(world_size)]
+                    flat = [f for start, end in pieces for f in range(start, end)]
+                    first = chunk * world_size * per_rank
+                    assert flat == list(range(first, min(num_frames, first + world_size * per_rank)))
+
+
+def _stream_worker(rank: int, world_size: int, port: int, num_frames: int, per_rank: int) -> None:
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world_size)
+    try:
+        device = torch.device("cpu")
+        all_inputs = torch.arange(num_frames, dtype=torch.float32).reshape(num_frames, 1) if rank == 0 else None
+        mine = frame_sharding.scatter_for_stream(all_inputs, num_frames, per_rank, device)
+        assert mine[:, 0].tolist() == [float(f) for f in frame_sharding.stream_order(num_frames, world_size, per_rank, rank)]
+
+        def synthesize_piece(offset: int, count: int) -> torch.Tensor:
+            # "frame f" = a 2x2x3 image filled with f mod 251, made from the scattered input (not from the index)
+            values = mine[offset : offset + count, 0].to(torch.int64) % 251
+            return values.to(torch.uint8).reshape(count, 1, 1, 1).expand(count, 2, 2, 3).contiguous()
+
+        got = []
+        for first, frames in frame_sharding.ordered_frame_stream(synthesize_piece, num_frames, per_rank, (2, 2, 3), device):
+            assert rank == 0
+            assert first == len(got)
+            got.extend(int(frame[0, 0, 0]) for frame in frames)
+            assert all(bool((frame == frame[0, 0, 0]).all()) for frame in frames)
+        if rank == 0:
+            assert got == [f % 251 for f in range(num_frames)]
+        else:
+            assert not got
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world_size,num_frames,per_rank", [(2, 37, 4), (3, 50, 3), (2, 8, 4), (2, 3, 4)])
+def test_ordered_frame_stream_gloo(world_size: int, num_frames: int, per_rank: int) -> None:
+    """The product's multi-rank path: scatter of per-chunk latent pieces, chunked synthesis, ordered gather, host drain."""
+    mp.spawn(_stream_worker, args=(world_size, _free_port(), num_frames, per_rank), nprocs=world_size, join=True)

@@ -232,6 +232,46 @@ def test_bench_configuration_batch_32_matches_oracle_and_single_calls(library) -
         _assert_same_frames(alone[k][0], frames[i])
 
 
+def test_host_entry_graph_replay_equals_the_eager_device_entry(library) -> None:
+    """
+    The one-frame host-buffer entry (the reference's call form) runs eagerly the first time, captures its launch
+    sequence into a hipGraph the second time and replays it afterwards: every call must return what the eager
+    device-pointer entry returns for the same input, for both entry kinds, changing inputs, psi and batch size.
+    """
+    resolution = 256
+    variables = sg2_spec.make_random_variables(resolution, seed=6, perturb=True)
+    engine = hip_lib.Engine(variables, resolution, max_batch=2)
+    rng = np.random.RandomState(17)
+    try:
+        def eager_z(z, psi):
+            d_z = torch.from_numpy(z).cuda()
+            out = torch.empty((len(z), resolution, resolution, 3), dtype=torch.uint8, device="cuda")
+            engine.synthesize_z_device(d_z.data_ptr(), len(z), psi, out.data_ptr(), 0, torch.cuda.current_stream().cuda_stream)
+            torch.cuda.synchronize()
+            return out.cpu().numpy()
+
+        for call in range(5):  # eager, capture, replay, replay, replay
+            z = rng.randn(1, 512).astype(np.float32)
+            assert np.array_equal(engine.synthesize_z(z, truncation_psi=1.2), eager_z(z, 1.2)), f"call {call}"
+        z2 = rng.randn(2, 512).astype(np.float32)
+        for call in range(3):  # another batch size and psi: their own graph
+            assert np.array_equal(engine.synthesize_z(z2, truncation_psi=0.7), eager_z(z2, 0.7)), f"call {call}"
+        for call in range(4):  # the matrix entry, with the float image read back every other call
+            dlatents = rng.randn(1, engine.num_layers, 512).astype(np.float32)
+            d_w = torch.from_numpy(dlatents).cuda()
+            want = torch.empty((1, resolution, resolution, 3), dtype=torch.uint8, device="cuda")
+            engine.synthesize_w_device(d_w.data_ptr(), 1, want.data_ptr(), 0, torch.cuda.current_stream().cuda_stream)
+            torch.cuda.synchronize()
+            if call % 2:
+                frames, image = engine.synthesize_w(dlatents, want_float=True)
+                assert np.isfinite(image).all()
+            else:
+                frames = engine.synthesize_w(dlatents)
+            assert np.array_equal(frames, want.cpu().numpy()), f"call {call}"
+    finally:
+        engine.close()
+
+
 def test_calls_are_validated(library) -> None:
     variables = sg2_spec.make_random_variables(8, seed=0)
     engine = hip_lib.Engine(variables, 8, max_batch=2)
