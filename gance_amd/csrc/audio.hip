@@ -425,19 +425,32 @@ static std::vector<double> fourier_resample_matrix(int n_in, int n_out) {
     const long double two_pi = 6.283185307179586476925286766559005768L;
     const int N = n_in < n_out ? n_in : n_out;
     const int nyq = N / 2 + 1;
+    // twiddles of the kept terms: X_k of the unit impulse at n is exp(-2 pi i k n / n_in), the output term of Y_k at j is
+    // Re(Y_k exp(+2 pi i k j / n_out)); angles reduced modulo the period before the long-double cos / sin
+    std::vector<long double> xin_re((size_t)nyq * n_in), xin_im((size_t)nyq * n_in), out_c((size_t)nyq * n_out), out_s((size_t)nyq * n_out);
+    for (int k = 0; k < nyq; ++k) {
+        for (int n = 0; n < n_in; ++n) {
+            const long double angle = two_pi * (long double)(((long long)k * n) % n_in) / n_in;
+            xin_re[(size_t)k * n_in + n] = cosl(angle);
+            xin_im[(size_t)k * n_in + n] = -sinl(angle);
+        }
+        for (int j = 0; j < n_out; ++j) {
+            const long double angle = two_pi * (long double)(((long long)k * j) % n_out) / n_out;
+            out_c[(size_t)k * n_out + j] = cosl(angle);
+            out_s[(size_t)k * n_out + j] = sinl(angle);
+        }
+    }
     for (int n = 0; n < n_in; ++n)
         for (int j = 0; j < n_out; ++j) {
             long double acc = 1.0L;  // k = 0
             for (int k = 1; k < nyq; ++k) {
-                // X_k = exp(-2 pi i k n / n_in); the output term is Re(Y_k exp(+2 pi i k j / n_out)), twice unless
-                // k is the irfft's own Nyquist bin
-                long double re = cosl(two_pi * k * n / n_in), im = -sinl(two_pi * k * n / n_in);
+                long double re = xin_re[(size_t)k * n_in + n], im = xin_im[(size_t)k * n_in + n];
                 if (N % 2 == 0 && k == N / 2) {
                     if (n_out < n_in) { re *= 2.0L; im *= 2.0L; }
                     else if (n_in < n_out) { re *= 0.5L; im *= 0.5L; }
                 }
-                const long double c = cosl(two_pi * k * j / n_out), sn = sinl(two_pi * k * j / n_out);
-                const bool out_nyquist = (n_out % 2 == 0) && (k == n_out / 2);
+                const long double c = out_c[(size_t)k * n_out + j], sn = out_s[(size_t)k * n_out + j];
+                const bool out_nyquist = (n_out % 2 == 0) && (k == n_out / 2);  // the irfft's own Nyquist bin: real, counted once
                 acc += out_nyquist ? re * c : 2.0L * (re * c - im * sn);
             }
             M[(size_t)n * n_out + j] = (double)(acc / n_in);

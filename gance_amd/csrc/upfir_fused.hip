@@ -173,19 +173,44 @@ __global__ __launch_bounds__(256, 1) void upfir_fused_kernel(const UpFirArgs p) 
             }
         }
     };
-    auto stage_chunk = [&](int chunk, float* buf) {
-        const int w_soff = chunk * kWlFloats * 4;
-        const int x_soff = chunk * kKC * Hp * Wp * 4;
-#pragma unroll
-        for (int r = 0; r < kPiecesPerWave; ++r) {
-            const int g = wave + 4 * r;
-            if (g < kWlPieces) {
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, (lds_ptr_t)(buf + g * 256), 16, (g * 256 + lane * 4) * 4, w_soff, 0, 0);
-            } else if (g < kPieces && poff[r] >= 0) {
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(x_rsrc, (lds_ptr_t)(buf + kWlRegion + (g - kWlPieces) * 256), 16,
-                                                         poff[r], x_soff, 0, 0);
-            }
+    // one DMA piece (r = 0..7 of this wave: piece g = wave + 4 r) of `chunk` into ring slot `buf`. Which kind a piece is
+    // is known at compile time except for r = 2 (g = 8 is the last weight piece, 9..11 are patch pieces) and r = 7
+    // (g = 28, 29 exist, 30, 31 do not); only piece 29 is partial (16 of its 64 lanes).
+    auto stage_piece = [&](auto rtag, int chunk, float* buf) {
+        constexpr int r = decltype(rtag)::value;
+        const int g = wave + 4 * r;
+        const bool weights = r < 2 || (r == 2 && wave == 0);
+        if (weights) {
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, (lds_ptr_t)(buf + g * 256), 16, (g * 256 + lane * 4) * 4,
+                                                     chunk * kWlFloats * 4, 0, 0);
+        } else if (r < 7 || wave < 2) {
+            if (r < 7 || poff[r] >= 0)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(x_rsrc, (lds_ptr_t)(buf + kWlRegion + (g - kWlPieces) * 256), 16, poff[r],
+                                                         chunk * kKC * Hp * Wp * 4, 0, 0);
         }
+    };
+    // (r is a constant wherever this is called from an unrolled loop: the switch folds away)
+    auto stage_piece_n = [&](int r, int chunk, float* buf) {
+        switch (r) {
+            case 0: stage_piece(std::integral_constant<int, 0>{}, chunk, buf); break;
+            case 1: stage_piece(std::integral_constant<int, 1>{}, chunk, buf); break;
+            case 2: stage_piece(std::integral_constant<int, 2>{}, chunk, buf); break;
+            case 3: stage_piece(std::integral_constant<int, 3>{}, chunk, buf); break;
+            case 4: stage_piece(std::integral_constant<int, 4>{}, chunk, buf); break;
+            case 5: stage_piece(std::integral_constant<int, 5>{}, chunk, buf); break;
+            case 6: stage_piece(std::integral_constant<int, 6>{}, chunk, buf); break;
+            default: stage_piece(std::integral_constant<int, 7>{}, chunk, buf); break;
+        }
+    };
+    auto stage_chunk = [&](int chunk, float* buf) {
+        stage_piece(std::integral_constant<int, 0>{}, chunk, buf);
+        stage_piece(std::integral_constant<int, 1>{}, chunk, buf);
+        stage_piece(std::integral_constant<int, 2>{}, chunk, buf);
+        stage_piece(std::integral_constant<int, 3>{}, chunk, buf);
+        stage_piece(std::integral_constant<int, 4>{}, chunk, buf);
+        stage_piece(std::integral_constant<int, 5>{}, chunk, buf);
+        stage_piece(std::integral_constant<int, 6>{}, chunk, buf);
+        stage_piece(std::integral_constant<int, 7>{}, chunk, buf);
     };
 
     // ---- staggered start: identical blocks would otherwise all reach their epilogues together and their
@@ -260,30 +285,35 @@ __global__ __launch_bounds__(256, 1) void upfir_fused_kernel(const UpFirArgs p) 
             asm volatile("" ::: "memory");
             float* const cur_buf = ring0 + ring * kSlot;
             float* const nxt_buf = ring0 + (ring ^ 1) * kSlot;
+            // the next chunk of the stream (this step's k+1, or the first one of the next step): its eight DMA pieces
+            // are issued one at a time BETWEEN the MFMA groups below, where their issue cost hides behind the matrix pipe
+            int next_chunk = -1;
             if (UPFIR_DBG & 8) {
             } else if (k + 1 < nchunks) {
-                stage_chunk(k + 1, nxt_buf);
+                next_chunk = k + 1;
             } else if (si + 1 < step_last) {
                 stage_setup(y0 + kTH);
-                stage_chunk(0, nxt_buf);
+                next_chunk = 0;
             }
             ring ^= 1;
             const float* Wl = cur_buf + aoff;
             const float* Pl = cur_buf + kWlRegion;
             const float* sp = s_lds + k * kKC + lh;
 
-            if (UPFIR_DBG & 4) continue;
+            if (UPFIR_DBG & 4) {
+                if (next_chunk >= 0) stage_chunk(next_chunk, nxt_buf);
+                continue;
+            }
             if constexpr (!kFlush) {
-                // 36 steps u = kk * 9 + tap. The fragments of step u+1 are read from LDS before the MFMAs of
-                // step u are issued; the patch fragments of a kk (4 shifts x 5 tiles) are shared by its 9 taps.
-                float afrag[2], sfrag[2];
+                // Per pair of input channels (kk): 9 taps in four class groups EE (4 taps) EO (2) OE (2) OO (1). A group's
+                // taps each issue 4 MFMAs on the wave's main tiles; the wave that holds the group's class of the halo tile
+                // then adds that tile's MFMAs for the whole group (one uniform branch per group, not per tap). The weight
+                // fragment of the next tap and, at the last tap of a kk, the 20 patch fragments of the next kk are read from
+                // LDS before the current tap's MFMAs are issued; the style scale is read once per kk.
                 float bfrag[2][4][4];
                 float bhalo[2][4];
-                auto load_a = [&](int u) {
-                    const int kk = u / 9, t = u % 9;
-                    sfrag[u & 1] = sp[2 * kk];
-                    afrag[u & 1] = Wl[(t * kKC + 2 * kk) * kBM];
-                };
+                float anext;
+                float snext;
                 auto load_b = [&](int kk) {
 #pragma unroll
                     for (int sh = 0; sh < 4; ++sh) {
@@ -292,28 +322,54 @@ __global__ __launch_bounds__(256, 1) void upfir_fused_kernel(const UpFirArgs p) 
                         bhalo[kk & 1][sh] = Pl[boffh + 2 * kk * kPlane + shift_off(sh)];
                     }
                 };
-                load_a(0);
+                anext = Wl[0];
+                snext = sp[0];
                 load_b(0);
+                constexpr int kGroupFirst[4] = {0, 4, 6, 8}, kGroupTaps[4] = {4, 2, 2, 1};
 #pragma unroll
-                for (int u = 0; u < 9 * (kKC / 2); ++u) {
-                    const int kk = u / 9, t = u % 9;
-                    if (u + 1 < 9 * (kKC / 2)) {
-                        load_a(u + 1);
-                        if (t == 8) load_b(kk + 1);
+                for (int kk = 0; kk < kKC / 2; ++kk) {
+                    const float sv = snext;
+#pragma unroll
+                    for (int grp = 0; grp < 4; ++grp) {
+                        float a[4];
+#pragma unroll
+                        for (int i = 0; i < kGroupTaps[grp]; ++i) {
+                            const int t = kGroupFirst[grp] + i;
+                            const float araw = anext;
+                            if (t + 1 < 9) {
+                                anext = Wl[((t + 1) * kKC + 2 * kk) * kBM];
+                            } else if (kk + 1 < kKC / 2) {
+                                anext = Wl[(2 * (kk + 1)) * kBM];
+                                snext = sp[2 * (kk + 1)];
+                                load_b(kk + 1);
+                            }
+                            __builtin_amdgcn_sched_barrier(0);
+                            a[i] = araw * sv;
+#pragma unroll
+                            for (int jj = 0; jj < 4; ++jj)
+                                acc[grp][jj] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], bfrag[kk & 1][tap_shift(t)][jj], acc[grp][jj], 0, 0, 0);
+                            __builtin_amdgcn_sched_barrier(0);
+                            // one DMA piece of the next chunk behind every other tap's MFMAs (8 pieces over the first 16 taps)
+                            if ((kk * 9 + t) % 2 == 1 && (kk * 9 + t) / 2 < kPiecesPerWave) {
+                                if (next_chunk >= 0) stage_piece_n((kk * 9 + t) / 2, next_chunk, nxt_buf);
+                                __builtin_amdgcn_sched_barrier(0);
+                            }
+                        }
+                        // the 17th accumulator tile: hipcc pins builtin MFMA accumulators to the 256 AGPRs, which the 16
+                        // main tiles fill, so this one is issued in the VGPR form by hand
+                        if (wave == grp) {
+#pragma unroll
+                            for (int i = 0; i < kGroupTaps[grp]; ++i)
+                                asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0"
+                                             : "+v"(acch)
+                                             : "v"(a[i]), "v"(bhalo[kk & 1][tap_shift(kGroupFirst[grp] + i)]));
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
                     }
-                    __builtin_amdgcn_sched_barrier(0);
-                    const float a = afrag[u & 1] * sfrag[u & 1];
-#pragma unroll
-                    for (int jj = 0; jj < 4; ++jj)
-                        acc[tap_cls(t)][jj] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bfrag[kk & 1][tap_shift(t)][jj],
-                                                                                   acc[tap_cls(t)][jj], 0, 0, 0);
-                    // the 17th accumulator tile: hipcc pins builtin MFMA accumulators to the 256 AGPRs, which the 16
-                    // main tiles fill, so this one is issued in the VGPR form by hand
-                    if (wave == tap_cls(t))
-                        asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+v"(acch) : "v"(a), "v"(bhalo[kk & 1][tap_shift(t)]));
-                    __builtin_amdgcn_sched_barrier(0);
                 }
-            } else if (wave < 2) {
+            } else {
+              if (next_chunk >= 0) stage_chunk(next_chunk, nxt_buf);
+              if (wave < 2) {
                 // flush step (si == step_main): only T row 2H exists below the image = position row y' = H, even row parity,
                 // and only its taps on input row H-1 are non-zero: EE taps 2, 3 (wave 0: its two tiles of the
                 // first position row and the halo tile) and EO tap 5 (wave 1: the halo tile; wave 0: its tiles)
@@ -336,6 +392,7 @@ __global__ __launch_bounds__(256, 1) void upfir_fused_kernel(const UpFirArgs p) 
                         }
                     }
                 }
+              }
             }
         }
         // (the T window lies over ring slot 1, which the last chunk was read from)
