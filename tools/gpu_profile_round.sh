@@ -8,12 +8,11 @@ cd /tmp && export TMPDIR=/tmp
 repo=$OLDPWD
 cd "$repo"
 set -x
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/${tag}_trace -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline > $out/${tag}_bench_under_rocprof.json 2> $out/${tag}_trace.err &&
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $out/${tag}_pmc_fetch -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2> $out/${tag}_pmc_fetch.err &&
-rocprofv3 --kernel-trace --pmc WRITE_SIZE GRBM_GUI_ACTIVE --output-format csv -d $out/${tag}_pmc_write -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2> $out/${tag}_pmc_write.err &&
-rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_LDS_BANK_CONFLICT --output-format csv -d $out/${tag}_pmc_sq -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2> $out/${tag}_pmc_sq.err &&
-python3 bench.py --steps 20 --warmup 3 --print-steps > $out/${tag}_bench.json 2> $out/${tag}_steps.txt &&
-python3 bench.py --workload blend --steps 20 --warmup 3 > $out/${tag}_bench_blend.json 2> $out/${tag}_blend.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/${tag}_trace -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-extras > $out/${tag}_bench_under_rocprof.json 2> $out/${tag}_trace.err &&
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $out/${tag}_pmc_fetch -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras > /dev/null 2> $out/${tag}_pmc_fetch.err &&
+rocprofv3 --kernel-trace --pmc WRITE_SIZE GRBM_GUI_ACTIVE --output-format csv -d $out/${tag}_pmc_write -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras > /dev/null 2> $out/${tag}_pmc_write.err &&
+rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_LDS_BANK_CONFLICT --output-format csv -d $out/${tag}_pmc_sq -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras > /dev/null 2> $out/${tag}_pmc_sq.err &&
+python3 bench.py --steps 20 --warmup 3 --print-steps > $out/${tag}_bench.json 2> $out/${tag}_steps.txt
 set +x
 for d in trace pmc_fetch pmc_write pmc_sq; do find $out/${tag}_$d -name "*.csv" | head -5; done
 python3 tools/pmc_summary.py $(find $out/${tag}_pmc_fetch -name "*counter_collection.csv") > $out/${tag}_pmc_fetch_size.csv
