@@ -257,6 +257,7 @@ struct gance_engine {
     size_t avg_off = 0, const_off = 0, A_off = 0, bias1_off = 0, w2_off = 0;
     std::vector<size_t> conv_w, conv_bias, conv_noise;
     std::vector<size_t> wino_w;  // Winograd-domain weights of the stride-1 layers that support them (else SIZE_MAX)
+    std::vector<size_t> wino64_w;  // the same for the 64-channel Winograd kernel (layers with >= 64 output channels)
     std::vector<size_t> upfir_w;  // fused transposed-conv + FIR kernel's weight image of the up layers that support it (else SIZE_MAX)
     int num_cus = 256;
     std::vector<float> conv_ns;
@@ -401,6 +402,13 @@ int run_conv(gance_engine* e, const ConvLayerHost& c, int li, const LayerPlan& p
     }
     StepScope scope(e, stream, name, flops, bytes);
     if (winograd) {
+        // layers with >= 64 output channels: the 64-channel kernel (GANCE_TUNE_WINO64=0 keeps the 32-channel one)
+        static const bool wino64_enabled = [] { const char* v = std::getenv("GANCE_TUNE_WINO64"); return !(v && std::atoi(v) == 0); }();
+        if (wino64_enabled && rgb == nullptr && epilogue == gance::kEpilogueFull && e->wino64_w[li] != SIZE_MAX) {
+            a.w = e->pool + e->wino64_w[li];
+            GANCE_HIP_CHECK(gance::launch_winograd64_conv(a, stream));
+            return GANCE_OK;
+        }
         a.w = e->pool + e->wino_w[li];
         GANCE_HIP_CHECK(gance::launch_winograd_conv(a, stream));
         return GANCE_OK;
@@ -859,6 +867,13 @@ int gance_engine_create(const gance_engine_config* config, const float* host_wei
             for (size_t j = 0; j < wn; ++j) scaled[j] = src[j] * coef;
             e->wino_w[i] = reserve(gance::winograd_weight_floats(c.cin, c.cout));
             gance::winograd_transform_weights(scaled.data(), c.cin, c.cout, &pool[e->wino_w[i]]);
+        }
+        e->wino64_w.push_back(SIZE_MAX);
+        if (!c.up && gance::winograd64_supported(c.cin, c.cout, 1 << c.res_log2, 1 << c.res_log2)) {
+            std::vector<float> scaled(wn);
+            for (size_t j = 0; j < wn; ++j) scaled[j] = src[j] * coef;
+            e->wino64_w[i] = reserve(gance::winograd64_weight_floats(c.cin, c.cout));
+            gance::winograd64_transform_weights(scaled.data(), c.cin, c.cout, &pool[e->wino64_w[i]]);
         }
         e->upfir_w.push_back(SIZE_MAX);
         if (c.up && gance::upfir_supported(c.cin, c.cout, (1 << c.res_log2) / 2, (1 << c.res_log2) / 2)) {

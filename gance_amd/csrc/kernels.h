@@ -133,6 +133,13 @@ size_t winograd_weight_floats(int cin, int cout);
 void winograd_transform_weights(const float* w_in /*[9][cin][cout]*/, int cin, int cout, float* w_out);
 hipError_t launch_winograd_conv(const ConvArgs& args, hipStream_t stream);
 
+// The same Winograd form for layers with >= 64 output channels (winograd64_conv.hip): 64 channels x 8x32 pixels per
+// block on v_mfma_f32_16x16x4_f32; args.w points at [m tile of 64][chunk of 8][16][8][16][4].
+bool winograd64_supported(int cin, int cout, int H, int W);
+size_t winograd64_weight_floats(int cin, int cout);
+void winograd64_transform_weights(const float* w_in /*[9][cin][cout]*/, int cin, int cout, float* w_out);
+hipError_t launch_winograd64_conv(const ConvArgs& args, hipStream_t stream);
+
 // Conv0_up as ONE kernel (upfir_fused.hip): transposed conv on the matrix cores + [1,3,3,1]^2 FIR + noise +
 // bias + leaky ReLU, for inputs >= 64 wide. Blocks sweep 64-column strips in steps of 8 position rows.
 struct UpFirArgs {

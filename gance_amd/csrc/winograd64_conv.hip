@@ -1,0 +1,418 @@
+// Winograd F(2x2, 3x3) form of the modulated 3x3 stride-1 convolution for layers with >= 64 output channels:
+// the same arithmetic as winograd_conv.hip (`modulated_conv2d_layer` -> tf.nn.conv2d), with the
+// input transform amortised over 64 output channels instead of 32.
+//
+// Why a second kernel. In winograd_conv.hip a wave transforms a 4x4 input window per (tile, channel) -- 40 vector
+// instructions -- and feeds the 16 results to 16 MFMAs (one 32x32x2 tile of 32 output channels per Winograd
+// position): 2.5 vector instructions per MFMA, and on gfx950 the fp32 MFMA does not hide vector work of its own
+// wave, so that kernel executes at 0.58 of the matrix peak. Here the MFMA is v_mfma_f32_16x16x4_f32
+// (16 channels x 16 tiles x 4 input channels, 32 cycles) and a wave holds FOUR channel tiles per position:
+// 16 positions x 4 x 4 registers = 256 accumulators, the same register budget, but a transformed window now feeds
+// 64 MFMAs (2048 matrix-pipe cycles) instead of 16 (1024): half the vector work per matrix cycle. The four weight
+// fragments of a position come out of LDS in ONE ds_read_b128 (the weight image is laid out [pos][ci][m % 16][m / 16]).
+//
+// Block = 4 waves = 64 output channels x (8 x 32) pixels = 4 x 16 Winograd tiles; wave w owns tile row w, lane
+// (n = lane % 16, kq = lane / 16) transforms the window of tile n for input channel 4 ks + kq of k-step ks.
+// K chunk = 4 input channels = ONE k-step: transformed weights [16][4][16][4] (16 KB) + haloed patch [4][10][40]
+// (6.4 KB) per ring slot, SIX slots. Blocks are persistent over ONE continuous stream of chunks (tiles back to back).
+// The window loads and the transform of k-step q+1 run under the MFMAs of k-step q, so at the top of every k-step the
+// wave waits for chunk q+1 -- issued FOUR k-steps earlier, counted vmcnt: the three younger chunks stay in flight --
+// the block synchronises (chunk q-1 is then dead) and the six LDS-DMA pieces a wave contributes to chunk q+5 are woven
+// between the MFMAs. (A first version with 8-channel chunks in a three-slot ring issued a chunk's last pieces right
+// before the wait that needed them and ran at 0.59 of the matrix peak -- DMA latency, not vector work, was the limit.)
+// The epilogue (output transform A^T M A, demodulation, noise, bias, leaky ReLU,
+// 8-byte stores: 128 contiguous bytes per 16 lanes) runs between tiles while the pipeline registers already hold
+// the next tile's first k-step.
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdint>
+#include <cstdlib>
+#include <type_traits>
+
+#include "kernels.h"
+
+// Timing ablations (GANCE_DEBUG_W64: 2 no DMA after the prologue, 4 no MFMA, 32 no input transform, 64 no per-k-step wait
+// and barrier) exist only in a -DGANCE_W64_DEBUG=1 build.
+#ifndef GANCE_W64_DEBUG
+#define GANCE_W64_DEBUG 0
+#endif
+#define W64_DBG (GANCE_W64_DEBUG ? p.debug_flags : 0)
+
+namespace gance {
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+
+constexpr int kBM = 64;                 // output channels per block
+constexpr int kTH = 8, kTW = 32;        // pixels per block
+constexpr int kKC = 4;                  // input channels per chunk = one k-step of the 16x16x4 MFMA
+constexpr int kPH = kTH + 2, kPW = kTW + 8;
+constexpr int kPlane = kPH * kPW;       // 400
+constexpr int kUFloats = 16 * kKC * kBM;             // 4096: [pos][ci][m % 16][m / 16]
+constexpr int kUPieces = kUFloats / 256;             // 16
+constexpr int kPlFloats = kKC * kPlane;              // 1600
+constexpr int kPlF4 = kPlFloats / 4;                 // 400
+constexpr int kPlPieces = (kPlF4 + 63) / 64;         // 7 (the last one a quarter full)
+constexpr int kSlot = kUFloats + kPlPieces * 256;    // 5888 floats = 23 KiB
+constexpr int kNBUF = 6;                             // ring depth: a chunk is issued four k-steps before its first use
+constexpr int kPieces = kUPieces + kPlPieces;        // 23
+constexpr int kPiecesPerWave = (kPieces + 3) / 4;    // 6: every wave issues six (wave 3's spare slot repeats piece 0), the waits count them
+constexpr int kConstFloats = 512 + 64 + 64;          // style | demod | bias of a tile
+static_assert(kUPieces % 4 == 0, "slots 0..3 of every wave are weight pieces");
+static_assert((kNBUF - 3) * kPiecesPerWave <= 63, "counted vmcnt");
+
+inline size_t lds_bytes() { return sizeof(float) * ((size_t)kNBUF * kSlot + 2 * kConstFloats); }
+
+struct Tile {
+    int m_tile, y0, x0, b0;
+};
+
+}  // namespace
+
+__global__ __launch_bounds__(256, 1) void winograd64_kernel(const ConvArgs p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* const buf0 = smem;
+    float* const const0 = smem + kNBUF * kSlot;
+
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63;
+    const int n16 = lane & 15, kq = lane >> 4;
+    const int Hp = p.H + 2, Wp = p.W + 8;
+    const int n = p.total_chunks;  // chunks per tile
+
+    const int my_tiles = (p.total_tiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int total_chunks = my_tiles * n;
+    auto decode = [&](int i) {
+        // virtual block id -> tile, XCD-aware (a persistent block strides by a multiple of 8): the channel tiles of a
+        // pixel tile and neighbouring pixel tiles land on one XCD's L2 at about the same time
+        const int v = (int)blockIdx.x + min(i, my_tiles - 1) * (int)gridDim.x;
+        const int nwg = p.total_tiles;
+        const int q = nwg >> 3, r = nwg & 7, xcd = v & 7;
+        int id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (v >> 3);
+        Tile t;
+        t.m_tile = id % p.m_tiles;
+        id /= p.m_tiles;
+        t.x0 = (id % p.tiles_x) * kTW;
+        id /= p.tiles_x;
+        t.y0 = (id % p.tiles_y) * kTH;
+        t.b0 = id / p.tiles_y;
+        return t;
+    };
+
+    // ---- LDS-DMA: piece g = wave + 4 r of a chunk; g < 32 weight image, else patch piece g - 32 ----
+    // (tiles are whole: H % 8 == 0, W % 32 == 0, so a patch piece's per-lane source offset depends on nothing but the lane)
+    // A wave's six slots: 0..3 weight pieces wave + 4 r; 4, 5 patch pieces wave + 4 (r - 4), wave 3's second one
+    // repeating patch piece 0 (same bytes: every wave issues six, the waits count them). Piece 6 is a quarter full:
+    // its other lanes copy float4 0 of the piece into the slot's padding. No slot needs a branch or a lane mask.
+    int p_voff[2], p_lds[2];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        int i = wave + 4 * r;
+        if (i >= kPlPieces) i = 0;
+        int f = i * 64 + lane;
+        if (f >= kPlF4) f = i * 64;
+        const int q = f % (kPW / 4);
+        const int row = (f / (kPW / 4)) % kPH;
+        const int c = f / (kPW / 4 * kPH);
+        p_voff[r] = ((c * Hp + row) * Wp + 4 * q) * 4;
+        p_lds[r] = kUFloats + i * 256;
+    }
+    const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, 0x7fffffff, 0x00020000);
+    // staging side of the stream: which (tile, chunk) is fetched next, into which ring slot. Past the end of the
+    // stream the last chunk is fetched again into the free slot (nobody reads it): every k-step then issues the same
+    // number of pieces and the counted waits need no tail case.
+    int st_tile = 0, st_chunk = 0, st_slot = 0;
+    int st_w_soff = 0, st_x_soff = 0;          // of the tile being staged
+    int cur_w_soff = 0, cur_x_soff = 0;        // of the chunk being staged (scalar offsets of its pieces)
+    float* cur_buf = buf0;
+    __amdgpu_buffer_rsrc_t st_x_rsrc = w_rsrc;
+    // Before a chunk's pieces go out: tile descriptors and constants if it opens a tile, then the chunk's scalar offsets.
+    // Runs at the top of a k-step, OUTSIDE the woven region (it branches).
+    auto stage_begin = [&]() {
+        if (st_chunk == 0 && st_tile < my_tiles) {
+            const Tile t = decode(st_tile);
+            const int b = min(t.b0, p.B - 1);
+            st_x_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(p.x + (size_t)b * p.x_b_stride), 0, 0x7fffffff, 0x00020000);
+            st_w_soff = t.m_tile * n * (kUFloats * 4);
+            st_x_soff = (t.y0 * Wp + t.x0) * 4;
+            // the tile's constants (style of the sample, demod and bias of the channel tile) by dword LDS-DMA
+            float* const set = const0 + (st_tile & 1) * kConstFloats;
+            const __amdgpu_buffer_rsrc_t s_rsrc =
+                __builtin_amdgcn_make_buffer_rsrc((void*)(p.s + (size_t)b * p.s_stride), 0, p.Cin * 4, 0x00020000);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(s_rsrc, (lds_ptr_t)(set + wave * 64), 4, (wave * 64 + lane) * 4, 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(s_rsrc, (lds_ptr_t)(set + (wave + 4) * 64), 4, ((wave + 4) * 64 + lane) * 4, 0, 0, 0);
+            if (wave < 2) {
+                const __amdgpu_buffer_rsrc_t c_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+                    (void*)(wave == 0 ? p.d + (size_t)b * p.d_stride + t.m_tile * kBM : p.bias + t.m_tile * kBM), 0, kBM * 4, 0x00020000);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(c_rsrc, (lds_ptr_t)(set + 512 + wave * 64), 4, lane * 4, 0, 0, 0);
+            }
+        }
+        cur_buf = buf0 + st_slot * kSlot;
+        cur_w_soff = st_w_soff + st_chunk * (kUFloats * 4);
+        cur_x_soff = st_x_soff + st_chunk * (kKC * Hp * Wp * 4);
+        // ... and move the staging position on (staying on the last chunk past the end)
+        st_slot = st_slot + 1 == kNBUF ? 0 : st_slot + 1;
+        const bool last = st_tile + 1 >= my_tiles && st_chunk + 1 >= n;
+        if (!last) {
+            if (++st_chunk == n) {
+                st_chunk = 0;
+                ++st_tile;
+            }
+        }
+    };
+    // slot r of the chunk set up by stage_begin(): one instruction, no control flow
+    auto stage_piece = [&](int r) {
+        if (r < 4) {
+            const int g = wave + 4 * r;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, (lds_ptr_t)(cur_buf + g * 256), 16, (g * 256 + lane * 4) * 4, cur_w_soff, 0, 0);
+        } else {
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(st_x_rsrc, (lds_ptr_t)(cur_buf + p_lds[r - 4]), 16, p_voff[r - 4], cur_x_soff, 0, 0);
+        }
+    };
+    // NOTE: st_x_rsrc changes when stage_begin opens a tile; the pieces of that chunk are the first to use it.
+
+    // ring prologue: the first NBUF - 1 chunks of the stream
+    for (int c = 0; c < kNBUF - 1; ++c) {
+        stage_begin();
+#pragma unroll
+        for (int r = 0; r < kPiecesPerWave; ++r) stage_piece(r);
+    }
+
+    f32x4 acc[16][4];
+#pragma unroll
+    for (int q = 0; q < 16; ++q)
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) acc[q][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // per-lane operand offsets (floats): window of tile (wave, n16): patch rows 2 wave .. + 3, columns 2 n16 + 3 .. + 6
+    const int poff = kq * kPlane + (2 * wave) * kPW + 2 * n16 + 3;
+    const int aoff = (kq * 16 + n16) * 4;  // + pos * kKC * 64
+
+    // ---- pipeline registers ----
+    float win[4][4];  // raw window of the k-step being transformed
+    float sval = 0.f;
+    float tcol[4][4];
+    float V[2][16];
+    auto load_window = [&](const float* __restrict__ patch, const float* __restrict__ style) {
+        const float* pc = patch + poff;
+#pragma unroll
+        for (int y = 0; y < 4; ++y)
+#pragma unroll
+            for (int x = 0; x < 4; ++x) win[y][x] = pc[y * kPW + x];
+        sval = style[kq];
+    };
+    // V = B^T (s d) B, B^T = [[1,0,-1,0],[0,1,1,0],[0,-1,1,0],[0,1,0,-1]]; the style scale rides on the window (V is linear in d)
+    auto transform = [&](float (&out)[16]) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const float e1 = sval * win[1][c], e2 = sval * win[2][c];
+            tcol[0][c] = fmaf(sval, win[0][c], -e2);
+            tcol[1][c] = e1 + e2;
+            tcol[2][c] = e2 - e1;
+            tcol[3][c] = fmaf(-sval, win[3][c], e1);
+        }
+#pragma unroll
+        for (int y = 0; y < 4; ++y) {
+            out[y * 4 + 0] = tcol[y][0] - tcol[y][2];
+            out[y * 4 + 1] = tcol[y][1] + tcol[y][2];
+            out[y * 4 + 2] = tcol[y][2] - tcol[y][1];
+            out[y * 4 + 3] = tcol[y][1] - tcol[y][3];
+        }
+    };
+
+    // ---- output transform Y = A^T M A (A^T = [[1,1,1,0],[0,1,-1,-1]]), epilogue, stores; clears acc ----
+    auto epilogue = [&](int i) {
+        const Tile t = decode(i);
+        const float* const d_lds = const0 + (i & 1) * kConstFloats + 512;
+        const float* const b_lds = d_lds + 64;
+        const int oy = t.y0 + 2 * wave, ox = t.x0 + 2 * n16;
+        const bool ok = t.b0 < p.B;
+        float nz[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
+        if (p.noise != nullptr && ok) {
+#pragma unroll
+            for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+                for (int dx = 0; dx < 2; ++dx) nz[dy][dx] = p.noise[(size_t)(oy + dy) * p.OW + ox + dx] * p.noise_strength;
+        }
+        const int c_stride_bytes = (int)p.out_c_stride * 4;
+        const __amdgpu_buffer_rsrc_t o_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+            (void*)(p.out + (size_t)t.b0 * p.out_b_stride + (size_t)(t.m_tile * kBM) * p.out_c_stride), 0, 0x7fffffff, 0x00020000);
+        const int voff0 = ((oy + p.out_y_off) * p.out_row_stride + ox + p.out_x_off) * 4 + 4 * kq * c_stride_bytes;
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                // one channel at a time (fenced): without it hipcc pulls all 256 accumulators into VGPRs at once
+                __builtin_amdgcn_sched_barrier(0);
+                const int m = mt * 16 + 4 * kq + r;
+                float u[2][4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    u[0][j] = acc[0 * 4 + j][mt][r] + acc[1 * 4 + j][mt][r] + acc[2 * 4 + j][mt][r];
+                    u[1][j] = acc[1 * 4 + j][mt][r] - acc[2 * 4 + j][mt][r] - acc[3 * 4 + j][mt][r];
+                }
+                const float dm = d_lds[m], bm = b_lds[m];
+#pragma unroll
+                for (int dy = 0; dy < 2; ++dy) {
+                    float y2[2];
+                    y2[0] = u[dy][0] + u[dy][1] + u[dy][2];
+                    y2[1] = u[dy][1] - u[dy][2] - u[dy][3];
+#pragma unroll
+                    for (int dx = 0; dx < 2; ++dx) {
+                        float v = y2[dx] * dm;
+                        v += nz[dy][dx] + bm;
+                        v = fmaxf(v, 0.2f * v) * 1.4142135623730951f;
+                        y2[dx] = v;
+                    }
+                    if (ok) {
+                        u32x2 pair;
+                        pair[0] = __float_as_uint(y2[0]);
+                        pair[1] = __float_as_uint(y2[1]);
+                        __builtin_amdgcn_raw_buffer_store_b64(pair, o_rsrc, voff0 + dy * p.out_row_stride * 4, (mt * 16 + r) * c_stride_bytes, 0);
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 16; ++q)
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) acc[q][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    };
+
+    // ---- prologue of the pipeline: first chunk visible, V of its k-step, its weight fragments ----
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((kNBUF - 2) * kPiecesPerWave) : "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    load_window(buf0 + kUFloats, const0);
+    transform(V[0]);
+    // weight fragments of a k-step are read during the k-step before it (64 + 64 registers)
+    f32x4 afrag[2][16];
+#pragma unroll
+    for (int pos = 0; pos < 16; ++pos) afrag[0][pos] = *reinterpret_cast<const f32x4*>(buf0 + aoff + pos * kKC * kBM);
+
+    // ---- the stream: chunk q = k-step q of the block's stream, ring slot q % NBUF ----
+    // A k-step is ONE branch-free scheduling region: the 64 MFMAs of k-step q, and for k-step q+1 its 16 weight-fragment
+    // reads (ds_read_b128), its window reads and its 40-instruction transform; six DMA pieces of chunk q+5. A wave alone on its SIMD
+    // keeps the matrix pipe busy only if the other instructions sit in the 32-cycle shadows BETWEEN the MFMAs (in clumps
+    // between groups of MFMAs they cost their full issue time: 0.60 of the peak); the sched_group_barrier pattern below
+    // deals them out one MFMA at a time.
+    int slot = 0;  // ring slot of the chunk being multiplied
+    int q = 0;     // its index in the block's stream
+    // tiles in the outer loop, their chunks in the inner one, the epilogue unconditionally after it: the accumulators
+    // must not flow through a conditional (hipcc then moves all 256 of them through VGPRs and scratch)
+    for (int tile = 0; tile < my_tiles; ++tile) {
+        for (int chunk = 0; chunk < n; chunk += 2) {
+            // (two k-steps per trip so that V[0] / V[1] alternate with compile-time indices; n is even)
+#pragma unroll
+            for (int half = 0; half < 2; ++half, ++q) {
+                const int next_slot = slot + 1 == kNBUF ? 0 : slot + 1;
+                const float* const Uc = buf0 + slot * kSlot;  // (only its successor is read below)
+                // (the stream's last k-step reads its own chunk again instead of a next one: no tail case)
+                const float* const Un = q + 1 < total_chunks ? buf0 + next_slot * kSlot : Uc;
+                const int c_here = chunk + half;
+                const float* const style_n = c_here + 1 == n ? const0 + ((tile + 1) & 1) * kConstFloats : const0 + (tile & 1) * kConstFloats + (c_here + 1) * kKC;
+                // chunk q+1 was issued four k-steps ago: wait for it (the three younger chunks stay in flight); once every
+                // wave is here chunk q-1 is dead and its slot takes the six pieces woven below
+                if (!(W64_DBG & 64)) {
+                    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((kNBUF - 3) * kPiecesPerWave) : "memory");
+                    __builtin_amdgcn_s_barrier();
+                    asm volatile("" ::: "memory");
+                }
+                stage_begin();
+                __builtin_amdgcn_sched_barrier(0);
+                load_window(Un + kUFloats, style_n);
+#pragma unroll
+                for (int pos = 0; pos < 16; ++pos) afrag[(half + 1) & 1][pos] = *reinterpret_cast<const f32x4*>(Un + aoff + pos * kKC * kBM);
+                if (!(W64_DBG & 32)) transform(V[(half + 1) & 1]);
+                if (!(W64_DBG & 2)) {
+#pragma unroll
+                    for (int r = 0; r < kPiecesPerWave; ++r) stage_piece(r);
+                }
+                if (!(W64_DBG & 4)) {
+#pragma unroll
+                    for (int pos = 0; pos < 16; ++pos)
+#pragma unroll
+                        for (int mt = 0; mt < 4; ++mt)
+                            acc[pos][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(afrag[half][pos][mt], V[half][pos], acc[pos][mt], 0, 0, 0);
+                }
+                // weave: 64 x (1 MFMA, then what fits in its shadow): the 26 LDS reads first (they feed everything else),
+                // the 40 transform instructions and the six DMA issues spread over the rest
+#pragma unroll
+                for (int i = 0; i < 64; ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                 // 1 MFMA
+                    if (i < 26) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);      // 1 LDS read
+                    if (i >= 8 && i < 60) __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);  // 1 VALU
+                    if (i % 10 == 9) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);  // 1 LDS-DMA issue
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                slot = next_slot;
+            }
+        }
+        epilogue(tile);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // nothing of the ring may still be landing when the block's LDS is given back
+}
+
+bool winograd64_supported(int cin, int cout, int H, int W) {
+    // (an even number of chunks per tile, and at least NBUF of them)
+    return cin % (2 * kKC) == 0 && cin <= 512 && cin / kKC >= kNBUF && cout % kBM == 0 && H % kTH == 0 && W % kTW == 0;
+}
+
+size_t winograd64_weight_floats(int cin, int cout) { return (size_t)16 * cin * cout; }
+
+// w_in: the layer's runtime-scaled weights [tap = ky*3+kx][ci][co]; w_out: [m tile of 64][chunk of 4][pos][ci][co % 16][co / 16]
+void winograd64_transform_weights(const float* w_in, int cin, int cout, float* w_out) {
+    const double G[4][3] = {{1., 0., 0.}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0., 0., 1.}};
+    const int chunks = cin / kKC;
+    for (int co = 0; co < cout; ++co)
+        for (int ci = 0; ci < cin; ++ci) {
+            double g[3][3], tmp[4][3], u[4][4];
+            for (int ky = 0; ky < 3; ++ky)
+                for (int kx = 0; kx < 3; ++kx) g[ky][kx] = w_in[((size_t)(ky * 3 + kx) * cin + ci) * cout + co];
+            for (int i = 0; i < 4; ++i)
+                for (int kx = 0; kx < 3; ++kx) tmp[i][kx] = G[i][0] * g[0][kx] + G[i][1] * g[1][kx] + G[i][2] * g[2][kx];
+            for (int i = 0; i < 4; ++i)
+                for (int j = 0; j < 4; ++j) u[i][j] = tmp[i][0] * G[j][0] + tmp[i][1] * G[j][1] + tmp[i][2] * G[j][2];
+            const int mtile = co / kBM, m = co % kBM, ch = ci / kKC, kc = ci % kKC;
+            float* dst = w_out + ((size_t)mtile * chunks + ch) * kUFloats;
+            for (int i = 0; i < 4; ++i)
+                for (int j = 0; j < 4; ++j) dst[(((i * 4 + j) * kKC + kc) * 16 + m % 16) * 4 + m / 16] = (float)u[i][j];
+        }
+}
+
+hipError_t launch_winograd64_conv(const ConvArgs& args, hipStream_t stream) {
+    if (args.epilogue != kEpilogueFull) return hipErrorInvalidValue;
+    static PerDeviceInt resident;  // per device: the dynamic-LDS opt-in and the launch size = one block per CU, a multiple of 8 (XCDs)
+    int resident_blocks = 0;
+    hipError_t e = resident.get(
+        [&](int device, int* value) {
+            hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(winograd64_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                 (int)lds_bytes());
+            if (err != hipSuccess) return err;
+            int cus = 0;
+            if ((err = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device)) != hipSuccess) return err;
+            *value = std::max(8, cus / 8 * 8);
+            return hipSuccess;
+        },
+        &resident_blocks);
+    if (e != hipSuccess) return e;
+    ConvArgs a = args;
+    static const int env_debug = [] { const char* v = std::getenv("GANCE_DEBUG_W64"); return v ? std::atoi(v) : 0; }();
+    a.debug_flags = env_debug;
+    a.tiles_x = a.W / kTW;
+    a.tiles_y = a.H / kTH;
+    a.m_tiles = a.Cout / kBM;
+    a.total_chunks = a.Cin / kKC;
+    a.total_tiles = a.m_tiles * a.tiles_x * a.tiles_y * a.B;
+    const int blocks = std::min(a.total_tiles, resident_blocks);
+    hipLaunchKernelGGL(winograd64_kernel, dim3(blocks), dim3(256), lds_bytes(), stream, a);
+    return hipGetLastError();
+}
+
+}  // namespace gance
