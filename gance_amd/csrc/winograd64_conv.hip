@@ -317,6 +317,21 @@ __global__ __launch_bounds__(256, 1) void winograd64_kernel(const ConvArgs p) {
                 const float* const Un = q + 1 < total_chunks ? buf0 + next_slot * kSlot : Uc;
                 const int c_here = chunk + half;
                 const float* const style_n = c_here + 1 == n ? const0 + ((tile + 1) & 1) * kConstFloats : const0 + (tile & 1) * kConstFloats + (c_here + 1) * kKC;
+                // The MFMAs of k-step q have their operands in registers: the first sixteen go out BEFORE the wait and the
+                // barrier, so the matrix pipe works while the wave does the staging bookkeeping (scalar, branchy) and waits
+                // for its siblings.
+                auto mfma_positions = [&](int first, int last) {
+                    if (W64_DBG & 4) return;
+#pragma unroll
+                    for (int pos = first; pos < last; ++pos)
+#pragma unroll
+                        for (int mt = 0; mt < 4; ++mt)
+                            acc[pos][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(afrag[half][pos][mt], V[half][pos], acc[pos][mt], 0, 0, 0);
+                };
+                __builtin_amdgcn_sched_barrier(0);
+                mfma_positions(0, 4);
+                stage_begin();
+                __builtin_amdgcn_sched_barrier(0);
                 // chunk q+1 was issued four k-steps ago: wait for it (the three younger chunks stay in flight); once every
                 // wave is here chunk q-1 is dead and its slot takes the six pieces woven below
                 if (!(W64_DBG & 64)) {
@@ -324,7 +339,6 @@ __global__ __launch_bounds__(256, 1) void winograd64_kernel(const ConvArgs p) {
                     __builtin_amdgcn_s_barrier();
                     asm volatile("" ::: "memory");
                 }
-                stage_begin();
                 __builtin_amdgcn_sched_barrier(0);
                 load_window(Un + kUFloats, style_n);
 #pragma unroll
@@ -334,21 +348,15 @@ __global__ __launch_bounds__(256, 1) void winograd64_kernel(const ConvArgs p) {
 #pragma unroll
                     for (int r = 0; r < kPiecesPerWave; ++r) stage_piece(r);
                 }
-                if (!(W64_DBG & 4)) {
-#pragma unroll
-                    for (int pos = 0; pos < 16; ++pos)
-#pragma unroll
-                        for (int mt = 0; mt < 4; ++mt)
-                            acc[pos][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(afrag[half][pos][mt], V[half][pos], acc[pos][mt], 0, 0, 0);
-                }
-                // weave: 64 x (1 MFMA, then what fits in its shadow): the 26 LDS reads first (they feed everything else),
+                mfma_positions(4, 16);
+                // weave: 48 x (1 MFMA, then what fits in its shadow): the 26 LDS reads first (they feed everything else),
                 // the 40 transform instructions and the six DMA issues spread over the rest
 #pragma unroll
-                for (int i = 0; i < 64; ++i) {
+                for (int i = 0; i < 48; ++i) {
                     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                 // 1 MFMA
                     if (i < 26) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);      // 1 LDS read
-                    if (i >= 8 && i < 60) __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);  // 1 VALU
-                    if (i % 10 == 9) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);  // 1 LDS-DMA issue
+                    if (i >= 4) __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);      // 1 VALU
+                    if (i % 8 == 7) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);  // 1 LDS-DMA issue
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 slot = next_slot;
