@@ -213,21 +213,21 @@ def test_config_f_1024_every_term_on_default_kernels(library, conv_form: str, up
     _check_frames(frames, image, ref.synthesize_z(z, variables, resolution, truncation_psi=1.2))
 
 
-def test_bench_configuration_batch_32_matches_oracle_and_single_calls(library) -> None:
+def test_bench_configuration_batch_64_matches_oracle_and_single_calls(library) -> None:
     """
-    The configuration bench.py times (1024^2, 32 frames per call, auto kernel selection: Winograd layers,
-    fused up kernels, fused last layer): frames 0 and 31 against the oracle, and against the same z alone.
+    The configuration bench.py times (1024^2, 64 frames per call, auto kernel selection: Winograd layers,
+    fused up kernels, fused last layer): first and last frame against the oracle, and against the same z alone.
     """
-    resolution, batch = 1024, 32
+    resolution, batch = 1024, 64
     variables = sg2_spec.make_random_variables(resolution, seed=0, perturb=True)
     z = np.random.RandomState(1).randn(batch, 512).astype(np.float32)
     engine = hip_lib.Engine(variables, resolution, max_batch=batch)
     try:
         frames, image = engine.synthesize_z(z, truncation_psi=1.2, want_float=True)
-        alone = [engine.synthesize_z(z[i : i + 1], truncation_psi=1.2) for i in (0, 31)]
+        alone = [engine.synthesize_z(z[i : i + 1], truncation_psi=1.2) for i in (0, batch - 1)]
     finally:
         engine.close()
-    for k, i in enumerate((0, 31)):
+    for k, i in enumerate((0, batch - 1)):
         _check_frames(frames[i : i + 1], image[i : i + 1], ref.synthesize_z(z[i : i + 1], variables, resolution, truncation_psi=1.2))
         _assert_same_frames(alone[k][0], frames[i])
 
