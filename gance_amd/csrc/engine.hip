@@ -486,6 +486,13 @@ int synthesize_from_dlat(gance_engine* e, const float* d_dlat, int B, uint8_t* d
             const auto& tile = gance::kConvTiles[p.tile_id];
             fused_rgb = fuse_enabled && c.res_log2 == e->res_log2 && limit == num_convs && p.nsplit == 1 &&
                         p.m_tiles == 1 && tile.TB == 1 && tile.BM == 32 && have_y;
+            // ... unless the layer runs in Winograd form on the 64-channel kernel's 32-channel geometry followed by the
+            // separate ToRGB pass (GANCE_TUNE_LAST_WINO64 = 0 / 1; measured: see DESIGN.md §3)
+            static const int last_wino64 = [] { const char* v = std::getenv("GANCE_TUNE_LAST_WINO64"); return v ? std::atoi(v) : 1; }();
+            const long long last_tiles = (long long)(res / 16) * (res / 32) * B;
+            if (fused_rgb && last_wino64 != 0 && c.cout == 32 && e->wino64_w[li] != SIZE_MAX && !(e->cfg.flags & GANCE_FLAG_DIRECT_CONV) &&
+                !(e->cfg.flags & GANCE_FLAG_FORCE_WINOGRAD) && last_tiles >= e->num_cus)
+                fused_rgb = false;
             // Winograd F(2x2,3x3) form where the layer supports it and the launch fills the chip
             // (one block per CU). Engine flags choose: DIRECT_CONV = never, FORCE_WINOGRAD = whatever
             // the block count; GANCE_TUNE_WINOGRAD = 0 / 1 / 2 overrides them for tuning.

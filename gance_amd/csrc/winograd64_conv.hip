@@ -39,6 +39,10 @@
 #define GANCE_W64_DEBUG 0
 #endif
 #define W64_DBG (GANCE_W64_DEBUG ? p.debug_flags : 0)
+// Compile-time epilogue ablation (results are wrong): 1 no stores (make w64ablate).
+#ifndef GANCE_W64_ABLATE
+#define GANCE_W64_ABLATE 0
+#endif
 
 namespace gance {
 
@@ -48,33 +52,59 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
-constexpr int kBM = 64;                 // output channels per block
-constexpr int kTH = 8, kTW = 32;        // pixels per block
+// Geometry of a variant: MT channel tiles of 16 per wave and position, TG tile rows per wave.
+//   <4, 1>: 64 output channels x  8 x 32 pixels per block (layers with >= 64 output channels)
+//   <2, 2>: 32 output channels x 16 x 32 pixels per block (the 32-channel layers: 1024^2); a wave then transforms TWO
+//           windows per k-step, i.e. the vector work per matrix cycle of winograd_conv.hip, but keeps this kernel's
+//           ring, weave and one-instruction weight fragments
+// Either way 16 positions x TG x MT x 4 registers = 256 accumulators and 64 MFMAs per k-step.
 constexpr int kKC = 4;                  // input channels per chunk = one k-step of the 16x16x4 MFMA
-constexpr int kPH = kTH + 2, kPW = kTW + 8;
-constexpr int kPlane = kPH * kPW;       // 400
-constexpr int kUFloats = 16 * kKC * kBM;             // 4096: [pos][ci][m % 16][m / 16]
-constexpr int kUPieces = kUFloats / 256;             // 16
-constexpr int kPlFloats = kKC * kPlane;              // 1600
-constexpr int kPlF4 = kPlFloats / 4;                 // 400
-constexpr int kPlPieces = (kPlF4 + 63) / 64;         // 7 (the last one a quarter full)
-constexpr int kSlot = kUFloats + kPlPieces * 256;    // 5888 floats = 23 KiB
-constexpr int kNBUF = 6;                             // ring depth: a chunk is issued four k-steps before its first use
-constexpr int kPieces = kUPieces + kPlPieces;        // 23
-constexpr int kPiecesPerWave = (kPieces + 3) / 4;    // 6: every wave issues six (wave 3's spare slot repeats piece 0), the waits count them
-constexpr int kConstFloats = 512 + 64 + 64;          // style | demod | bias of a tile
-static_assert(kUPieces % 4 == 0, "slots 0..3 of every wave are weight pieces");
-static_assert((kNBUF - 3) * kPiecesPerWave <= 63, "counted vmcnt");
-
-inline size_t lds_bytes() { return sizeof(float) * ((size_t)kNBUF * kSlot + 2 * kConstFloats); }
+constexpr int kTW = 32, kPW = kTW + 8;
+constexpr int kNBUF = 6;                // ring depth: a chunk is issued four k-steps before its first use
+constexpr int kConstHead = 512 + 64 + 64;  // style | demod | bias of a tile, then its noise [pixel row][32]
+template <int MT, int TG>
+struct Geo {
+    static_assert(MT * TG == 4, "256 accumulators");
+    static constexpr int kBM = 16 * MT;                       // output channels per block
+    static constexpr int kTH = 8 * TG;                        // pixel rows per block
+    static constexpr int kPH = kTH + 2;
+    static constexpr int kPlane = kPH * kPW;                  // 400 / 720
+    static constexpr int kUFloats = 16 * kKC * kBM;           // 4096 / 2048: [pos][ci][m % 16][m / 16]
+    static constexpr int kUPieces = kUFloats / 256;           // 16 / 8
+    static constexpr int kUSlots = kUPieces / 4;              // weight pieces per wave: 4 / 2
+    static constexpr int kPlF4 = kKC * kPlane / 4;            // 400 / 720
+    static constexpr int kPlPieces = (kPlF4 + 63) / 64;       // 7 / 12 (the last one a quarter full)
+    static constexpr int kPlSlots = (kPlPieces + 3) / 4;      // patch pieces per wave: 2 / 3
+    static constexpr int kSlot = kUFloats + kPlPieces * 256;  // 5888 / 5120 floats
+    static constexpr int kPiecesPerWave = kUSlots + kPlSlots; // 6 / 5: every wave issues as many, the waits count them
+    static_assert((kNBUF - 3) * kPiecesPerWave <= 63, "counted vmcnt");
+    static constexpr int kConstFloats = kConstHead + kTH * kTW;  // 896 / 1152
+    static size_t lds_bytes() { return sizeof(float) * ((size_t)kNBUF * kSlot + 2 * kConstFloats); }
+};
 
 struct Tile {
     int m_tile, y0, x0, b0;
 };
 
+// The lane id, computed where it is used. The once-per-tile code (tile constants, epilogue) derives its per-lane offsets
+// from this instead of from values computed at kernel entry: those would be live across the k-steps, where every
+// register is taken, hipcc would spill them, and a scratch reload is a vector-memory load -- the s_waitcnt vmcnt(0)
+// behind it drains the whole LDS-DMA ring once per tile.
+__device__ __forceinline__ int fresh_lane() {
+    int l;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+    return l;
+}
+
 }  // namespace
 
-__global__ __launch_bounds__(256, 1) void winograd64_kernel(const ConvArgs p) {
+template <int MT, int TG>
+__device__ __forceinline__ void winograd64_body(const ConvArgs& p) {
+    using G = Geo<MT, TG>;
+    constexpr int kBM = G::kBM, kTH = G::kTH, kPH = G::kPH, kPlane = G::kPlane, kUFloats = G::kUFloats, kPlF4 = G::kPlF4;
+    constexpr int kConstFloats = G::kConstFloats;
+    constexpr int kPlPieces = G::kPlPieces, kSlot = G::kSlot, kPiecesPerWave = G::kPiecesPerWave, kUSlots = G::kUSlots, kPlSlots = G::kPlSlots;
+    typedef float afrag_t __attribute__((ext_vector_type(MT)));
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* const buf0 = smem;
     float* const const0 = smem + kNBUF * kSlot;
@@ -83,6 +113,7 @@ __global__ __launch_bounds__(256, 1) void winograd64_kernel(const ConvArgs p) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lane = tid & 63;
     const int n16 = lane & 15, kq = lane >> 4;
+    const int lane16 = lane * 16;
     const int Hp = p.H + 2, Wp = p.W + 8;
     const int n = p.total_chunks;  // chunks per tile
 
@@ -105,14 +136,14 @@ __global__ __launch_bounds__(256, 1) void winograd64_kernel(const ConvArgs p) {
         return t;
     };
 
-    // ---- LDS-DMA: piece g = wave + 4 r of a chunk; g < 32 weight image, else patch piece g - 32 ----
+    // ---- LDS-DMA: a chunk = kUPieces weight pieces + kPlPieces patch pieces of 256 floats (64 lanes x 16 bytes) ----
     // (tiles are whole: H % 8 == 0, W % 32 == 0, so a patch piece's per-lane source offset depends on nothing but the lane)
-    // A wave's six slots: 0..3 weight pieces wave + 4 r; 4, 5 patch pieces wave + 4 (r - 4), wave 3's second one
-    // repeating patch piece 0 (same bytes: every wave issues six, the waits count them). Piece 6 is a quarter full:
-    // its other lanes copy float4 0 of the piece into the slot's padding. No slot needs a branch or a lane mask.
-    int p_voff[2], p_lds[2];
+    // A wave's slots: first its weight pieces kUSlots wave + r, then its patch pieces wave + 4 r; a slot beyond the last patch
+    // piece repeats patch piece 0 (same bytes: every wave issues as many, the waits count them). The last patch piece is
+    // a quarter full: its other lanes copy float4 0 of the piece into the slot's padding. No slot needs a branch or a mask.
+    int p_voff[kPlSlots], p_lds[kPlSlots];
 #pragma unroll
-    for (int r = 0; r < 2; ++r) {
+    for (int r = 0; r < kPlSlots; ++r) {
         int i = wave + 4 * r;
         if (i >= kPlPieces) i = 0;
         int f = i * 64 + lane;
@@ -132,12 +163,14 @@ __global__ __launch_bounds__(256, 1) void winograd64_kernel(const ConvArgs p) {
     int cur_w_soff = 0, cur_x_soff = 0;        // of the chunk being staged (scalar offsets of its pieces)
     float* cur_buf = buf0;
     __amdgpu_buffer_rsrc_t st_x_rsrc = w_rsrc;
+    const __amdgpu_buffer_rsrc_t nz_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.noise, 0, 0x7fffffff, 0x00020000);
     // Before a chunk's pieces go out: tile descriptors and constants if it opens a tile, then the chunk's scalar offsets.
     // Runs at the top of a k-step, OUTSIDE the woven region (it branches).
     auto stage_begin = [&]() {
         if (st_chunk == 0 && st_tile < my_tiles) {
             const Tile t = decode(st_tile);
-            const int b = min(t.b0, p.B - 1);
+            const int b = t.b0;
+            const int l4 = fresh_lane() * 4;  // every constant below: this one register + scalar offsets
             st_x_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(p.x + (size_t)b * p.x_b_stride), 0, 0x7fffffff, 0x00020000);
             st_w_soff = t.m_tile * n * (kUFloats * 4);
             st_x_soff = (t.y0 * Wp + t.x0) * 4;
@@ -145,16 +178,27 @@ __global__ __launch_bounds__(256, 1) void winograd64_kernel(const ConvArgs p) {
             float* const set = const0 + (st_tile & 1) * kConstFloats;
             const __amdgpu_buffer_rsrc_t s_rsrc =
                 __builtin_amdgcn_make_buffer_rsrc((void*)(p.s + (size_t)b * p.s_stride), 0, p.Cin * 4, 0x00020000);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(s_rsrc, (lds_ptr_t)(set + wave * 64), 4, (wave * 64 + lane) * 4, 0, 0, 0);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(s_rsrc, (lds_ptr_t)(set + (wave + 4) * 64), 4, ((wave + 4) * 64 + lane) * 4, 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(s_rsrc, (lds_ptr_t)(set + wave * 64), 4, l4 + wave * 256, 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(s_rsrc, (lds_ptr_t)(set + (wave + 4) * 64), 4, l4 + (wave + 4) * 256, 0, 0, 0);  // (in the vector offset: the resource's bound clips Cin < 512)
             if (wave < 2) {
                 const __amdgpu_buffer_rsrc_t c_rsrc = __builtin_amdgcn_make_buffer_rsrc(
                     (void*)(wave == 0 ? p.d + (size_t)b * p.d_stride + t.m_tile * kBM : p.bias + t.m_tile * kBM), 0, kBM * 4, 0x00020000);
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(c_rsrc, (lds_ptr_t)(set + 512 + wave * 64), 4, lane * 4, 0, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(c_rsrc, (lds_ptr_t)(set + 512 + wave * 64), 4, l4, 0, 0, 0);
+            }
+            // ... and its noise: the 2 TG pixel rows x 32 columns this wave's epilogue adds, two rows per instruction
+            // (fetched here, n k-steps ahead: a global load inside the epilogue cost its whole latency once per tile)
+            if (p.noise != nullptr) {
+                const int nz_voff = ((l4 & 128) >> 5) * p.OW + (l4 & 127);  // ((lane >> 5) * OW + lane % 32) * 4
+#pragma unroll
+                for (int tg = 0; tg < TG; ++tg) {
+                    const int row = 2 * (wave * TG + tg);
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(nz_rsrc, (lds_ptr_t)(set + kConstHead + row * kTW), 4, nz_voff,
+                                                             ((t.y0 + row) * p.OW + t.x0) * 4, 0, 0);
+                }
             }
         }
         cur_buf = buf0 + st_slot * kSlot;
-        cur_w_soff = st_w_soff + st_chunk * (kUFloats * 4);
+        cur_w_soff = st_w_soff + st_chunk * (kUFloats * 4) + wave * (kUSlots * 1024);  // (of the wave's first weight piece)
         cur_x_soff = st_x_soff + st_chunk * (kKC * Hp * Wp * 4);
         // ... and move the staging position on (staying on the last chunk past the end)
         st_slot = st_slot + 1 == kNBUF ? 0 : st_slot + 1;
@@ -168,11 +212,20 @@ __global__ __launch_bounds__(256, 1) void winograd64_kernel(const ConvArgs p) {
     };
     // slot r of the chunk set up by stage_begin(): one instruction, no control flow
     auto stage_piece = [&](int r) {
-        if (r < 4) {
-            const int g = wave + 4 * r;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, (lds_ptr_t)(cur_buf + g * 256), 16, (g * 256 + lane * 4) * 4, cur_w_soff, 0, 0);
+        if (r < kUSlots) {
+            // weight piece g = kUSlots wave + r: ONE vector register (lane * 16) and one scalar offset for all of a wave's
+            // pieces, r in the instruction's immediate (a register per piece did not survive the epilogue: spilled, and
+            // its reload put a vmcnt wait into the k-step)
+            // (the immediate offset of an LDS-DMA instruction moves BOTH addresses, global and LDS: one LDS base per wave)
+            lds_ptr_t const dst = (lds_ptr_t)(cur_buf + kUSlots * wave * 256);
+            switch (r) {  // (the immediate must be a literal; r is one after unrolling)
+                case 0: __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, dst, 16, lane16, cur_w_soff, 0, 0); break;
+                case 1: __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, dst, 16, lane16, cur_w_soff, 1024, 0); break;
+                case 2: __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, dst, 16, lane16, cur_w_soff, 2048, 0); break;
+                default: __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, dst, 16, lane16, cur_w_soff, 3072, 0); break;
+            }
         } else {
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(st_x_rsrc, (lds_ptr_t)(cur_buf + p_lds[r - 4]), 16, p_voff[r - 4], cur_x_soff, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(st_x_rsrc, (lds_ptr_t)(cur_buf + p_lds[r - kUSlots]), 16, p_voff[r - kUSlots], cur_x_soff, 0, 0);
         }
     };
     // NOTE: st_x_rsrc changes when stage_begin opens a tile; the pieces of that chunk are the first to use it.
@@ -184,45 +237,54 @@ __global__ __launch_bounds__(256, 1) void winograd64_kernel(const ConvArgs p) {
         for (int r = 0; r < kPiecesPerWave; ++r) stage_piece(r);
     }
 
-    f32x4 acc[16][4];
+    f32x4 acc[16][TG][MT];
 #pragma unroll
     for (int q = 0; q < 16; ++q)
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt) acc[q][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int tg = 0; tg < TG; ++tg)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) acc[q][tg][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    // per-lane operand offsets (floats): window of tile (wave, n16): patch rows 2 wave .. + 3, columns 2 n16 + 3 .. + 6
-    const int poff = kq * kPlane + (2 * wave) * kPW + 2 * n16 + 3;
-    const int aoff = (kq * 16 + n16) * 4;  // + pos * kKC * 64
+    // per-lane operand offsets (floats): window of tile (row wave * TG + tg, column n16): patch rows 2 row .. + 3,
+    // columns 2 n16 + 3 .. + 6
+    const int poff = kq * kPlane + (2 * wave * TG) * kPW + 2 * n16 + 3;  // + tg * 2 * kPW
+    const int aoff = (kq * 16 + n16) * MT;  // + pos * kKC * kBM
 
     // ---- pipeline registers ----
-    float win[4][4];  // raw window of the k-step being transformed
+    float win[TG][4][4];  // raw windows of the k-step being transformed
     float sval = 0.f;
     float tcol[4][4];
-    float V[2][16];
+    float V[2][TG][16];
     auto load_window = [&](const float* __restrict__ patch, const float* __restrict__ style) {
-        const float* pc = patch + poff;
 #pragma unroll
-        for (int y = 0; y < 4; ++y)
+        for (int tg = 0; tg < TG; ++tg) {
+            const float* pc = patch + poff + tg * 2 * kPW;
 #pragma unroll
-            for (int x = 0; x < 4; ++x) win[y][x] = pc[y * kPW + x];
+            for (int y = 0; y < 4; ++y)
+#pragma unroll
+                for (int x = 0; x < 4; ++x) win[tg][y][x] = pc[y * kPW + x];
+        }
         sval = style[kq];
     };
     // V = B^T (s d) B, B^T = [[1,0,-1,0],[0,1,1,0],[0,-1,1,0],[0,1,0,-1]]; the style scale rides on the window (V is linear in d)
-    auto transform = [&](float (&out)[16]) {
+    auto transform = [&](float (&outs)[TG][16]) {
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const float e1 = sval * win[1][c], e2 = sval * win[2][c];
-            tcol[0][c] = fmaf(sval, win[0][c], -e2);
-            tcol[1][c] = e1 + e2;
-            tcol[2][c] = e2 - e1;
-            tcol[3][c] = fmaf(-sval, win[3][c], e1);
-        }
+        for (int tg = 0; tg < TG; ++tg) {
 #pragma unroll
-        for (int y = 0; y < 4; ++y) {
-            out[y * 4 + 0] = tcol[y][0] - tcol[y][2];
-            out[y * 4 + 1] = tcol[y][1] + tcol[y][2];
-            out[y * 4 + 2] = tcol[y][2] - tcol[y][1];
-            out[y * 4 + 3] = tcol[y][1] - tcol[y][3];
+            for (int c = 0; c < 4; ++c) {
+                const float e1 = sval * win[tg][1][c], e2 = sval * win[tg][2][c];
+                tcol[0][c] = fmaf(sval, win[tg][0][c], -e2);
+                tcol[1][c] = e1 + e2;
+                tcol[2][c] = e2 - e1;
+                tcol[3][c] = fmaf(-sval, win[tg][3][c], e1);
+            }
+#pragma unroll
+            for (int y = 0; y < 4; ++y) {
+                outs[tg][y * 4 + 0] = tcol[y][0] - tcol[y][2];
+                outs[tg][y * 4 + 1] = tcol[y][1] + tcol[y][2];
+                outs[tg][y * 4 + 2] = tcol[y][2] - tcol[y][1];
+                outs[tg][y * 4 + 3] = tcol[y][1] - tcol[y][3];
+            }
         }
     };
 
@@ -231,70 +293,87 @@ __global__ __launch_bounds__(256, 1) void winograd64_kernel(const ConvArgs p) {
         const Tile t = decode(i);
         const float* const d_lds = const0 + (i & 1) * kConstFloats + 512;
         const float* const b_lds = d_lds + 64;
-        const int oy = t.y0 + 2 * wave, ox = t.x0 + 2 * n16;
-        const bool ok = t.b0 < p.B;
-        float nz[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
-        if (p.noise != nullptr && ok) {
-#pragma unroll
-            for (int dy = 0; dy < 2; ++dy)
-#pragma unroll
-                for (int dx = 0; dx < 2; ++dx) nz[dy][dx] = p.noise[(size_t)(oy + dy) * p.OW + ox + dx] * p.noise_strength;
-        }
+        const float* const nz_lds = const0 + (i & 1) * kConstFloats + kConstHead;
+        const int le = fresh_lane();
+        const int n16 = le & 15, kq = le >> 4;  // (shadow the kernel's: see fresh_lane)
         const int c_stride_bytes = (int)p.out_c_stride * 4;
         const __amdgpu_buffer_rsrc_t o_rsrc = __builtin_amdgcn_make_buffer_rsrc(
             (void*)(p.out + (size_t)t.b0 * p.out_b_stride + (size_t)(t.m_tile * kBM) * p.out_c_stride), 0, 0x7fffffff, 0x00020000);
-        const int voff0 = ((oy + p.out_y_off) * p.out_row_stride + ox + p.out_x_off) * 4 + 4 * kq * c_stride_bytes;
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt) {
+        for (int tg = 0; tg < TG; ++tg) {
+            const int oy = t.y0 + 2 * (wave * TG + tg), ox = t.x0 + 2 * n16;
+            float nz[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
+            if (p.noise != nullptr) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                // one channel at a time (fenced): without it hipcc pulls all 256 accumulators into VGPRs at once
+                for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+                    for (int dx = 0; dx < 2; ++dx) nz[dy][dx] = nz_lds[(2 * (wave * TG + tg) + dy) * kTW + 2 * n16 + dx] * p.noise_strength;
+            }
+            const int voff0 = ((oy + p.out_y_off) * p.out_row_stride + ox + p.out_x_off) * 4 + 4 * kq * c_stride_bytes;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                // One accumulator tile set at a time, fenced: the 16 positions of four channels (whole MFMA result
+                // tuples: consuming single components of all 64 tuples channel by channel made hipcc shuffle the
+                // accumulator file and spill), cleared as soon as they are read. Without the fence hipcc pulls all 256
+                // accumulators into VGPRs at once.
                 __builtin_amdgcn_sched_barrier(0);
-                const int m = mt * 16 + 4 * kq + r;
-                float u[2][4];
+                // demodulation and bias of this lane's channels mt * 16 + 4 kq + (0 .. 3): one 16-byte read each
+                const f32x4 dm = *reinterpret_cast<const f32x4*>(d_lds + mt * 16 + 4 * kq);
+                const f32x4 bm = *reinterpret_cast<const f32x4*>(b_lds + mt * 16 + 4 * kq);
+                f32x4 m[16];
+#pragma unroll
+                for (int pos = 0; pos < 16; ++pos) {
+                    m[pos] = acc[pos][tg][mt];
+                    acc[pos][tg][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+                f32x4 u[2][4];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    u[0][j] = acc[0 * 4 + j][mt][r] + acc[1 * 4 + j][mt][r] + acc[2 * 4 + j][mt][r];
-                    u[1][j] = acc[1 * 4 + j][mt][r] - acc[2 * 4 + j][mt][r] - acc[3 * 4 + j][mt][r];
+                    u[0][j] = m[0 * 4 + j] + m[1 * 4 + j] + m[2 * 4 + j];
+                    u[1][j] = m[1 * 4 + j] - m[2 * 4 + j] - m[3 * 4 + j];
                 }
-                const float dm = d_lds[m], bm = b_lds[m];
+                f32x4 y[2][2];
 #pragma unroll
                 for (int dy = 0; dy < 2; ++dy) {
-                    float y2[2];
-                    y2[0] = u[dy][0] + u[dy][1] + u[dy][2];
-                    y2[1] = u[dy][1] - u[dy][2] - u[dy][3];
+                    y[dy][0] = u[dy][0] + u[dy][1] + u[dy][2];
+                    y[dy][1] = u[dy][1] - u[dy][2] - u[dy][3];
 #pragma unroll
                     for (int dx = 0; dx < 2; ++dx) {
-                        float v = y2[dx] * dm;
+                        f32x4 v = y[dy][dx] * dm;
                         v += nz[dy][dx] + bm;
-                        v = fmaxf(v, 0.2f * v) * 1.4142135623730951f;
-                        y2[dx] = v;
-                    }
-                    if (ok) {
-                        u32x2 pair;
-                        pair[0] = __float_as_uint(y2[0]);
-                        pair[1] = __float_as_uint(y2[1]);
-                        __builtin_amdgcn_raw_buffer_store_b64(pair, o_rsrc, voff0 + dy * p.out_row_stride * 4, (mt * 16 + r) * c_stride_bytes, 0);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.2f * v[r]) * 1.4142135623730951f;
+                        y[dy][dx] = v;
                     }
                 }
+                if (GANCE_W64_ABLATE & 1) {
+                    asm volatile("" ::"v"(y[0][0]), "v"(y[0][1]), "v"(y[1][0]), "v"(y[1][1]));
+                    continue;
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int dy = 0; dy < 2; ++dy) {
+                        u32x2 pair;
+                        pair[0] = __float_as_uint(y[dy][0][r]);
+                        pair[1] = __float_as_uint(y[dy][1][r]);
+                        __builtin_amdgcn_raw_buffer_store_b64(pair, o_rsrc, voff0 + dy * p.out_row_stride * 4, (mt * 16 + r) * c_stride_bytes, 0);
+                    }
             }
         }
-#pragma unroll
-        for (int q = 0; q < 16; ++q)
-#pragma unroll
-            for (int mt = 0; mt < 4; ++mt) acc[q][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        __builtin_amdgcn_sched_barrier(0);
     };
 
     // ---- prologue of the pipeline: first chunk visible, V of its k-step, its weight fragments ----
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((kNBUF - 2) * kPiecesPerWave) : "memory");
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((kNBUF - 2) * G::kPiecesPerWave) : "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     load_window(buf0 + kUFloats, const0);
     transform(V[0]);
-    // weight fragments of a k-step are read during the k-step before it (64 + 64 registers)
-    f32x4 afrag[2][16];
+    // weight fragments of a k-step are read during the k-step before it (2 x 16 x MT registers)
+    afrag_t afrag[2][16];
 #pragma unroll
-    for (int pos = 0; pos < 16; ++pos) afrag[0][pos] = *reinterpret_cast<const f32x4*>(buf0 + aoff + pos * kKC * kBM);
+    for (int pos = 0; pos < 16; ++pos) afrag[0][pos] = *reinterpret_cast<const afrag_t*>(buf0 + aoff + pos * kKC * kBM);
 
     // ---- the stream: chunk q = k-step q of the block's stream, ring slot q % NBUF ----
     // A k-step is ONE branch-free scheduling region: the 64 MFMAs of k-step q, and for k-step q+1 its 16 weight-fragment
@@ -306,8 +385,12 @@ __global__ __launch_bounds__(256, 1) void winograd64_kernel(const ConvArgs p) {
     int q = 0;     // its index in the block's stream
     // tiles in the outer loop, their chunks in the inner one, the epilogue unconditionally after it: the accumulators
     // must not flow through a conditional (hipcc then moves all 256 of them through VGPRs and scratch)
-    for (int tile = 0; tile < my_tiles; ++tile) {
-        for (int chunk = 0; chunk < n; chunk += 2) {
+    // (do-while, both: every block has a tile and a tile has chunks; the guard path of a `for` that hipcc adds -- all
+    // accumulators zero, merged with the real path in front of the epilogue -- cost accumulator copies and spills there)
+    int tile = 0;
+    do {
+        int chunk = 0;
+        do {
             // (two k-steps per trip so that V[0] / V[1] alternate with compile-time indices; n is even)
 #pragma unroll
             for (int half = 0; half < 2; ++half, ++q) {
@@ -325,8 +408,11 @@ __global__ __launch_bounds__(256, 1) void winograd64_kernel(const ConvArgs p) {
 #pragma unroll
                     for (int pos = first; pos < last; ++pos)
 #pragma unroll
-                        for (int mt = 0; mt < 4; ++mt)
-                            acc[pos][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(afrag[half][pos][mt], V[half][pos], acc[pos][mt], 0, 0, 0);
+                        for (int tg = 0; tg < TG; ++tg)
+#pragma unroll
+                            for (int mt = 0; mt < MT; ++mt)
+                                acc[pos][tg][mt] =
+                                    __builtin_amdgcn_mfma_f32_16x16x4f32(afrag[half][pos][mt], V[half][tg][pos], acc[pos][tg][mt], 0, 0, 0);
                 };
                 __builtin_amdgcn_sched_barrier(0);
                 mfma_positions(0, 4);
@@ -335,49 +421,53 @@ __global__ __launch_bounds__(256, 1) void winograd64_kernel(const ConvArgs p) {
                 // chunk q+1 was issued four k-steps ago: wait for it (the three younger chunks stay in flight); once every
                 // wave is here chunk q-1 is dead and its slot takes the six pieces woven below
                 if (!(W64_DBG & 64)) {
-                    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((kNBUF - 3) * kPiecesPerWave) : "memory");
+                    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((kNBUF - 3) * G::kPiecesPerWave) : "memory");
                     __builtin_amdgcn_s_barrier();
                     asm volatile("" ::: "memory");
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 load_window(Un + kUFloats, style_n);
 #pragma unroll
-                for (int pos = 0; pos < 16; ++pos) afrag[(half + 1) & 1][pos] = *reinterpret_cast<const f32x4*>(Un + aoff + pos * kKC * kBM);
+                for (int pos = 0; pos < 16; ++pos) afrag[(half + 1) & 1][pos] = *reinterpret_cast<const afrag_t*>(Un + aoff + pos * kKC * kBM);
                 if (!(W64_DBG & 32)) transform(V[(half + 1) & 1]);
                 if (!(W64_DBG & 2)) {
 #pragma unroll
                     for (int r = 0; r < kPiecesPerWave; ++r) stage_piece(r);
                 }
                 mfma_positions(4, 16);
-                // weave: 48 x (1 MFMA, then what fits in its shadow): the 26 LDS reads first (they feed everything else),
-                // the 40 transform instructions and the six DMA issues spread over the rest
+                // weave: 48 x (1 MFMA, then what fits in its shadow): the LDS reads first (16 weight fragments + 9 per window:
+                // they feed everything else), the 40 transform instructions per window and the DMA issues spread over the rest
 #pragma unroll
                 for (int i = 0; i < 48; ++i) {
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                 // 1 MFMA
-                    if (i < 26) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);      // 1 LDS read
-                    if (i >= 4) __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);      // 1 VALU
-                    if (i % 8 == 7) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);  // 1 LDS-DMA issue
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                              // 1 MFMA
+                    if (i < 17 + 9 * TG) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);          // 1 LDS read
+                    if (i >= 4) __builtin_amdgcn_sched_group_barrier(0x002, TG, 0);                  // 1 VALU per window
+                    if (i % 8 == 7) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);               // 1 LDS-DMA issue
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 slot = next_slot;
             }
-        }
+            chunk += 2;
+        } while (chunk < n);
         epilogue(tile);
-    }
+    } while (++tile < my_tiles);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // nothing of the ring may still be landing when the block's LDS is given back
 }
 
 bool winograd64_supported(int cin, int cout, int H, int W) {
-    // (an even number of chunks per tile, and at least NBUF of them)
-    return cin % (2 * kKC) == 0 && cin <= 512 && cin / kKC >= kNBUF && cout % kBM == 0 && H % kTH == 0 && W % kTW == 0;
+    // (an even number of chunks per tile, and at least NBUF of them). 32-channel layers take the <2, 2> geometry.
+    const bool geometry = cout % 64 == 0 ? (H % 8 == 0 && W % kTW == 0) : (cout % 32 == 0 && H % 16 == 0 && W % kTW == 0);
+    return cin % (2 * kKC) == 0 && cin <= 512 && cin / kKC >= kNBUF && geometry;
 }
 
 size_t winograd64_weight_floats(int cin, int cout) { return (size_t)16 * cin * cout; }
 
-// w_in: the layer's runtime-scaled weights [tap = ky*3+kx][ci][co]; w_out: [m tile of 64][chunk of 4][pos][ci][co % 16][co / 16]
+// w_in: the layer's runtime-scaled weights [tap = ky*3+kx][ci][co]; w_out: [m tile of BM][chunk of 4][pos][ci][co % 16][co / 16]
+// with BM = 64 channels per block when cout is a multiple of 64, else 32
 void winograd64_transform_weights(const float* w_in, int cin, int cout, float* w_out) {
     const double G[4][3] = {{1., 0., 0.}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0., 0., 1.}};
-    const int chunks = cin / kKC;
+    const int bm = cout % 64 == 0 ? 64 : 32, mt_count = bm / 16;
+    const int chunks = cin / kKC, u_floats = 16 * kKC * bm;
     for (int co = 0; co < cout; ++co)
         for (int ci = 0; ci < cin; ++ci) {
             double g[3][3], tmp[4][3], u[4][4];
@@ -387,21 +477,28 @@ void winograd64_transform_weights(const float* w_in, int cin, int cout, float* w
                 for (int kx = 0; kx < 3; ++kx) tmp[i][kx] = G[i][0] * g[0][kx] + G[i][1] * g[1][kx] + G[i][2] * g[2][kx];
             for (int i = 0; i < 4; ++i)
                 for (int j = 0; j < 4; ++j) u[i][j] = tmp[i][0] * G[j][0] + tmp[i][1] * G[j][1] + tmp[i][2] * G[j][2];
-            const int mtile = co / kBM, m = co % kBM, ch = ci / kKC, kc = ci % kKC;
-            float* dst = w_out + ((size_t)mtile * chunks + ch) * kUFloats;
+            const int mtile = co / bm, m = co % bm, ch = ci / kKC, kc = ci % kKC;
+            float* dst = w_out + ((size_t)mtile * chunks + ch) * u_floats;
             for (int i = 0; i < 4; ++i)
-                for (int j = 0; j < 4; ++j) dst[(((i * 4 + j) * kKC + kc) * 16 + m % 16) * 4 + m / 16] = (float)u[i][j];
+                for (int j = 0; j < 4; ++j) dst[(((i * 4 + j) * kKC + kc) * 16 + m % 16) * mt_count + m / 16] = (float)u[i][j];
         }
 }
 
-hipError_t launch_winograd64_conv(const ConvArgs& args, hipStream_t stream) {
-    if (args.epilogue != kEpilogueFull) return hipErrorInvalidValue;
+
+// The kernels are plain functions around the templated body: as a kernel TEMPLATE the host pass of hipcc drops the
+// instantiation without a diagnostic (the 16-byte LDS-DMA builtin does not pass the host's feature check) and the
+// library is left with an undefined stub.
+__global__ __launch_bounds__(256, 1) void winograd64_kernel(const ConvArgs p) { winograd64_body<4, 1>(p); }
+__global__ __launch_bounds__(256, 1) void winograd64_c32_kernel(const ConvArgs p) { winograd64_body<2, 2>(p); }
+
+template <int MT, int TG>
+static hipError_t launch_variant(void (*kernel)(const ConvArgs), const ConvArgs& args, hipStream_t stream) {
+    using G = Geo<MT, TG>;
     static PerDeviceInt resident;  // per device: the dynamic-LDS opt-in and the launch size = one block per CU, a multiple of 8 (XCDs)
     int resident_blocks = 0;
     hipError_t e = resident.get(
         [&](int device, int* value) {
-            hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(winograd64_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                 (int)lds_bytes());
+            hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::lds_bytes());
             if (err != hipSuccess) return err;
             int cus = 0;
             if ((err = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device)) != hipSuccess) return err;
@@ -414,13 +511,18 @@ hipError_t launch_winograd64_conv(const ConvArgs& args, hipStream_t stream) {
     static const int env_debug = [] { const char* v = std::getenv("GANCE_DEBUG_W64"); return v ? std::atoi(v) : 0; }();
     a.debug_flags = env_debug;
     a.tiles_x = a.W / kTW;
-    a.tiles_y = a.H / kTH;
-    a.m_tiles = a.Cout / kBM;
+    a.tiles_y = a.H / G::kTH;
+    a.m_tiles = a.Cout / G::kBM;
     a.total_chunks = a.Cin / kKC;
     a.total_tiles = a.m_tiles * a.tiles_x * a.tiles_y * a.B;
     const int blocks = std::min(a.total_tiles, resident_blocks);
-    hipLaunchKernelGGL(winograd64_kernel, dim3(blocks), dim3(256), lds_bytes(), stream, a);
+    hipLaunchKernelGGL(kernel, dim3(blocks), dim3(256), G::lds_bytes(), stream, a);
     return hipGetLastError();
+}
+
+hipError_t launch_winograd64_conv(const ConvArgs& args, hipStream_t stream) {
+    if (args.epilogue != kEpilogueFull) return hipErrorInvalidValue;
+    return args.Cout % 64 == 0 ? launch_variant<4, 1>(winograd64_kernel, args, stream) : launch_variant<2, 2>(winograd64_c32_kernel, args, stream);
 }
 
 }  // namespace gance
