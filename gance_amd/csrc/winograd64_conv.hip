@@ -111,18 +111,14 @@ __device__ __forceinline__ void winograd64_body(const ConvArgs& p) {
 
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int lane = tid & 63;
-    const int n16 = lane & 15, kq = lane >> 4;
-    const int lane16 = lane * 16;
     const int Hp = p.H + 2, Wp = p.W + 8;
     const int n = p.total_chunks;  // chunks per tile
 
     const int my_tiles = (p.total_tiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
-    const int total_chunks = my_tiles * n;
     auto decode = [&](int i) {
         // virtual block id -> tile, XCD-aware (a persistent block strides by a multiple of 8): the channel tiles of a
         // pixel tile and neighbouring pixel tiles land on one XCD's L2 at about the same time
-        const int v = (int)blockIdx.x + min(i, my_tiles - 1) * (int)gridDim.x;
+        const int v = (int)blockIdx.x + i * (int)gridDim.x;  // i < my_tiles
         const int nwg = p.total_tiles;
         const int q = nwg >> 3, r = nwg & 7, xcd = v & 7;
         int id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (v >> 3);
@@ -141,74 +137,95 @@ __device__ __forceinline__ void winograd64_body(const ConvArgs& p) {
     // A wave's slots: first its weight pieces kUSlots wave + r, then its patch pieces wave + 4 r; a slot beyond the last patch
     // piece repeats patch piece 0 (same bytes: every wave issues as many, the waits count them). The last patch piece is
     // a quarter full: its other lanes copy float4 0 of the piece into the slot's padding. No slot needs a branch or a mask.
+    //
+    // Every per-lane offset of the k-steps lives in these few registers, and they are recomputed from the lane id at the
+    // top of every tile (lane_offsets): values computed once at kernel entry are live across the epilogue, where hipcc
+    // spills them, and a scratch reload is a vector-memory load -- the s_waitcnt vmcnt(0) behind it drains the DMA ring.
+    int kq, lane16, poff, aoff;
     int p_voff[kPlSlots], p_lds[kPlSlots];
+    auto lane_offsets = [&]() {
+        const int lane = fresh_lane();
+        const int n16 = lane & 15;
+        kq = lane >> 4;
+        lane16 = lane * 16;
+        // operand offsets (floats): window of tile (row wave * TG + tg, column n16): patch rows 2 row .. + 3, columns
+        // 2 n16 + 3 .. + 6; weight fragment of (input channel kq, output channels n16 + 16 mt)
+        poff = kq * kPlane + (2 * wave * TG) * kPW + 2 * n16 + 3;  // + tg * 2 * kPW
+        aoff = (kq * 16 + n16) * MT;                               // + pos * kKC * kBM
 #pragma unroll
-    for (int r = 0; r < kPlSlots; ++r) {
-        int i = wave + 4 * r;
-        if (i >= kPlPieces) i = 0;
-        int f = i * 64 + lane;
-        if (f >= kPlF4) f = i * 64;
-        const int q = f % (kPW / 4);
-        const int row = (f / (kPW / 4)) % kPH;
-        const int c = f / (kPW / 4 * kPH);
-        p_voff[r] = ((c * Hp + row) * Wp + 4 * q) * 4;
-        p_lds[r] = kUFloats + i * 256;
-    }
+        for (int r = 0; r < kPlSlots; ++r) {
+            int i = wave + 4 * r;
+            if (i >= kPlPieces) i = 0;
+            int f = i * 64 + lane;
+            if (f >= kPlF4) f = i * 64;
+            const int q = f % (kPW / 4);
+            const int row = (f / (kPW / 4)) % kPH;
+            const int c = f / (kPW / 4 * kPH);
+            p_voff[r] = ((c * Hp + row) * Wp + 4 * q) * 4;
+            p_lds[r] = kUFloats + i * 256;
+        }
+    };
+    lane_offsets();
     const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, 0x7fffffff, 0x00020000);
-    // staging side of the stream: which (tile, chunk) is fetched next, into which ring slot. Past the end of the
-    // stream the last chunk is fetched again into the free slot (nobody reads it): every k-step then issues the same
-    // number of pieces and the counted waits need no tail case.
-    int st_tile = 0, st_chunk = 0, st_slot = 0;
-    int st_w_soff = 0, st_x_soff = 0;          // of the tile being staged
-    int cur_w_soff = 0, cur_x_soff = 0;        // of the chunk being staged (scalar offsets of its pieces)
-    float* cur_buf = buf0;
+    // Staging side of the stream, kept as running offsets (every scalar instruction of a k-step costs its issue time
+    // beside the MFMAs, so the per-k-step bookkeeping is a handful of adds): the next tile to open, the chunks of the open
+    // tile still to fetch, the ring slot to fetch into (float offset in smem) and the global byte offsets of the next
+    // chunk's weights (this wave's pieces) and patch. Past the end of the stream the last chunk is fetched again into
+    // the free slot (nobody reads it): every k-step issues the same number of pieces and the counted waits need no tail.
+    int st_tile = 0, st_left = 0, st_off = 0;
+    int st_w = 0, st_x = 0;
+    const int x_step = kKC * Hp * Wp * 4;
+    int cur_off = 0, cur_w_soff = 0, cur_x_soff = 0;  // of the chunk being staged
     __amdgpu_buffer_rsrc_t st_x_rsrc = w_rsrc;
     const __amdgpu_buffer_rsrc_t nz_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.noise, 0, 0x7fffffff, 0x00020000);
     // Before a chunk's pieces go out: tile descriptors and constants if it opens a tile, then the chunk's scalar offsets.
     // Runs at the top of a k-step, OUTSIDE the woven region (it branches).
     auto stage_begin = [&]() {
-        if (st_chunk == 0 && st_tile < my_tiles) {
-            const Tile t = decode(st_tile);
-            const int b = t.b0;
-            const int l4 = fresh_lane() * 4;  // every constant below: this one register + scalar offsets
-            st_x_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(p.x + (size_t)b * p.x_b_stride), 0, 0x7fffffff, 0x00020000);
-            st_w_soff = t.m_tile * n * (kUFloats * 4);
-            st_x_soff = (t.y0 * Wp + t.x0) * 4;
-            // the tile's constants (style of the sample, demod and bias of the channel tile) by dword LDS-DMA
-            float* const set = const0 + (st_tile & 1) * kConstFloats;
-            const __amdgpu_buffer_rsrc_t s_rsrc =
-                __builtin_amdgcn_make_buffer_rsrc((void*)(p.s + (size_t)b * p.s_stride), 0, p.Cin * 4, 0x00020000);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(s_rsrc, (lds_ptr_t)(set + wave * 64), 4, l4 + wave * 256, 0, 0, 0);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(s_rsrc, (lds_ptr_t)(set + (wave + 4) * 64), 4, l4 + (wave + 4) * 256, 0, 0, 0);  // (in the vector offset: the resource's bound clips Cin < 512)
-            if (wave < 2) {
-                const __amdgpu_buffer_rsrc_t c_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-                    (void*)(wave == 0 ? p.d + (size_t)b * p.d_stride + t.m_tile * kBM : p.bias + t.m_tile * kBM), 0, kBM * 4, 0x00020000);
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(c_rsrc, (lds_ptr_t)(set + 512 + wave * 64), 4, l4, 0, 0, 0);
-            }
-            // ... and its noise: the 2 TG pixel rows x 32 columns this wave's epilogue adds, two rows per instruction
-            // (fetched here, n k-steps ahead: a global load inside the epilogue cost its whole latency once per tile)
-            if (p.noise != nullptr) {
-                const int nz_voff = ((l4 & 128) >> 5) * p.OW + (l4 & 127);  // ((lane >> 5) * OW + lane % 32) * 4
-#pragma unroll
-                for (int tg = 0; tg < TG; ++tg) {
-                    const int row = 2 * (wave * TG + tg);
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(nz_rsrc, (lds_ptr_t)(set + kConstHead + row * kTW), 4, nz_voff,
-                                                             ((t.y0 + row) * p.OW + t.x0) * 4, 0, 0);
+        if (st_left == 0) {
+            if (st_tile < my_tiles) {
+                const Tile t = decode(st_tile);
+                const int b = t.b0;
+                const int l4 = fresh_lane() * 4;  // every constant below: this one register + scalar offsets
+                st_x_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(p.x + (size_t)b * p.x_b_stride), 0, 0x7fffffff, 0x00020000);
+                st_w = t.m_tile * n * (kUFloats * 4) + wave * (kUSlots * 1024);  // (of the wave's first weight piece)
+                st_x = (t.y0 * Wp + t.x0) * 4;
+                // the tile's constants (style of the sample, demod and bias of the channel tile) by dword LDS-DMA
+                float* const set = const0 + (st_tile & 1) * kConstFloats;
+                const __amdgpu_buffer_rsrc_t s_rsrc =
+                    __builtin_amdgcn_make_buffer_rsrc((void*)(p.s + (size_t)b * p.s_stride), 0, p.Cin * 4, 0x00020000);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(s_rsrc, (lds_ptr_t)(set + wave * 64), 4, l4 + wave * 256, 0, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(s_rsrc, (lds_ptr_t)(set + (wave + 4) * 64), 4, l4 + (wave + 4) * 256, 0, 0, 0);  // (in the vector offset: the resource's bound clips Cin < 512)
+                if (wave < 2) {
+                    const __amdgpu_buffer_rsrc_t c_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+                        (void*)(wave == 0 ? p.d + (size_t)b * p.d_stride + t.m_tile * kBM : p.bias + t.m_tile * kBM), 0, kBM * 4, 0x00020000);
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(c_rsrc, (lds_ptr_t)(set + 512 + wave * 64), 4, l4, 0, 0, 0);
                 }
-            }
-        }
-        cur_buf = buf0 + st_slot * kSlot;
-        cur_w_soff = st_w_soff + st_chunk * (kUFloats * 4) + wave * (kUSlots * 1024);  // (of the wave's first weight piece)
-        cur_x_soff = st_x_soff + st_chunk * (kKC * Hp * Wp * 4);
-        // ... and move the staging position on (staying on the last chunk past the end)
-        st_slot = st_slot + 1 == kNBUF ? 0 : st_slot + 1;
-        const bool last = st_tile + 1 >= my_tiles && st_chunk + 1 >= n;
-        if (!last) {
-            if (++st_chunk == n) {
-                st_chunk = 0;
+                // ... and its noise: the 2 TG pixel rows x 32 columns this wave's epilogue adds, two rows per instruction
+                // (fetched here, n k-steps ahead: a global load inside the epilogue cost its whole latency once per tile)
+                if (p.noise != nullptr) {
+                    const int nz_voff = ((l4 & 128) >> 5) * p.OW + (l4 & 127);  // ((lane >> 5) * OW + lane % 32) * 4
+#pragma unroll
+                    for (int tg = 0; tg < TG; ++tg) {
+                        const int row = 2 * (wave * TG + tg);
+                        __builtin_amdgcn_raw_ptr_buffer_load_lds(nz_rsrc, (lds_ptr_t)(set + kConstHead + row * kTW), 4, nz_voff,
+                                                                 ((t.y0 + row) * p.OW + t.x0) * 4, 0, 0);
+                    }
+                }
+                st_left = n;
                 ++st_tile;
+            } else {  // past the end: the last chunk again
+                st_w -= kUFloats * 4;
+                st_x -= x_step;
+                st_left = 1;
             }
         }
+        cur_off = st_off;
+        cur_w_soff = st_w;
+        cur_x_soff = st_x;
+        st_w += kUFloats * 4;
+        st_x += x_step;
+        --st_left;
+        st_off = st_off + kSlot == kNBUF * kSlot ? 0 : st_off + kSlot;
     };
     // slot r of the chunk set up by stage_begin(): one instruction, no control flow
     auto stage_piece = [&](int r) {
@@ -217,7 +234,7 @@ __device__ __forceinline__ void winograd64_body(const ConvArgs& p) {
             // pieces, r in the instruction's immediate (a register per piece did not survive the epilogue: spilled, and
             // its reload put a vmcnt wait into the k-step)
             // (the immediate offset of an LDS-DMA instruction moves BOTH addresses, global and LDS: one LDS base per wave)
-            lds_ptr_t const dst = (lds_ptr_t)(cur_buf + kUSlots * wave * 256);
+            lds_ptr_t const dst = (lds_ptr_t)(smem + cur_off + kUSlots * wave * 256);
             switch (r) {  // (the immediate must be a literal; r is one after unrolling)
                 case 0: __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, dst, 16, lane16, cur_w_soff, 0, 0); break;
                 case 1: __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, dst, 16, lane16, cur_w_soff, 1024, 0); break;
@@ -225,7 +242,7 @@ __device__ __forceinline__ void winograd64_body(const ConvArgs& p) {
                 default: __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, dst, 16, lane16, cur_w_soff, 3072, 0); break;
             }
         } else {
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(st_x_rsrc, (lds_ptr_t)(cur_buf + p_lds[r - kUSlots]), 16, p_voff[r - kUSlots], cur_x_soff, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(st_x_rsrc, (lds_ptr_t)(smem + cur_off + p_lds[r - kUSlots]), 16, p_voff[r - kUSlots], cur_x_soff, 0, 0);
         }
     };
     // NOTE: st_x_rsrc changes when stage_begin opens a tile; the pieces of that chunk are the first to use it.
@@ -245,26 +262,25 @@ __device__ __forceinline__ void winograd64_body(const ConvArgs& p) {
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) acc[q][tg][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    // per-lane operand offsets (floats): window of tile (row wave * TG + tg, column n16): patch rows 2 row .. + 3,
-    // columns 2 n16 + 3 .. + 6
-    const int poff = kq * kPlane + (2 * wave * TG) * kPW + 2 * n16 + 3;  // + tg * 2 * kPW
-    const int aoff = (kq * 16 + n16) * MT;  // + pos * kKC * kBM
-
     // ---- pipeline registers ----
     float win[TG][4][4];  // raw windows of the k-step being transformed
     float sval = 0.f;
     float tcol[4][4];
     float V[2][TG][16];
-    auto load_window = [&](const float* __restrict__ patch, const float* __restrict__ style) {
+    // (slot_off, style_off: float offsets in smem. The window base is made opaque to the compiler: folded into the 16
+    // reads as one big constant each, it cost a vector add per ds_read2 -- from one base the rows are immediates)
+    auto load_window = [&](int slot_off, int style_off) {
+        int po = slot_off + kUFloats + poff;
+        asm volatile("" : "+v"(po));
 #pragma unroll
         for (int tg = 0; tg < TG; ++tg) {
-            const float* pc = patch + poff + tg * 2 * kPW;
+            const float* pc = smem + po + tg * 2 * kPW;
 #pragma unroll
             for (int y = 0; y < 4; ++y)
 #pragma unroll
                 for (int x = 0; x < 4; ++x) win[tg][y][x] = pc[y * kPW + x];
         }
-        sval = style[kq];
+        sval = smem[style_off + kq];
     };
     // V = B^T (s d) B, B^T = [[1,0,-1,0],[0,1,1,0],[0,-1,1,0],[0,1,0,-1]]; the style scale rides on the window (V is linear in d)
     auto transform = [&](float (&outs)[TG][16]) {
@@ -368,38 +384,40 @@ __device__ __forceinline__ void winograd64_body(const ConvArgs& p) {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"((kNBUF - 2) * G::kPiecesPerWave) : "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
-    load_window(buf0 + kUFloats, const0);
+    load_window(0, kNBUF * kSlot);
     transform(V[0]);
     // weight fragments of a k-step are read during the k-step before it (2 x 16 x MT registers)
     afrag_t afrag[2][16];
 #pragma unroll
     for (int pos = 0; pos < 16; ++pos) afrag[0][pos] = *reinterpret_cast<const afrag_t*>(buf0 + aoff + pos * kKC * kBM);
 
-    // ---- the stream: chunk q = k-step q of the block's stream, ring slot q % NBUF ----
+    // ---- the stream: k-step q of the block multiplies chunk q, ring slot q % NBUF ----
     // A k-step is ONE branch-free scheduling region: the 64 MFMAs of k-step q, and for k-step q+1 its 16 weight-fragment
     // reads (ds_read_b128), its window reads and its 40-instruction transform; six DMA pieces of chunk q+5. A wave alone on its SIMD
     // keeps the matrix pipe busy only if the other instructions sit in the 32-cycle shadows BETWEEN the MFMAs (in clumps
     // between groups of MFMAs they cost their full issue time: 0.60 of the peak); the sched_group_barrier pattern below
     // deals them out one MFMA at a time.
-    int slot = 0;  // ring slot of the chunk being multiplied
-    int q = 0;     // its index in the block's stream
+    int mul_off = 0;  // ring slot (float offset in smem) of the chunk being multiplied
     // tiles in the outer loop, their chunks in the inner one, the epilogue unconditionally after it: the accumulators
     // must not flow through a conditional (hipcc then moves all 256 of them through VGPRs and scratch)
     // (do-while, both: every block has a tile and a tile has chunks; the guard path of a `for` that hipcc adds -- all
     // accumulators zero, merged with the real path in front of the epilogue -- cost accumulator copies and spills there)
     int tile = 0;
     do {
+        lane_offsets();
+        // style of the NEXT k-step (float offset in smem): this tile's constant set, then chunk 0 of the next tile's
+        const int next_set = kNBUF * kSlot + ((tile + 1) & 1) * kConstFloats;
+        int style_n = kNBUF * kSlot + (tile & 1) * kConstFloats + kKC;
         int chunk = 0;
         do {
             // (two k-steps per trip so that V[0] / V[1] alternate with compile-time indices; n is even)
 #pragma unroll
-            for (int half = 0; half < 2; ++half, ++q) {
-                const int next_slot = slot + 1 == kNBUF ? 0 : slot + 1;
-                const float* const Uc = buf0 + slot * kSlot;  // (only its successor is read below)
-                // (the stream's last k-step reads its own chunk again instead of a next one: no tail case)
-                const float* const Un = q + 1 < total_chunks ? buf0 + next_slot * kSlot : Uc;
-                const int c_here = chunk + half;
-                const float* const style_n = c_here + 1 == n ? const0 + ((tile + 1) & 1) * kConstFloats : const0 + (tile & 1) * kConstFloats + (c_here + 1) * kKC;
+            for (int half = 0; half < 2; ++half) {
+                // the chunk after this one: the next ring slot (the stream's last k-step reads a slot nobody filled and
+                // transforms it for nothing: no tail case)
+                const int next_off = mul_off + kSlot == kNBUF * kSlot ? 0 : mul_off + kSlot;
+                const float* const Un = smem + next_off;
+                const int style_here = half == 1 && chunk + 2 == n ? next_set : style_n;
                 // The MFMAs of k-step q have their operands in registers: the first sixteen go out BEFORE the wait and the
                 // barrier, so the matrix pipe works while the wave does the staging bookkeeping (scalar, branchy) and waits
                 // for its siblings.
@@ -418,15 +436,18 @@ __device__ __forceinline__ void winograd64_body(const ConvArgs& p) {
                 mfma_positions(0, 4);
                 stage_begin();
                 __builtin_amdgcn_sched_barrier(0);
-                // chunk q+1 was issued four k-steps ago: wait for it (the three younger chunks stay in flight); once every
-                // wave is here chunk q-1 is dead and its slot takes the six pieces woven below
-                if (!(W64_DBG & 64)) {
-                    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((kNBUF - 3) * G::kPiecesPerWave) : "memory");
+                // ONE wait and barrier per PAIR of k-steps (7 % of the kernel's time went into one per k-step): in front of
+                // the even k-step q the wave waits for chunks q+1 and q+2 -- issued four and three k-steps ago, the two
+                // younger chunks stay in flight -- and the block synchronises. Behind the barrier both are visible to every
+                // wave, and the slots the pair's DMA pieces go to (chunks q+5 and q+6 into the slots of q-1 and q) were last
+                // read in k-steps q-2 and q-1, which every wave has left.
+                if (half == 0 && !(W64_DBG & 64)) {
+                    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((kNBUF - 4) * G::kPiecesPerWave) : "memory");
                     __builtin_amdgcn_s_barrier();
                     asm volatile("" ::: "memory");
                 }
                 __builtin_amdgcn_sched_barrier(0);
-                load_window(Un + kUFloats, style_n);
+                load_window(next_off, style_here);
 #pragma unroll
                 for (int pos = 0; pos < 16; ++pos) afrag[(half + 1) & 1][pos] = *reinterpret_cast<const afrag_t*>(Un + aoff + pos * kKC * kBM);
                 if (!(W64_DBG & 32)) transform(V[(half + 1) & 1]);
@@ -445,7 +466,8 @@ __device__ __forceinline__ void winograd64_body(const ConvArgs& p) {
                     if (i % 8 == 7) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);               // 1 LDS-DMA issue
                 }
                 __builtin_amdgcn_sched_barrier(0);
-                slot = next_slot;
+                mul_off = next_off;
+                style_n += kKC;
             }
             chunk += 2;
         } while (chunk < n);
