@@ -49,6 +49,8 @@ namespace gance {
 namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2_lds __attribute__((ext_vector_type(2), aligned(4)));  // a window's column pair: ds_read2_b32
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
@@ -263,9 +265,8 @@ __device__ __forceinline__ void winograd64_body(const ConvArgs& p) {
             for (int mt = 0; mt < MT; ++mt) acc[q][tg][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     // ---- pipeline registers ----
-    float win[TG][4][4];  // raw windows of the k-step being transformed
+    f32x2 win[TG][4][2];  // raw windows of the k-step being transformed: [row][column pair]
     float sval = 0.f;
-    float tcol[4][4];
     float V[2][TG][16];
     // (slot_off, style_off: float offsets in smem. The window base is made opaque to the compiler: folded into the 16
     // reads as one big constant each, it cost a vector add per ds_read2 -- from one base the rows are immediates)
@@ -278,28 +279,61 @@ __device__ __forceinline__ void winograd64_body(const ConvArgs& p) {
 #pragma unroll
             for (int y = 0; y < 4; ++y)
 #pragma unroll
-                for (int x = 0; x < 4; ++x) win[tg][y][x] = pc[y * kPW + x];
+                for (int cp = 0; cp < 2; ++cp) win[tg][y][cp] = *reinterpret_cast<const f32x2_lds*>(pc + y * kPW + 2 * cp);
         }
         sval = smem[style_off + kq];
     };
-    // V = B^T (s d) B, B^T = [[1,0,-1,0],[0,1,1,0],[0,-1,1,0],[0,1,0,-1]]; the style scale rides on the window (V is linear in d)
+    // V = B^T (s d) B, B^T = [[1,0,-1,0],[0,1,1,0],[0,-1,1,0],[0,1,0,-1]]; the style scale rides on the window (V is linear in d).
+    // Packed fp32 (v_pk_*_f32, two columns per instruction): the row pass works on column pairs; in the column pass
+    // (V0, V3) of a row is one packed subtraction of its two pairs, (V1, V2) two scalar operations: 24 vector
+    // instructions per window instead of 40 -- beside the fp32 MFMAs of its own wave every one of them costs its issue time.
+    // Only where a wave transforms two windows per k-step: in the <4, 1> geometry the aligned register pairs made hipcc
+    // park ten accumulator tiles in VGPRs and copy them in and out of every loop trip (+13 %); there the scalar form stays.
     auto transform = [&](float (&outs)[TG][16]) {
-#pragma unroll
-        for (int tg = 0; tg < TG; ++tg) {
+        if constexpr (TG == 1) {
+            float tcol[4][4];
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
-                const float e1 = sval * win[tg][1][c], e2 = sval * win[tg][2][c];
-                tcol[0][c] = fmaf(sval, win[tg][0][c], -e2);
+                const float w0 = win[0][0][c >> 1][c & 1], w1 = win[0][1][c >> 1][c & 1], w2 = win[0][2][c >> 1][c & 1], w3 = win[0][3][c >> 1][c & 1];
+                const float e1 = sval * w1, e2 = sval * w2;
+                tcol[0][c] = fmaf(sval, w0, -e2);
                 tcol[1][c] = e1 + e2;
                 tcol[2][c] = e2 - e1;
-                tcol[3][c] = fmaf(-sval, win[tg][3][c], e1);
+                tcol[3][c] = fmaf(-sval, w3, e1);
             }
 #pragma unroll
             for (int y = 0; y < 4; ++y) {
-                outs[tg][y * 4 + 0] = tcol[y][0] - tcol[y][2];
-                outs[tg][y * 4 + 1] = tcol[y][1] + tcol[y][2];
-                outs[tg][y * 4 + 2] = tcol[y][2] - tcol[y][1];
-                outs[tg][y * 4 + 3] = tcol[y][1] - tcol[y][3];
+                outs[0][y * 4 + 0] = tcol[y][0] - tcol[y][2];
+                outs[0][y * 4 + 1] = tcol[y][1] + tcol[y][2];
+                outs[0][y * 4 + 2] = tcol[y][2] - tcol[y][1];
+                outs[0][y * 4 + 3] = tcol[y][1] - tcol[y][3];
+            }
+            return;
+        }
+        const f32x2 s2 = {sval, sval};
+#pragma unroll
+        for (int tg = 0; tg < TG; ++tg) {
+            f32x2 t[4][2];
+#pragma unroll
+            for (int cp = 0; cp < 2; ++cp) {
+                const f32x2 e1 = s2 * win[tg][1][cp], e2 = s2 * win[tg][2][cp];
+                t[0][cp] = __builtin_elementwise_fma(s2, win[tg][0][cp], -e2);
+                t[1][cp] = e1 + e2;
+                t[2][cp] = e2 - e1;
+                t[3][cp] = __builtin_elementwise_fma(-s2, win[tg][3][cp], e1);
+                // (kept opaque: where a packed result is only read by element, hipcc splits the operation again)
+#pragma unroll
+                for (int y = 0; y < 4; ++y) asm("" : "+v"(t[y][cp]));
+            }
+#pragma unroll
+            for (int y = 0; y < 4; ++y) {
+                f32x2 a = t[y][0] - t[y][1];  // (c0 - c2, c1 - c3)
+                asm("" : "+v"(a));
+                const float c1 = t[y][0][1], c2 = t[y][1][0];
+                outs[tg][y * 4 + 0] = a[0];
+                outs[tg][y * 4 + 1] = c1 + c2;
+                outs[tg][y * 4 + 2] = c2 - c1;
+                outs[tg][y * 4 + 3] = a[1];
             }
         }
     };
