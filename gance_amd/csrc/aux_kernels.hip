@@ -340,8 +340,10 @@ __global__ __launch_bounds__(256) void torgb_kernel(const ToRgbArgs p) {
     __shared__ float coef[512 * 3];
     const int tid = threadIdx.x;
     const int b = blockIdx.y;
-    for (int i = tid; i < p.Cin * 3; i += 256)
-        coef[i] = p.s[(size_t)b * p.s_stride + i / 3] * p.w[i];
+    if (p.partial == nullptr) {
+        for (int i = tid; i < p.Cin * 3; i += 256)
+            coef[i] = p.s[(size_t)b * p.s_stride + i / 3] * p.w[i];
+    }
     __syncthreads();
     const int R = p.R;
     const size_t npix = (size_t)R * R;
@@ -356,9 +358,16 @@ __global__ __launch_bounds__(256) void torgb_kernel(const ToRgbArgs p) {
     for (int c = 0; c < 3; ++c)
 #pragma unroll
         for (int k = 0; k < 4; ++k) acc[c][k] = 0.f;
+    if (p.partial != nullptr) {  // the conv kernel's epilogue did the channel sum (kEpilogueFullRgbPart)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float4 v = *reinterpret_cast<const float4*>(p.partial + ((size_t)b * 3 + c) * npix + p4);
+            acc[c][0] = v.x; acc[c][1] = v.y; acc[c][2] = v.z; acc[c][3] = v.w;
+        }
+    }
     const float* xp = p.x + (size_t)b * p.Cin * xplane + (size_t)(oy + 1) * (R + 8) + ox0 + 4;
 #pragma unroll 4
-    for (int ci = 0; ci < p.Cin; ++ci) {
+    for (int ci = 0; ci < (p.partial != nullptr ? 0 : p.Cin); ++ci) {
         const float4 v = *reinterpret_cast<const float4*>(xp + (size_t)ci * xplane);
         const float c0 = coef[ci * 3 + 0], c1 = coef[ci * 3 + 1], c2 = coef[ci * 3 + 2];
         acc[0][0] = fmaf(v.x, c0, acc[0][0]); acc[0][1] = fmaf(v.y, c0, acc[0][1]);
@@ -501,6 +510,7 @@ __global__ __launch_bounds__(256) void torgb_small_kernel(const ToRgbArgs p) {
 
 hipError_t launch_torgb(const ToRgbArgs& args, hipStream_t stream) {
     const size_t npix = (size_t)args.R * args.R;
+    if (args.partial != nullptr && args.R <= 128) return hipErrorInvalidValue;  // (the small kernel has no such mode)
     if (args.R <= 128 && args.Cin % 8 == 0) {
         hipLaunchKernelGGL(torgb_small_kernel, dim3((unsigned)((npix + 31) / 32), args.B), dim3(256), 0,
                            stream, args);

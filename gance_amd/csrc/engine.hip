@@ -208,6 +208,7 @@ struct gance_workspace {
     std::vector<float*> tplanes;  // per up layer: [4 cls][max_units][cout][H+3][W+8] (else nullptr)
     float* slabs = nullptr;       // split-K scratch of the small stride-1 convs (dense)
     float* ybuf[2] = {nullptr, nullptr};
+    float* rgb_coef = nullptr;  // [Bmax][16][64]: A operand of a ToRGB product fused into a Winograd conv epilogue
     uint8_t* u8buf = nullptr;  // staging for the host-buffer entry points
     hipEvent_t last_use = nullptr;
     bool used = false;
@@ -232,6 +233,7 @@ struct gance_workspace {
         hipFree(slabs);
         hipFree(ybuf[0]);
         hipFree(ybuf[1]);
+        hipFree(rgb_coef);
         hipFree(u8buf);
         if (last_use) hipEventDestroy(last_use);
     }
@@ -343,7 +345,10 @@ int run_conv(gance_engine* e, const ConvLayerHost& c, int li, const LayerPlan& p
              long long slab_stride, long long cls_stride, int B, hipStream_t stream,
              const char* name, const FusedRgb* rgb = nullptr, bool winograd = false) {
     gance::ConvArgs a{};
-    if (rgb != nullptr) {
+    if (epilogue == gance::kEpilogueFullRgbPart) {  // (rgb->y: the partial image; the coefficient table is the workspace's)
+        a.rgb_y = rgb->y;
+        a.rgb_coef = e->ws->rgb_coef;
+    } else if (rgb != nullptr) {
         a.rgb_w = rgb->w;
         a.rgb_s = rgb->s;
         a.rgb_bias = rgb->bias;
@@ -396,7 +401,10 @@ int run_conv(gance_engine* e, const ConvLayerHost& c, int li, const LayerPlan& p
     double flops = 2.0 * 9 * (double)c.cin * c.cout * H * W * B;
     const double out_elems = (double)B * c.cout * (c.up ? 4.0 * H * W : (double)H * W) * p.nsplit;
     double bytes = 4.0 * ((double)B * c.cin * H * W + out_elems + 9.0 * c.cin * c.cout);
-    if (rgb != nullptr) {  // no activation leaves the chip: the uint8 image and the half-size skip image instead
+    if (epilogue == gance::kEpilogueFullRgbPart) {  // + the ToRGB product and its fp32 partial image; no activation when out is null
+        flops += 2.0 * 3 * (double)c.cout * H * W * B;
+        bytes = 4.0 * ((double)B * c.cin * H * W + (out != nullptr ? out_elems : 0.0) + 9.0 * c.cin * c.cout + 3.0 * B * H * W);
+    } else if (rgb != nullptr) {  // no activation leaves the chip: the uint8 image and the half-size skip image instead
         flops += 2.0 * 3 * (double)c.cout * H * W * B;
         bytes = 4.0 * ((double)B * c.cin * H * W + 9.0 * c.cin * c.cout + 0.75 * B * H * W) + 3.0 * B * H * W;
     }
@@ -404,6 +412,11 @@ int run_conv(gance_engine* e, const ConvLayerHost& c, int li, const LayerPlan& p
     if (winograd) {
         // layers with >= 64 output channels: the 64-channel kernel (GANCE_TUNE_WINO64=0 keeps the 32-channel one)
         static const bool wino64_enabled = [] { const char* v = std::getenv("GANCE_TUNE_WINO64"); return !(v && std::atoi(v) == 0); }();
+        if (epilogue == gance::kEpilogueFullRgbPart) {
+            a.w = e->pool + e->wino64_w[li];
+            GANCE_HIP_CHECK(gance::launch_winograd64_conv(a, stream));
+            return GANCE_OK;
+        }
         if (wino64_enabled && rgb == nullptr && epilogue == gance::kEpilogueFull && e->wino64_w[li] != SIZE_MAX) {
             a.w = e->pool + e->wino64_w[li];
             GANCE_HIP_CHECK(gance::launch_winograd64_conv(a, stream));
@@ -476,6 +489,7 @@ int synthesize_from_dlat(gance_engine* e, const float* d_dlat, int B, uint8_t* d
         const bool has_noise = e->conv_ns[li] != 0.0f;
         const float* noise = has_noise ? e->pool + e->conv_noise[li] : nullptr;
         const float* bias = e->pool + e->conv_bias[li];
+        bool rgb_part = false;  // this layer's conv launch also did the channel sum of its ToRGB
         if (!c.up) {
             std::snprintf(name, sizeof(name), "conv%d_%dx%d_%d->%d", c.layer_idx, res, res, c.cin,
                           c.cout);
@@ -518,10 +532,28 @@ int synthesize_from_dlat(gance_engine* e, const float* d_dlat, int B, uint8_t* d
                 if (rc) return rc;
                 ycur = 1 - ycur;
             } else if (p.nsplit == 1 || winograd) {
-                if (winograd) std::snprintf(name, sizeof(name), "convW%d_%dx%d_%d->%d", c.layer_idx, res, res, c.cin, c.cout);
-                int rc = run_conv(e, c, li, p, x_in, x_b_stride, res, res, x_out,
+                // Where the 64-channel Winograd kernel holds every channel of a pixel in one block (Cout = 64 at 512^2,
+                // Cout = 32 at 1024^2) its epilogue also does the channel sum of the layer's ToRGB on the matrix pipe; the
+                // ToRGB pass below then only adds bias and skip image (and converts). The LAST layer's activation has no
+                // other reader and is not stored (unless a debug tap wants it). GANCE_TUNE_W64_RGB=0 turns this off.
+                static const bool w64_rgb_enabled = [] { const char* v = std::getenv("GANCE_TUNE_W64_RGB"); return !(v && std::atoi(v) == 0); }();
+                static const bool wino64_on = [] { const char* v = std::getenv("GANCE_TUNE_WINO64"); return !(v && std::atoi(v) == 0); }();
+                rgb_part = winograd && wino64_on && w64_rgb_enabled && e->wino64_w[li] != SIZE_MAX && gance::winograd64_rgb_supported(c.cout);
+                if (winograd) std::snprintf(name, sizeof(name), rgb_part ? "convW%d+rgb_%dx%d_%d->%d" : "convW%d_%dx%d_%d->%d", c.layer_idx, res, res, c.cin, c.cout);
+                int rc;
+                if (rgb_part) {
+                    const int ri = c.res_log2 - 2;
+                    GANCE_HIP_CHECK(gance::launch_winograd64_rgb_coef(e->pool + e->rgb_w[ri], e->ws->styles + e->rgb_s_off[ri], e->ctot, B, c.cout,
+                                                                      e->ws->rgb_coef, stream));
+                    FusedRgb part{nullptr, nullptr, nullptr, nullptr, e->ws->ybuf[have_y ? 1 - ycur : ycur], nullptr};
+                    const bool last_unread = c.res_log2 == e->res_log2 && limit == num_convs && e->debug_stop_after <= 0;
+                    rc = run_conv(e, c, li, p, x_in, x_b_stride, res, res, last_unread ? nullptr : x_out, gance::kEpilogueFullRgbPart,
+                                  res + 8, 1, 4, out_b, out_c, 0, 0, B, stream, name, &part, true);
+                } else {
+                    rc = run_conv(e, c, li, p, x_in, x_b_stride, res, res, x_out,
                                   gance::kEpilogueFull, res + 8, 1, 4, out_b, out_c, 0, 0, B, stream,
                                   name, nullptr, winograd);
+                }
                 if (rc) return rc;
             } else {
                 const long long dense_c = (long long)res * res;
@@ -626,6 +658,7 @@ int synthesize_from_dlat(gance_engine* e, const float* d_dlat, int B, uint8_t* d
             t.y = e->ws->ybuf[have_y ? 1 - ycur : ycur];
             const bool last = (c.res_log2 == e->res_log2);
             t.u8 = last ? d_u8 : nullptr;
+            t.partial = rgb_part ? t.y : nullptr;  // (in place: the conv epilogue left the channel sums there)
             t.B = B;
             t.Cin = r.cin;
             t.R = res;
@@ -696,7 +729,7 @@ int acquire_workspace(gance_engine* e) {
     }
     ok = ok && alloc((void**)&ws->slabs, e->slab_floats * sizeof(float), false) &&
          alloc((void**)&ws->ybuf[0], e->y_floats * sizeof(float), false) && alloc((void**)&ws->ybuf[1], e->y_floats * sizeof(float), false) &&
-         alloc((void**)&ws->u8buf, e->y_floats, false);
+         alloc((void**)&ws->rgb_coef, (size_t)Bmax * 16 * 64 * sizeof(float), false) && alloc((void**)&ws->u8buf, e->y_floats, false);
     if (ok && (hipEventCreateWithFlags(&ws->last_use, hipEventDisableTiming) != hipSuccess ||
                hipStreamCreateWithFlags(&ws->host_stream, hipStreamNonBlocking) != hipSuccess ||
                hipHostMalloc((void**)&ws->pinned_in, (size_t)Bmax * e->num_rows * kDlatent * sizeof(float), hipHostMallocDefault) != hipSuccess ||

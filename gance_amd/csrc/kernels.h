@@ -78,6 +78,10 @@ constexpr int kEpilogueFull = 1;  // out = lrelu(acc * d + noise * strength + bi
 // to 3 channels, + bias + upsampled skip image) and converted to uint8 NHWC: the LAST layer of the
 // network, when one wave holds every output channel of its pixels (Cout = BM = 32: the 1024^2 generator)
 constexpr int kEpilogueRgb = 2;
+// kEpilogueFull, and the layer's ToRGB product (no bias, no skip image) goes to rgb_y as [B][3][OH][OW]: the 64-channel
+// Winograd kernel when one block holds every channel of its pixels (Cout = 64 or 32); out may be nullptr (last layer).
+// launch_torgb(partial = that image) finishes it.
+constexpr int kEpilogueFullRgbPart = 3;
 
 // One launch of the implicit-GEMM modulated convolution (conv_mfma.hip).
 // Activations are zero-bordered: x is [B][Cin][H+2][W+8] with the interior at [y+1][x+4].
@@ -114,6 +118,7 @@ struct ConvArgs {
     const float* rgb_y_prev;
     float* rgb_y;
     unsigned char* rgb_u8;
+    const float* rgb_coef;  // kEpilogueFullRgbPart: [B][Cout / 4][64], launch_winograd64_rgb_coef
     unsigned long long* debug_stamps;  // [blocks][4] s_memrealtime stamps when debug_flags & 16
     int debug_flags;       // timing ablations only (GANCE_DEBUG_CONV): 1 no stores, 2 no DMA after chunk 0, 4 no MFMA
 };
@@ -139,6 +144,8 @@ bool winograd64_supported(int cin, int cout, int H, int W);
 size_t winograd64_weight_floats(int cin, int cout);
 void winograd64_transform_weights(const float* w_in /*[9][cin][cout]*/, int cin, int cout, float* w_out);
 hipError_t launch_winograd64_conv(const ConvArgs& args, hipStream_t stream);
+bool winograd64_rgb_supported(int cout);
+hipError_t launch_winograd64_rgb_coef(const float* rgb_w, const float* rgb_s, int s_stride, int B, int cout, float* coef, hipStream_t stream);
 
 // Conv0_up as ONE kernel (upfir_fused.hip): transposed conv on the matrix cores + [1,3,3,1]^2 FIR + noise +
 // bias + leaky ReLU, for inputs >= 64 wide. Blocks sweep 64-column strips in steps of 8 position rows.
@@ -220,6 +227,7 @@ struct ToRgbArgs {
     const float* y_prev;  // [B][3][R/2][R/2] or nullptr
     float* y;             // [B][3][R][R]
     uint8_t* u8;          // [B][R][R][3] or nullptr
+    const float* partial; // nullptr, or [B][3][R][R]: the channel sum is already there (may be y itself): x, w, s unused
     int B, Cin, R, s_stride;
 };
 hipError_t launch_torgb(const ToRgbArgs& args, hipStream_t stream);

@@ -80,8 +80,11 @@ struct Geo {
     static constexpr int kSlot = kUFloats + kPlPieces * 256;  // 5888 / 5120 floats
     static constexpr int kPiecesPerWave = kUSlots + kPlSlots; // 6 / 5: every wave issues as many, the waits count them
     static_assert((kNBUF - 3) * kPiecesPerWave <= 63, "counted vmcnt");
-    static constexpr int kConstFloats = kConstHead + kTH * kTW;  // 896 / 1152
-    static size_t lds_bytes() { return sizeof(float) * ((size_t)kNBUF * kSlot + 2 * kConstFloats); }
+    static constexpr int kNoiseFloats = kTH * kTW;                      // 256 / 512
+    static constexpr int kRgbSteps = 4 * MT;                            // k-steps of the ToRGB product: 16 / 8
+    // constants of a tile: head | noise | (RGB) the A operand of every ToRGB k-step [step][lane]
+    static constexpr int const_floats(bool rgb) { return kConstHead + kNoiseFloats + (rgb ? kRgbSteps * 64 : 0); }  // 896 (+1024) / 1152 (+512)
+    static size_t lds_bytes(bool rgb) { return sizeof(float) * ((size_t)kNBUF * kSlot + 2 * const_floats(rgb)); }
 };
 
 struct Tile {
@@ -100,11 +103,11 @@ __device__ __forceinline__ int fresh_lane() {
 
 }  // namespace
 
-template <int MT, int TG>
+template <int MT, int TG, bool RGB>
 __device__ __forceinline__ void winograd64_body(const ConvArgs& p) {
     using G = Geo<MT, TG>;
     constexpr int kBM = G::kBM, kTH = G::kTH, kPH = G::kPH, kPlane = G::kPlane, kUFloats = G::kUFloats, kPlF4 = G::kPlF4;
-    constexpr int kConstFloats = G::kConstFloats;
+    constexpr int kConstFloats = G::const_floats(RGB), kRgbOff = kConstHead + G::kNoiseFloats;
     constexpr int kPlPieces = G::kPlPieces, kSlot = G::kSlot, kPiecesPerWave = G::kPiecesPerWave, kUSlots = G::kUSlots, kPlSlots = G::kPlSlots;
     typedef float afrag_t __attribute__((ext_vector_type(MT)));
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -211,6 +214,16 @@ __device__ __forceinline__ void winograd64_body(const ConvArgs& p) {
                         const int row = 2 * (wave * TG + tg);
                         __builtin_amdgcn_raw_ptr_buffer_load_lds(nz_rsrc, (lds_ptr_t)(set + kConstHead + row * kTW), 4, nz_voff,
                                                                  ((t.y0 + row) * p.OW + t.x0) * 4, 0, 0);
+                    }
+                }
+                // ... and (RGB) the A operands of the tile's ToRGB product: [step][lane] for its sample, a row per instruction
+                if constexpr (RGB) {
+                    const __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+                        (void*)(p.rgb_coef + (size_t)b * (G::kRgbSteps * 64)), 0, G::kRgbSteps * 256, 0x00020000);
+#pragma unroll
+                    for (int i = 0; i < G::kRgbSteps / 4; ++i) {
+                        const int step = wave + 4 * i;
+                        __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rsrc, (lds_ptr_t)(set + kRgbOff + step * 64), 4, l4, step * 256, 0, 0);
                     }
                 }
                 st_left = n;
@@ -349,6 +362,23 @@ __device__ __forceinline__ void winograd64_body(const ConvArgs& p) {
         const int c_stride_bytes = (int)p.out_c_stride * 4;
         const __amdgpu_buffer_rsrc_t o_rsrc = __builtin_amdgcn_make_buffer_rsrc(
             (void*)(p.out + (size_t)t.b0 * p.out_b_stride + (size_t)(t.m_tile * kBM) * p.out_c_stride), 0, 0x7fffffff, 0x00020000);
+        // (RGB) The layer's ToRGB product rides on the matrix pipe as well: rgb[colour][pixel] = sum over the block's
+        // channels of coefficient x activation is one more small GEMM, and the activations are already where its B operand
+        // wants them -- v_mfma_f32_16x16x4 takes B[k][n] from lane (n = lane % 16, k = lane / 16), this lane holds channels
+        // 16 mt + 4 kq + r of the pixels in column n16, so k-step (mt, r) of the product reads each lane's OWN channel. The
+        // A operand (colour m = lane % 16 < 3, else 0; channel 16 mt + 4 (lane / 16) + r) comes from the table the tile's
+        // constants brought in. Accumulators in VGPRs (every AGPR holds a conv accumulator), hence the inline assembly.
+        // Lanes 0 .. 15 end up with (R, G, B, 0) of their column in the four result registers.
+        const float* const rgb_lds = const0 + (i & 1) * kConstFloats + kRgbOff;
+        f32x4 rgbacc[TG][2][2];
+        if constexpr (RGB) {
+#pragma unroll
+            for (int tg = 0; tg < TG; ++tg)
+#pragma unroll
+                for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+                    for (int dx = 0; dx < 2; ++dx) rgbacc[tg][dy][dx] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
 #pragma unroll
         for (int tg = 0; tg < TG; ++tg) {
             const int oy = t.y0 + 2 * (wave * TG + tg), ox = t.x0 + 2 * n16;
@@ -396,22 +426,66 @@ __device__ __forceinline__ void winograd64_body(const ConvArgs& p) {
                         y[dy][dx] = v;
                     }
                 }
+                if constexpr (RGB) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float a_r = rgb_lds[(mt * 4 + r) * 64 + le];
+                        // (the four pixels of a k-step back to back: independent accumulators between dependent ones)
+#pragma unroll
+                        for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+                            for (int dx = 0; dx < 2; ++dx)
+                                // (s_nop: an MFMA may not read a register a vector instruction wrote in the cycle before it; hipcc
+                                // places that wait state for the MFMAs it knows, not in front of this one: without it exactly the
+                                // pixel whose activation was computed last came out wrong)
+                                asm volatile("s_nop 1\n\tv_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(rgbacc[tg][dy][dx]) : "v"(a_r), "v"(y[dy][dx][r]));
+                    }
+                }
                 if (GANCE_W64_ABLATE & 1) {
                     asm volatile("" ::"v"(y[0][0]), "v"(y[0][1]), "v"(y[1][0]), "v"(y[1][1]));
                     continue;
                 }
+                // (RGB: the network's last layer has no other reader: out == nullptr, nothing but the image leaves the chip)
+                if (!RGB || p.out != nullptr) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r)
+                    for (int r = 0; r < 4; ++r)
 #pragma unroll
-                    for (int dy = 0; dy < 2; ++dy) {
-                        u32x2 pair;
-                        pair[0] = __float_as_uint(y[dy][0][r]);
-                        pair[1] = __float_as_uint(y[dy][1][r]);
-                        __builtin_amdgcn_raw_buffer_store_b64(pair, o_rsrc, voff0 + dy * p.out_row_stride * 4, (mt * 16 + r) * c_stride_bytes, 0);
-                    }
+                        for (int dy = 0; dy < 2; ++dy) {
+                            u32x2 pair;
+                            pair[0] = __float_as_uint(y[dy][0][r]);
+                            pair[1] = __float_as_uint(y[dy][1][r]);
+                            __builtin_amdgcn_raw_buffer_store_b64(pair, o_rsrc, voff0 + dy * p.out_row_stride * 4, (mt * 16 + r) * c_stride_bytes, 0);
+                        }
+                }
             }
         }
         __builtin_amdgcn_sched_barrier(0);
+        if constexpr (RGB) {
+            // the partial image (no bias, no skip image yet: torgb_kernel finishes it in place): [B][3][OH][OW], the two
+            // pixels of a row as one 8-byte store per colour. The compiler does not know the assembly above is an MFMA:
+            // the wait states between an MFMA and a read of its result are spelled out.
+#pragma unroll
+            for (int tg = 0; tg < TG; ++tg)
+                asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 3" : "+v"(rgbacc[tg][0][0]), "+v"(rgbacc[tg][0][1]), "+v"(rgbacc[tg][1][0]), "+v"(rgbacc[tg][1][1]));
+            const __amdgpu_buffer_rsrc_t y_rsrc =
+                __builtin_amdgcn_make_buffer_rsrc((void*)(p.rgb_y + (size_t)t.b0 * 3 * p.OH * p.OW), 0, 0x7fffffff, 0x00020000);
+            if (kq == 0) {
+#pragma unroll
+                for (int tg = 0; tg < TG; ++tg)
+#pragma unroll
+                    for (int dy = 0; dy < 2; ++dy) {
+                        const int voff = ((t.y0 + 2 * (wave * TG + tg) + dy) * p.OW + t.x0 + 2 * n16) * 4;
+#pragma unroll
+                        for (int k = 0; k < 3; ++k) {
+                            u32x2 pair;
+                            pair[0] = __float_as_uint(rgbacc[tg][dy][0][k]);
+                            pair[1] = __float_as_uint(rgbacc[tg][dy][1][k]);
+                            __builtin_amdgcn_raw_buffer_store_b64(pair, y_rsrc, voff, k * p.OH * p.OW * 4, 0);
+                        }
+                    }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
     };
 
     // ---- prologue of the pipeline: first chunk visible, V of its k-step, its weight fragments ----
@@ -544,17 +618,19 @@ void winograd64_transform_weights(const float* w_in, int cin, int cout, float* w
 // The kernels are plain functions around the templated body: as a kernel TEMPLATE the host pass of hipcc drops the
 // instantiation without a diagnostic (the 16-byte LDS-DMA builtin does not pass the host's feature check) and the
 // library is left with an undefined stub.
-__global__ __launch_bounds__(256, 1) void winograd64_kernel(const ConvArgs p) { winograd64_body<4, 1>(p); }
-__global__ __launch_bounds__(256, 1) void winograd64_c32_kernel(const ConvArgs p) { winograd64_body<2, 2>(p); }
+__global__ __launch_bounds__(256, 1) void winograd64_kernel(const ConvArgs p) { winograd64_body<4, 1, false>(p); }
+__global__ __launch_bounds__(256, 1) void winograd64_c32_kernel(const ConvArgs p) { winograd64_body<2, 2, false>(p); }
+__global__ __launch_bounds__(256, 1) void winograd64_rgb_kernel(const ConvArgs p) { winograd64_body<4, 1, true>(p); }
+__global__ __launch_bounds__(256, 1) void winograd64_c32_rgb_kernel(const ConvArgs p) { winograd64_body<2, 2, true>(p); }
 
-template <int MT, int TG>
+template <int MT, int TG, bool RGB>
 static hipError_t launch_variant(void (*kernel)(const ConvArgs), const ConvArgs& args, hipStream_t stream) {
     using G = Geo<MT, TG>;
     static PerDeviceInt resident;  // per device: the dynamic-LDS opt-in and the launch size = one block per CU, a multiple of 8 (XCDs)
     int resident_blocks = 0;
     hipError_t e = resident.get(
         [&](int device, int* value) {
-            hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::lds_bytes());
+            hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::lds_bytes(RGB));
             if (err != hipSuccess) return err;
             int cus = 0;
             if ((err = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device)) != hipSuccess) return err;
@@ -572,13 +648,40 @@ static hipError_t launch_variant(void (*kernel)(const ConvArgs), const ConvArgs&
     a.total_chunks = a.Cin / kKC;
     a.total_tiles = a.m_tiles * a.tiles_x * a.tiles_y * a.B;
     const int blocks = std::min(a.total_tiles, resident_blocks);
-    hipLaunchKernelGGL(kernel, dim3(blocks), dim3(256), G::lds_bytes(), stream, a);
+    hipLaunchKernelGGL(kernel, dim3(blocks), dim3(256), G::lds_bytes(RGB), stream, a);
+    return hipGetLastError();
+}
+
+bool winograd64_rgb_supported(int cout) { return cout == 64 || cout == 32; }  // one block holds every channel of its pixels
+
+// rgb_coef[b][step = 4 mt + r][lane] = style[b][ch] * w[ch][lane % 16] for lane % 16 < 3, else 0, ch = 16 mt + 4 (lane / 16) + r:
+// the A operand of the fused ToRGB product, lane by lane (see the epilogue)
+__global__ void winograd64_rgb_coef_kernel(const float* __restrict__ w, const float* __restrict__ s, int s_stride, int steps,
+                                           float* __restrict__ out) {
+    const int b = blockIdx.x;
+    for (int i = threadIdx.x; i < steps * 64; i += blockDim.x) {
+        const int lane = i & 63, step = i >> 6;
+        const int ch = 16 * (step >> 2) + 4 * (lane >> 4) + (step & 3), colour = lane & 15;
+        out[(size_t)b * steps * 64 + i] = colour < 3 ? s[(size_t)b * s_stride + ch] * w[ch * 3 + colour] : 0.f;
+    }
+}
+
+hipError_t launch_winograd64_rgb_coef(const float* rgb_w, const float* rgb_s, int s_stride, int B, int cout, float* coef, hipStream_t stream) {
+    if (!winograd64_rgb_supported(cout)) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(winograd64_rgb_coef_kernel, dim3(B), dim3(256), 0, stream, rgb_w, rgb_s, s_stride, cout / 4, coef);
     return hipGetLastError();
 }
 
 hipError_t launch_winograd64_conv(const ConvArgs& args, hipStream_t stream) {
-    if (args.epilogue != kEpilogueFull) return hipErrorInvalidValue;
-    return args.Cout % 64 == 0 ? launch_variant<4, 1>(winograd64_kernel, args, stream) : launch_variant<2, 2>(winograd64_c32_kernel, args, stream);
+    if (args.epilogue == kEpilogueFullRgbPart) {
+        // every channel of a pixel in one block; the partial image and the coefficient table are the caller's
+        if (!winograd64_rgb_supported(args.Cout) || args.rgb_coef == nullptr || args.rgb_y == nullptr) return hipErrorInvalidValue;
+        return args.Cout == 64 ? launch_variant<4, 1, true>(winograd64_rgb_kernel, args, stream)
+                               : launch_variant<2, 2, true>(winograd64_c32_rgb_kernel, args, stream);
+    }
+    if (args.epilogue != kEpilogueFull || args.out == nullptr) return hipErrorInvalidValue;
+    return args.Cout % 64 == 0 ? launch_variant<4, 1, false>(winograd64_kernel, args, stream)
+                               : launch_variant<2, 2, false>(winograd64_c32_kernel, args, stream);
 }
 
 }  // namespace gance
