@@ -21,6 +21,7 @@ Prints ONE JSON line on rank 0 (contract in the task statement) with two extra o
 
 import argparse
 import json
+import re
 import os
 import sys
 import time
@@ -53,10 +54,28 @@ def usable_cores() -> int:
     return max(1, cores)
 
 
-def measured_traffic(kernel_name: str, resolution: int, batch: int):
+def kernel_of_step(step_name: str) -> str:
+    """The HIP kernel behind a conv launch of the engine's step table (names: engine.hip)."""
+    if step_name.startswith("convTF"):
+        return "upfir_fused_kernel"
+    if step_name.startswith("convW"):
+        narrow = step_name.endswith("->32")
+        if "+rgb" in step_name:
+            return "winograd64_c32_rgb_kernel" if narrow else "winograd64_rgb_kernel"
+        return "winograd64_c32_kernel" if narrow else "winograd64_kernel"
+    return "modconv_mfma_kernel"
+
+
+def executed_fraction(step_name: str) -> float:
+    """Matrix-core flops a launch EXECUTES per algorithmic (direct-form) flop: Winograd F(2x2,3x3) does 16 of 36."""
+    return 4.0 / 9.0 if step_name.startswith("convW") else 1.0
+
+
+def measured_traffic(step_name: str, resolution: int, batch: int):
     """
     HBM bytes per launch of the dominant kernel from the committed PMC pass (rocprofv3 cannot run
-    inside this process): profiles/traffic_latest.json, only if it was taken on this workload.
+    inside this process): profiles/traffic_latest.json, only if it was taken on this workload and
+    holds this launch (the two largest launches trade places from run to run: both are recorded).
     """
     path = REPO_ROOT / "profiles" / "traffic_latest.json"
     try:
@@ -66,7 +85,10 @@ def measured_traffic(kernel_name: str, resolution: int, batch: int):
     workload = record.get("workload", {})
     if workload.get("resolution") != resolution or workload.get("frames_per_step_per_gpu") != batch:
         return None
-    return record.get("hbm_bytes_per_launch")
+    for prefix, entry in record.get("launches", {}).items():
+        if step_name.startswith(prefix):
+            return entry.get("hbm_bytes_per_launch")
+    return None
 
 
 def cpu_baseline(resolution: int, variables, budget_seconds: float = 15.0) -> dict:
@@ -115,9 +137,8 @@ def blend_measurement(resolution: int, batch: int, num_networks: int, output_sid
         hip_lib.Engine(sg2_spec.make_random_variables(resolution, seed=seed), resolution, max_batch=batch, device=device.index, profile=True)
         for seed in range(num_networks)
     ]
-    last_conv = "conv%d+torgb_%dx%d_" % (2 * int(np.log2(resolution)) - 4, resolution, resolution)
-    for engine in engines:
-        engine.set_profiling(False)
+    # the network's last conv launch, whatever form the engine runs it in (names: engine.hip)
+    last_conv_pattern = re.compile(r"^conv[A-Z]*%d[+_].*_%dx%d_" % (2 * int(np.log2(resolution)) - 4, resolution, resolution))
     audio, latents = synthetic.benchmark_blend_inputs(num_frames)
     frames = torch.empty((batch, resolution, resolution, 3), dtype=torch.uint8, device=device)
     stream = torch.cuda.current_stream(device)
@@ -151,7 +172,8 @@ def blend_measurement(resolution: int, batch: int, num_networks: int, output_sid
         blend.blend.close()
         return t1 - t0, t2 - t1
 
-    run_once()  # warm-up (LDS attribute setup, allocator)
+    run_once()  # warm-up (LDS attribute setup, allocator), every launch bracketed: it names the last conv launch
+    last_conv = next((s.name for s in engines[0].steps() if last_conv_pattern.match(s.name)), "conv")
     for engine in engines:
         engine.set_profiling(True, only_step=last_conv)
     audio_s, synth_s = run_once()
@@ -168,11 +190,11 @@ def blend_measurement(resolution: int, batch: int, num_networks: int, output_sid
         "dtype": "f64 (audio) / f32 (synthesis)", "data": "synthetic",
         "roofline": {
             "bound": "mfma",
-            "kernel": "modconv_mfma_kernel (%s)" % (timed[0].name if timed else last_conv),
+            "kernel": "%s (%s)" % (kernel_of_step(last_conv), last_conv),
             "launches_averaged": len(timed),
-            "achieved": round(timed[0].flops / (sum(s.ms for s in timed) / len(timed) * 1e-3) / 1e12, 3) if timed else None,
+            "achieved": round(executed_fraction(last_conv) * timed[0].flops / (sum(s.ms for s in timed) / len(timed) * 1e-3) / 1e12, 3) if timed else None,
             "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(timed[0].flops / (sum(s.ms for s in timed) / len(timed) * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4) if timed else None,
+            "frac": round(executed_fraction(last_conv) * timed[0].flops / (sum(s.ms for s in timed) / len(timed) * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4) if timed else None,
             "audio_stage": {
                 "bound": "hbm (launch-latency in practice: six kernels over < 60 MB)", "algorithmic_bytes": audio_bytes,
                 "achieved": round(audio_bytes / audio_s / 1e9, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -375,23 +397,31 @@ def main() -> int:
             },
             "roofline": {
                 "bound": "mfma",
-                "kernel": "modconv_mfma_kernel (%s)" % dominant.name,
+                "kernel": "%s (%s)" % (kernel_of_step(dominant.name), dominant.name),
                 "launches_averaged": len(timed),
-                "achieved": round(dominant.flops / (dominant.ms * 1e-3) / 1e12, 3),
+                # what the matrix cores execute per second: for a Winograd launch 4/9 of the direct-form figure beside it
+                "achieved": round(executed_fraction(dominant.name) * dominant.flops / (dominant.ms * 1e-3) / 1e12, 3),
                 "peak": FP32_MFMA_PEAK_TFLOPS,
                 "unit": "TFLOP/s",
-                "frac": round(dominant.flops / (dominant.ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4),
+                "frac": round(executed_fraction(dominant.name) * dominant.flops / (dominant.ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4),
+                "algorithmic_direct_form": round(dominant.flops / (dominant.ms * 1e-3) / 1e12, 3),
                 "traffic": measured_traffic(dominant.name, resolution, batch),
                 "traffic_note": "HBM bytes per launch from profiles/traffic_latest.json (2*FETCH_SIZE + WRITE_SIZE, separate --pmc passes); algorithmic bytes per launch = %d" % int(dominant.bytes),
                 "all_conv_launches": {
-                    "achieved": round(conv_flops / (conv_ms * 1e-3) / 1e12, 3),
-                    "frac": round(conv_flops / (conv_ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4),
+                    # executed matrix-core flops of all conv launches over their summed durations (Winograd launches
+                    # count 4/9 of their direct-form flops: that is what runs)
+                    "achieved": round(executed_flops / (conv_ms * 1e-3) / 1e12, 3),
+                    "frac": round(executed_flops / (conv_ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4),
+                    "algorithmic_direct_form": round(conv_flops / (conv_ms * 1e-3) / 1e12, 3),
                     "share_of_step_time": round(conv_ms / total_ms, 4),
                     "winograd_launches": winograd_launches,
-                    "executed_mfma_tflops": round(executed_flops / (conv_ms * 1e-3) / 1e12, 3),
-                    "note": "achieved / frac count direct-form (algorithmic) flops; %d of the %d conv launches run in Winograd F(2x2,3x3) form and execute 4/9 of theirs" % (winograd_launches, len(conv_steps)),
+                    "note": "%d of the %d conv launches run in Winograd F(2x2,3x3) form and execute 4/9 of their direct-form flops; "
+                    "algorithmic_direct_form prices every launch as a direct convolution and may exceed the peak" % (winograd_launches, len(conv_steps)),
                 },
-                "whole_path_frac": round(
+                # the whole step (mapping, styles, ToRGB, uint8 included) against the matrix peak: executed flops of a
+                # step over its wall time; and the same in direct-form flops, the work a direct implementation would do
+                "whole_path_frac": round(executed_flops / (elapsed / args.steps) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4),
+                "whole_path_direct_form_frac": round(
                     (fps / world_size) * ALGORITHMIC_GFLOP_PER_FRAME_1024 * (resolution / 1024) ** 2 / 1e3 / FP32_MFMA_PEAK_TFLOPS, 4
                 ),
             },

@@ -413,10 +413,12 @@ __global__ __launch_bounds__(256) void torgb_kernel(const ToRgbArgs p) {
             }
         }
     }
+    if (!p.skip_y_store) {
 #pragma unroll
-    for (int c = 0; c < 3; ++c)
-        *reinterpret_cast<float4*>(p.y + ((size_t)b * 3 + c) * npix + p4) =
-            make_float4(acc[c][0], acc[c][1], acc[c][2], acc[c][3]);
+        for (int c = 0; c < 3; ++c)
+            *reinterpret_cast<float4*>(p.y + ((size_t)b * 3 + c) * npix + p4) =
+                make_float4(acc[c][0], acc[c][1], acc[c][2], acc[c][3]);
+    }
 
     if (p.u8 != nullptr) {
         uint8_t q[12];

@@ -659,13 +659,17 @@ int synthesize_from_dlat(gance_engine* e, const float* d_dlat, int B, uint8_t* d
             const bool last = (c.res_log2 == e->res_log2);
             t.u8 = last ? d_u8 : nullptr;
             t.partial = rgb_part ? t.y : nullptr;  // (in place: the conv epilogue left the channel sums there)
+            t.skip_y_store = last && res > 128 && d_u8 != nullptr && d_f32 == nullptr && !e->keep_skip_image && limit == num_convs;
             t.B = B;
             t.Cin = r.cin;
             t.R = res;
             t.s_stride = e->ctot;
             std::snprintf(name, sizeof(name), "torgb_%dx%d", res, res);
-            StepScope scope(e, stream, name, 2.0 * 3 * (double)r.cin * res * res * B,
-                            4.0 * (double)B * res * res * (r.cin + 3 + 0.75) + 3.0 * B * res * res);
+            // (after a conv launch that did the channel sum: partial image in, bias and skip image added, image and/or bytes out)
+            const double px = (double)B * res * res;
+            StepScope scope(e, stream, name, rgb_part ? 0.0 : 2.0 * 3 * (double)r.cin * px,
+                            rgb_part ? px * (12.0 + 3.0 + (t.skip_y_store ? 0.0 : 12.0) + (t.u8 != nullptr ? 3.0 : 0.0))
+                                     : 4.0 * px * (r.cin + 3 + 0.75) + 3.0 * px);
             GANCE_HIP_CHECK(gance::launch_torgb(t, stream));
             if (have_y) ycur = 1 - ycur;
             have_y = true;

@@ -228,6 +228,7 @@ struct ToRgbArgs {
     float* y;             // [B][3][R][R]
     uint8_t* u8;          // [B][R][R][3] or nullptr
     const float* partial; // nullptr, or [B][3][R][R]: the channel sum is already there (may be y itself): x, w, s unused
+    bool skip_y_store;    // the last layer when nobody reads the fp32 image: only u8 leaves (torgb_kernel only)
     int B, Cin, R, s_stride;
 };
 hipError_t launch_torgb(const ToRgbArgs& args, hipStream_t stream);
