@@ -1,28 +1,30 @@
-// Winograd F(2x2, 3x3) form of the modulated 3x3 stride-1 convolution for layers with >= 64 output channels:
-// the same arithmetic as winograd_conv.hip (`modulated_conv2d_layer` -> tf.nn.conv2d), with the
-// input transform amortised over 64 output channels instead of 32.
+// Winograd F(2x2, 3x3) form of the modulated 3x3 stride-1 convolution on v_mfma_f32_16x16x4_f32: the same arithmetic as
+// winograd_conv.hip (`modulated_conv2d_layer` -> tf.nn.conv2d), every Conv1 layer from 32^2 to 1024^2.
 //
 // Why a second kernel. In winograd_conv.hip a wave transforms a 4x4 input window per (tile, channel) -- 40 vector
 // instructions -- and feeds the 16 results to 16 MFMAs (one 32x32x2 tile of 32 output channels per Winograd
 // position): 2.5 vector instructions per MFMA, and on gfx950 the fp32 MFMA does not hide vector work of its own
 // wave, so that kernel executes at 0.58 of the matrix peak. Here the MFMA is v_mfma_f32_16x16x4_f32
-// (16 channels x 16 tiles x 4 input channels, 32 cycles) and a wave holds FOUR channel tiles per position:
+// (16 channels x 16 tiles x 4 input channels, 32 cycles) and a wave holds FOUR accumulator tiles per position:
 // 16 positions x 4 x 4 registers = 256 accumulators, the same register budget, but a transformed window now feeds
-// 64 MFMAs (2048 matrix-pipe cycles) instead of 16 (1024): half the vector work per matrix cycle. The four weight
-// fragments of a position come out of LDS in ONE ds_read_b128 (the weight image is laid out [pos][ci][m % 16][m / 16]).
+// 64 MFMAs (2048 matrix-pipe cycles) instead of 16 (1024). The weight fragments of a position come out of LDS in ONE
+// read (the weight image is laid out [pos][ci][m % 16][m / 16]).
 //
-// Block = 4 waves = 64 output channels x (8 x 32) pixels = 4 x 16 Winograd tiles; wave w owns tile row w, lane
-// (n = lane % 16, kq = lane / 16) transforms the window of tile n for input channel 4 ks + kq of k-step ks.
-// K chunk = 4 input channels = ONE k-step: transformed weights [16][4][16][4] (16 KB) + haloed patch [4][10][40]
-// (6.4 KB) per ring slot, SIX slots. Blocks are persistent over ONE continuous stream of chunks (tiles back to back).
-// The window loads and the transform of k-step q+1 run under the MFMAs of k-step q, so at the top of every k-step the
-// wave waits for chunk q+1 -- issued FOUR k-steps earlier, counted vmcnt: the three younger chunks stay in flight --
-// the block synchronises (chunk q-1 is then dead) and the six LDS-DMA pieces a wave contributes to chunk q+5 are woven
-// between the MFMAs. (A first version with 8-channel chunks in a three-slot ring issued a chunk's last pieces right
-// before the wait that needed them and ran at 0.59 of the matrix peak -- DMA latency, not vector work, was the limit.)
-// The epilogue (output transform A^T M A, demodulation, noise, bias, leaky ReLU,
-// 8-byte stores: 128 contiguous bytes per 16 lanes) runs between tiles while the pipeline registers already hold
-// the next tile's first k-step.
+// Geometries (template <MT channel tiles, TG tile rows per wave>): <4, 1> = 64 output channels x (8 x 32) pixels per
+// block; <2, 2> = 32 channels x (16 x 32) pixels (the 32-channel layer at 1024^2). Block = 4 waves; wave w owns tile
+// row(s) w TG .. of the block's 16 tile columns, lane (n = lane % 16, kq = lane / 16) transforms the window of tile n for
+// input channel 4 ks + kq of k-step ks.
+// K chunk = 4 input channels = ONE k-step: transformed weights + haloed patch per ring slot, SIX slots. Blocks are
+// persistent over ONE continuous stream of chunks (tiles back to back). The window loads and the transform of k-step
+// q+1 run under the MFMAs of k-step q. In front of every EVEN k-step q the wave waits for chunks q+1 and q+2 -- issued
+// four and three k-steps earlier, counted vmcnt: the two younger chunks stay in flight -- and the block synchronises;
+// the DMA pieces a wave contributes to chunks q+5 / q+6 are woven between the MFMAs of the pair. (A first version with
+// 8-channel chunks in a three-slot ring issued a chunk's last pieces right before the wait that needed them and ran at
+// 0.59 of the matrix peak -- DMA latency, not vector work, was the limit.)
+// The epilogue (output transform A^T M A, demodulation, noise, bias, leaky ReLU, 8-byte stores: 128 contiguous bytes
+// per 16 lanes; RGB variants: the layer's ToRGB channel sum as 64 more MFMAs) runs between tiles while the pipeline
+// registers already hold the next tile's first k-step. Nothing in the tile loop may spill: a scratch reload is a
+// vector-memory load and the wait behind it drains the ring (see fresh_lane / lane_offsets).
 
 #include <hip/hip_runtime.h>
 
