@@ -241,15 +241,21 @@ __global__ __launch_bounds__(256, 1) void upfir_fused_kernel(const UpFirArgs p) 
 #pragma unroll
     for (int jj = 0; jj < 4; ++jj)
         boff[jj] = lh * kPlane + (2 * wave + (jj >> 1) + 1) * kPW + 32 * (jj & 1) + l31 + 4;
+    // halo tile = 32 channels x 16 slots on v_mfma_f32_16x16x4_f32 (two channel halves, FOUR input channels per
+    // MFMA): lane (slot = lane % 16, q4 = lane / 16) supplies input channel 4 j + q4 of the pair of channel pairs j
     const int hslot = l31 & 15;
-    const int boffh = lh * kPlane + ((hslot & 7) + 1) * kPW + ((hslot >> 3) ? 64 : -1) + 4;
+    const int q4 = 2 * lh + (l31 >> 4);
+    const int aoffh = q4 * kBM + hslot;  // + (t * kKC + 4 j) * kBM + 16 half
+    const int boffh = q4 * kPlane + ((hslot & 7) + 1) * kPW + ((hslot >> 3) ? 64 : -1) + 4;  // + 4 j * kPlane + shift
 
     // ---- epilogue roles ----
     // dump: lane writes T[cl = rr + 4 lh][trow = 2 ry + py][sc = 2 cx + px + 1] of pass g = r >> 2, rr = r & 3
     const int dump_base = (4 * lh) * (kStageRows * kTW) + (4 * wave) * kTW + 2 * l31 + 1;
     const int hpy = wave >> 1, hpx = wave & 1;  // the halo tile's class held by this wave
-    const bool halo_writes = l31 < 16 && ((hslot >> 3) == 1 || hpx == 1);
-    const int dump_halo = (4 * lh) * (kStageRows * kTW) + (2 * (hslot & 7) + hpy) * kTW + ((hslot >> 3) ? 129 + hpx : 0);
+    // (halo tile: result register rr of half h = channel 16 h + 4 q4 + rr: pass g takes half g / 2 from the lanes with
+    // q4 / 2 == g % 2, i.e. lh == g % 2, as channel 4 (q4 % 2) + rr of the pass)
+    const bool halo_writes = (hslot >> 3) == 1 || hpx == 1;
+    const int dump_halo = (4 * (l31 >> 4)) * (kStageRows * kTW) + (2 * (hslot & 7) + hpy) * kTW + ((hslot >> 3) ? 129 + hpx : 0);
     // filter: thread = (channel c of the pass, column group cg): output columns 2 X0 + 4 cg .. + 3
     const int fc = 2 * wave + lh;
     const int cg = l31;
@@ -269,10 +275,9 @@ __global__ __launch_bounds__(256, 1) void upfir_fused_kernel(const UpFirArgs p) 
         constexpr bool kFlush = decltype(flush_tag)::value;
         const int y0 = y_begin + kTH * si;
         f32x16 acc[4][4];
-        f32x16 acch;
+        f32x4 acch[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            acch[r] = 0.f;
 #pragma unroll
             for (int c = 0; c < 4; ++c)
 #pragma unroll
@@ -311,7 +316,7 @@ __global__ __launch_bounds__(256, 1) void upfir_fused_kernel(const UpFirArgs p) 
                 // fragment of the next tap and, at the last tap of a kk, the 20 patch fragments of the next kk are read from
                 // LDS before the current tap's MFMAs are issued; the style scale is read once per kk.
                 float bfrag[2][4][4];
-                float bhalo[2][4];
+                float bhalo[4];  // the halo tile's B operands of a pair of channel pairs, times the style scale
                 float anext;
                 float snext;
                 auto load_b = [&](int kk) {
@@ -319,9 +324,10 @@ __global__ __launch_bounds__(256, 1) void upfir_fused_kernel(const UpFirArgs p) 
                     for (int sh = 0; sh < 4; ++sh) {
 #pragma unroll
                         for (int jj = 0; jj < 4; ++jj) bfrag[kk & 1][sh][jj] = Pl[boff[jj] + 2 * kk * kPlane + shift_off(sh)];
-                        bhalo[kk & 1][sh] = Pl[boffh + 2 * kk * kPlane + shift_off(sh)];
                     }
                 };
+                const float* const Wh = cur_buf + aoffh;
+                const float* const sph = s_lds + k * kKC + q4;
                 anext = Wl[0];
                 snext = sp[0];
                 load_b(0);
@@ -329,6 +335,12 @@ __global__ __launch_bounds__(256, 1) void upfir_fused_kernel(const UpFirArgs p) 
 #pragma unroll
                 for (int kk = 0; kk < kKC / 2; ++kk) {
                     const float sv = snext;
+                    if ((kk & 1) == 0) {
+                        // the halo operands of channels 4 j .. 4 j + 3 (j = kk / 2), used after the main MFMAs of kk + 1
+                        const float sh4 = sph[2 * kk];
+#pragma unroll
+                        for (int sh = 0; sh < 4; ++sh) bhalo[sh] = Pl[boffh + 2 * kk * kPlane + shift_off(sh)] * sh4;
+                    }
 #pragma unroll
                     for (int grp = 0; grp < 4; ++grp) {
                         float a[4];
@@ -355,14 +367,23 @@ __global__ __launch_bounds__(256, 1) void upfir_fused_kernel(const UpFirArgs p) 
                                 __builtin_amdgcn_sched_barrier(0);
                             }
                         }
-                        // the 17th accumulator tile: hipcc pins builtin MFMA accumulators to the 256 AGPRs, which the 16
-                        // main tiles fill, so this one is issued in the VGPR form by hand
-                        if (wave == grp) {
+                        // The halo tile (one class per wave): hipcc pins builtin MFMA accumulators to the 256 AGPRs, which the
+                        // 16 main tiles fill, so it is issued in the VGPR form by hand -- as 16x16x4 MFMAs, once per PAIR of
+                        // channel pairs: 16 slots is all the tile needs, and a tap costs 2 x 32 matrix cycles per four input
+                        // channels instead of 2 x 64 (the wave with the four-tap class was 10 % behind its siblings).
+                        if ((kk & 1) == 1 && wave == grp) {
+                            float ah[4][2];
 #pragma unroll
                             for (int i = 0; i < kGroupTaps[grp]; ++i)
-                                asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0"
-                                             : "+v"(acch)
-                                             : "v"(a[i]), "v"(bhalo[kk & 1][tap_shift(kGroupFirst[grp] + i)]));
+#pragma unroll
+                                for (int h = 0; h < 2; ++h) ah[i][h] = Wh[((kGroupFirst[grp] + i) * kKC + 2 * (kk - 1)) * kBM + 16 * h];
+#pragma unroll
+                            for (int i = 0; i < kGroupTaps[grp]; ++i)
+#pragma unroll
+                                for (int h = 0; h < 2; ++h)
+                                    asm volatile("s_nop 1\n\tv_mfma_f32_16x16x4_f32 %0, %1, %2, %0"
+                                                 : "+v"(acch[h])
+                                                 : "v"(ah[i][h]), "v"(bhalo[tap_shift(kGroupFirst[grp] + i)]));
                         }
                         __builtin_amdgcn_sched_barrier(0);
                     }
@@ -386,9 +407,13 @@ __global__ __launch_bounds__(256, 1) void upfir_fused_kernel(const UpFirArgs p) 
                                 acc[tap_cls(t)][jj] = __builtin_amdgcn_mfma_f32_32x32x2f32(
                                     a, Pl[boff[jj] + 2 * kk * kPlane + shift_off(tap_shift(t))], acc[tap_cls(t)][jj], 0, 0, 0);
                         }
-                        if (wave == tap_cls(t)) {
-                            const float bh = Pl[boffh + 2 * kk * kPlane + shift_off(tap_shift(t))];
-                            asm volatile("s_nop 4\n\tv_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+v"(acch) : "v"(a), "v"(bh));
+                        if ((kk & 1) == 1 && wave == tap_cls(t)) {  // the halo tile, four input channels at a time
+                            const float bh = Pl[boffh + 2 * (kk - 1) * kPlane + shift_off(tap_shift(t))] * s_lds[k * kKC + 2 * (kk - 1) + q4];
+#pragma unroll
+                            for (int h = 0; h < 2; ++h) {
+                                const float ah = cur_buf[aoffh + (t * kKC + 2 * (kk - 1)) * kBM + 16 * h];
+                                asm volatile("s_nop 4\n\tv_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(acch[h]) : "v"(ah), "v"(bh));
+                            }
                         }
                     }
                 }
@@ -431,9 +456,9 @@ __global__ __launch_bounds__(256, 1) void upfir_fused_kernel(const UpFirArgs p) 
                     for (int rr = 0; rr < 4; ++rr)
                         stage[dump_base + rr * (kStageRows * kTW) + (2 * (jj >> 1) + (c >> 1)) * kTW + 64 * (jj & 1) + (c & 1)] =
                             acc[c][jj][4 * g + rr];
-            if (halo_writes) {
+            if (halo_writes && lh == (g & 1)) {
 #pragma unroll
-                for (int rr = 0; rr < 4; ++rr) stage[dump_halo + rr * (kStageRows * kTW)] = acch[4 * g + rr];
+                for (int rr = 0; rr < 4; ++rr) stage[dump_halo + rr * (kStageRows * kTW)] = acch[g >> 1][rr];
             }
             lds_barrier();
 
