@@ -13,13 +13,14 @@
 // around an output tile. A block therefore SWEEPS a column strip of 64 positions top to bottom in steps
 // of 8 position rows:
 //   * horizontally the two halo position columns (x' = X0-1: odd column parity only; x' = X0+64) are
-//     recomputed: 16 positions packed into one extra 32-slot MFMA tile whose four classes are split over
-//     the four waves (a wave issues 36 + {4,2,2,1} MFMAs per pair of input channels instead of 36);
+//     recomputed: 16 positions = one extra tile of 16 slots whose four classes are split over the four
+//     waves, on v_mfma_f32_16x16x4_f32 (two channel halves, four input channels per MFMA: {4,2,2,1} x 2
+//     MFMAs of 32 cycles per two pairs of input channels beside the 72 of 64 cycles on the main tiles);
 //   * vertically nothing is recomputed: the last three T rows of a step stay in LDS (32 channels x 3 rows
 //     x 131 columns = 50 KB) and are the top of the next step's FIR window.
-// One block = 32 output channels x (8 x 64 + 16) positions x 4 classes = 272 accumulator registers per
+// One block = 32 output channels x (8 x 64 + 16) positions x 4 classes = 256 + 8 accumulator registers per
 // lane: one wave per SIMD, one block per CU, like the Winograd kernel. A step = K loop (LDS-DMA ring of
-// two slots, chunks of 4 input channels: weight image [9][4][32] + haloed patch [4][9][72]), then the
+// two slots, chunks of 8 input channels: weight image [9][8][32] + haloed patch [8][9][72]), then the
 // epilogue in four passes of 8 channels: accumulators -> LDS T window [8][16][132], barrier, every
 // thread filters a 16-row x 4-column output strip of one channel (two aligned ds_read_b128 per T row,
 // horizontal taps carry demod * sqrt 2, vertical taps, + noise + bias, leaky ReLU) and stores float4s.
