@@ -392,23 +392,29 @@ __global__ __launch_bounds__(256) void torgb_kernel(const ToRgbArgs p) {
         const int yb = ya + 1;
         const float wya = (oy & 1) ? 0.75f : 0.25f;
         const float wyb = 1.0f - wya;
+        // the thread's four pixels ox0 .. ox0 + 3 (ox0 a multiple of 4) read source columns X0 - 1 .. X0 + 2, X0 = ox0 / 2:
+        // pixel 0: (.25, .75) of columns (X0-1, X0); 1: (.75, .25) of (X0, X0+1); 2: (.25, .75) of (X0, X0+1);
+        // 3: (.75, .25) of (X0+1, X0+2) -- four loads per row and colour instead of eight
+        const int X0 = ox0 >> 1;
+        const bool ra = ya >= 0, rb = yb < Rh;  // (ya < Rh and yb >= 0 always)
+        const bool c0 = X0 >= 1, c3 = X0 + 2 < Rh;
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
             const float* yp = p.y_prev + ((size_t)b * 3 + c) * Rh * Rh;
+            float ta[4], tb[4];  // source rows ya, yb, columns X0 - 1 .. X0 + 2 (zero outside the image)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const bool cok = j == 0 ? c0 : (j == 3 ? c3 : true);
+                ta[j] = (ra && cok) ? yp[(size_t)ya * Rh + X0 - 1 + j] : 0.f;
+                tb[j] = (rb && cok) ? yp[(size_t)yb * Rh + X0 - 1 + j] : 0.f;
+            }
+            // (the same order of operations as one pixel at a time: along the row first, then the two rows)
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                const int ox = ox0 + k;
-                const int X = ox >> 1;
-                const int xa = (ox & 1) ? X : X - 1;
-                const int xb = xa + 1;
-                const float wxa = (ox & 1) ? 0.75f : 0.25f;
-                const float wxb = 1.0f - wxa;
-                auto at = [&](int yy, int xx) -> float {
-                    return (yy >= 0 && yy < Rh && xx >= 0 && xx < Rh) ? yp[(size_t)yy * Rh + xx]
-                                                                      : 0.f;
-                };
-                const float top = wxa * at(ya, xa) + wxb * at(ya, xb);
-                const float bot = wxa * at(yb, xa) + wxb * at(yb, xb);
+                const int j = (k + 1) >> 1;  // first source column of pixel k: 0, 1, 1, 2
+                const float wxa = (k & 1) ? 0.75f : 0.25f, wxb = 1.0f - wxa;
+                const float top = wxa * ta[j] + wxb * ta[j + 1];
+                const float bot = wxa * tb[j] + wxb * tb[j + 1];
                 acc[c][k] += wya * top + wyb * bot;
             }
         }
