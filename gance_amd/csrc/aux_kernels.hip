@@ -361,8 +361,10 @@ __global__ __launch_bounds__(256) void torgb_kernel(const ToRgbArgs p) {
     if (p.partial != nullptr) {  // the conv kernel's epilogue did the channel sum (kEpilogueFullRgbPart)
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-            const float4 v = *reinterpret_cast<const float4*>(p.partial + ((size_t)b * 3 + c) * npix + p4);
-            acc[c][0] = v.x; acc[c][1] = v.y; acc[c][2] = v.z; acc[c][3] = v.w;
+            for (int m = 0; m < p.partials; ++m) {  // (fixed order: reproducible)
+                const float4 v = *reinterpret_cast<const float4*>(p.partial + (((size_t)m * p.B + b) * 3 + c) * npix + p4);
+                acc[c][0] += v.x; acc[c][1] += v.y; acc[c][2] += v.z; acc[c][3] += v.w;
+            }
         }
     }
     const float* xp = p.x + (size_t)b * p.Cin * xplane + (size_t)(oy + 1) * (R + 8) + ox0 + 4;
@@ -518,8 +520,8 @@ __global__ __launch_bounds__(256) void torgb_small_kernel(const ToRgbArgs p) {
 
 hipError_t launch_torgb(const ToRgbArgs& args, hipStream_t stream) {
     const size_t npix = (size_t)args.R * args.R;
-    if (args.partial != nullptr && args.R <= 128) return hipErrorInvalidValue;  // (the small kernel has no such mode)
-    if (args.R <= 128 && args.Cin % 8 == 0) {
+    if (args.partial != nullptr && (args.partials < 1 || args.R % 4 != 0)) return hipErrorInvalidValue;
+    if (args.partial == nullptr && args.R <= 128 && args.Cin % 8 == 0) {  // (the finishing pass has no channel loop to split)
         hipLaunchKernelGGL(torgb_small_kernel, dim3((unsigned)((npix + 31) / 32), args.B), dim3(256), 0,
                            stream, args);
         return hipGetLastError();

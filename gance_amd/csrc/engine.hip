@@ -208,7 +208,8 @@ struct gance_workspace {
     std::vector<float*> tplanes;  // per up layer: [4 cls][max_units][cout][H+3][W+8] (else nullptr)
     float* slabs = nullptr;       // split-K scratch of the small stride-1 convs (dense)
     float* ybuf[2] = {nullptr, nullptr};
-    float* rgb_coef = nullptr;  // [Bmax][16][64]: A operand of a ToRGB product fused into a Winograd conv epilogue
+    float* rgb_coef = nullptr;  // [Bmax][8 m tiles][16][64]: A operands of a ToRGB product fused into a Winograd conv epilogue
+    float* rgb_part = nullptr;  // [m tiles][Bmax][3][R][R]: its partial images where a pixel's channels span several blocks
     uint8_t* u8buf = nullptr;  // staging for the host-buffer entry points
     hipEvent_t last_use = nullptr;
     bool used = false;
@@ -234,6 +235,7 @@ struct gance_workspace {
         hipFree(ybuf[0]);
         hipFree(ybuf[1]);
         hipFree(rgb_coef);
+        hipFree(rgb_part);
         hipFree(u8buf);
         if (last_use) hipEventDestroy(last_use);
     }
@@ -275,7 +277,7 @@ struct gance_engine {
     // captured launch sequences of the host-buffer entry points, by (batch, entry kind, psi bits, float image wanted)
     std::map<std::tuple<int, int, unsigned, int>, GraphEntry> graphs;
     std::vector<int> t_units;     // max_units of each up layer's parity planes
-    size_t slab_floats = 0, y_floats = 0;
+    size_t slab_floats = 0, y_floats = 0, rgb_part_floats = 0;
 
     // profiling / debug
     std::vector<StepRecord> steps;
@@ -490,6 +492,7 @@ int synthesize_from_dlat(gance_engine* e, const float* d_dlat, int B, uint8_t* d
         const float* noise = has_noise ? e->pool + e->conv_noise[li] : nullptr;
         const float* bias = e->pool + e->conv_bias[li];
         bool rgb_part = false;  // this layer's conv launch also did the channel sum of its ToRGB
+        int rgb_partials = 1;   // ... in this many partial images (one per channel tile of a pixel)
         if (!c.up) {
             std::snprintf(name, sizeof(name), "conv%d_%dx%d_%d->%d", c.layer_idx, res, res, c.cin,
                           c.cout);
@@ -545,7 +548,9 @@ int synthesize_from_dlat(gance_engine* e, const float* d_dlat, int B, uint8_t* d
                     const int ri = c.res_log2 - 2;
                     GANCE_HIP_CHECK(gance::launch_winograd64_rgb_coef(e->pool + e->rgb_w[ri], e->ws->styles + e->rgb_s_off[ri], e->ctot, B, c.cout,
                                                                       e->ws->rgb_coef, stream));
-                    FusedRgb part{nullptr, nullptr, nullptr, nullptr, e->ws->ybuf[have_y ? 1 - ycur : ycur], nullptr};
+                    // (one partial image: straight into the skip buffer ToRGB finishes in place; several: the workspace's)
+                    rgb_partials = gance::winograd64_rgb_partials(c.cout);
+                    FusedRgb part{nullptr, nullptr, nullptr, nullptr, rgb_partials == 1 ? e->ws->ybuf[have_y ? 1 - ycur : ycur] : e->ws->rgb_part, nullptr};
                     const bool last_unread = c.res_log2 == e->res_log2 && limit == num_convs && e->debug_stop_after <= 0;
                     rc = run_conv(e, c, li, p, x_in, x_b_stride, res, res, last_unread ? nullptr : x_out, gance::kEpilogueFullRgbPart,
                                   res + 8, 1, 4, out_b, out_c, 0, 0, B, stream, name, &part, true);
@@ -658,7 +663,8 @@ int synthesize_from_dlat(gance_engine* e, const float* d_dlat, int B, uint8_t* d
             t.y = e->ws->ybuf[have_y ? 1 - ycur : ycur];
             const bool last = (c.res_log2 == e->res_log2);
             t.u8 = last ? d_u8 : nullptr;
-            t.partial = rgb_part ? t.y : nullptr;  // (in place: the conv epilogue left the channel sums there)
+            t.partial = rgb_part ? (rgb_partials == 1 ? t.y : e->ws->rgb_part) : nullptr;  // (one piece: in place)
+            t.partials = rgb_partials;
             t.skip_y_store = last && res > 128 && d_u8 != nullptr && d_f32 == nullptr && !e->keep_skip_image && limit == num_convs;
             t.B = B;
             t.Cin = r.cin;
@@ -668,7 +674,7 @@ int synthesize_from_dlat(gance_engine* e, const float* d_dlat, int B, uint8_t* d
             // (after a conv launch that did the channel sum: partial image in, bias and skip image added, image and/or bytes out)
             const double px = (double)B * res * res;
             StepScope scope(e, stream, name, rgb_part ? 0.0 : 2.0 * 3 * (double)r.cin * px,
-                            rgb_part ? px * (12.0 + 3.0 + (t.skip_y_store ? 0.0 : 12.0) + (t.u8 != nullptr ? 3.0 : 0.0))
+                            rgb_part ? px * (12.0 * rgb_partials + 3.0 + (t.skip_y_store ? 0.0 : 12.0) + (t.u8 != nullptr ? 3.0 : 0.0))
                                      : 4.0 * px * (r.cin + 3 + 0.75) + 3.0 * px);
             GANCE_HIP_CHECK(gance::launch_torgb(t, stream));
             if (have_y) ycur = 1 - ycur;
@@ -733,7 +739,8 @@ int acquire_workspace(gance_engine* e) {
     }
     ok = ok && alloc((void**)&ws->slabs, e->slab_floats * sizeof(float), false) &&
          alloc((void**)&ws->ybuf[0], e->y_floats * sizeof(float), false) && alloc((void**)&ws->ybuf[1], e->y_floats * sizeof(float), false) &&
-         alloc((void**)&ws->rgb_coef, (size_t)Bmax * 16 * 64 * sizeof(float), false) && alloc((void**)&ws->u8buf, e->y_floats, false);
+         alloc((void**)&ws->rgb_coef, (size_t)Bmax * 8 * 16 * 64 * sizeof(float), false) &&
+         alloc((void**)&ws->rgb_part, std::max<size_t>(1, e->rgb_part_floats) * sizeof(float), false) && alloc((void**)&ws->u8buf, e->y_floats, false);
     if (ok && (hipEventCreateWithFlags(&ws->last_use, hipEventDisableTiming) != hipSuccess ||
                hipStreamCreateWithFlags(&ws->host_stream, hipStreamNonBlocking) != hipSuccess ||
                hipHostMalloc((void**)&ws->pinned_in, (size_t)Bmax * e->num_rows * kDlatent * sizeof(float), hipHostMallocDefault) != hipSuccess ||
@@ -999,6 +1006,12 @@ int gance_engine_create(const gance_engine_config* config, const float* host_wei
     }
     e->slab_floats = slab_max;
     e->y_floats = (size_t)3 * config->resolution * config->resolution * Bmax;
+    // partial ToRGB images of the Winograd conv launches whose pixels span several channel tiles: [Cout / 64][Bmax][3][R][R]
+    for (int i = 0; i < nconv; ++i) {
+        const ConvLayerHost& c = e->convs[i];
+        if (!c.up && c.cout > 64 && gance::winograd64_rgb_supported(c.cout))
+            e->rgb_part_floats = std::max(e->rgb_part_floats, (size_t)gance::winograd64_rgb_partials(c.cout) * Bmax * 3 << (2 * c.res_log2));
+    }
 
 #define GANCE_CREATE_CHECK(expr)                                                            \
     do {                                                                                    \

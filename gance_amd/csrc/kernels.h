@@ -118,7 +118,7 @@ struct ConvArgs {
     const float* rgb_y_prev;
     float* rgb_y;
     unsigned char* rgb_u8;
-    const float* rgb_coef;  // kEpilogueFullRgbPart: [B][Cout / 4][64], launch_winograd64_rgb_coef
+    const float* rgb_coef;  // kEpilogueFullRgbPart: [B][Cout / 4][64], launch_winograd64_rgb_coef; rgb_y: [Cout / 64 or 1][B][3][OH][OW]
     unsigned long long* debug_stamps;  // [blocks][4] s_memrealtime stamps when debug_flags & 16
     int debug_flags;       // timing ablations only (GANCE_DEBUG_CONV): 1 no stores, 2 no DMA after chunk 0, 4 no MFMA
 };
@@ -145,6 +145,7 @@ size_t winograd64_weight_floats(int cin, int cout);
 void winograd64_transform_weights(const float* w_in /*[9][cin][cout]*/, int cin, int cout, float* w_out);
 hipError_t launch_winograd64_conv(const ConvArgs& args, hipStream_t stream);
 bool winograd64_rgb_supported(int cout);
+int winograd64_rgb_partials(int cout);  // partial images the launch writes: [partials][B][3][OH][OW]
 hipError_t launch_winograd64_rgb_coef(const float* rgb_w, const float* rgb_s, int s_stride, int B, int cout, float* coef, hipStream_t stream);
 
 // Conv0_up as ONE kernel (upfir_fused.hip): transposed conv on the matrix cores + [1,3,3,1]^2 FIR + noise +
@@ -227,7 +228,9 @@ struct ToRgbArgs {
     const float* y_prev;  // [B][3][R/2][R/2] or nullptr
     float* y;             // [B][3][R][R]
     uint8_t* u8;          // [B][R][R][3] or nullptr
-    const float* partial; // nullptr, or [B][3][R][R]: the channel sum is already there (may be y itself): x, w, s unused
+    const float* partial; // nullptr, or [partials][B][3][R][R]: the channel sum is already there, in `partials` pieces added
+                          // in order (one piece: may be y itself): x, w, s unused
+    int partials;
     bool skip_y_store;    // the last layer when nobody reads the fp32 image: only u8 leaves (torgb_kernel only)
     int B, Cin, R, s_stride;
 };

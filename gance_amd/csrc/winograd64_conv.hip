@@ -221,7 +221,7 @@ __device__ __forceinline__ void winograd64_body(const ConvArgs& p) {
                 // ... and (RGB) the A operands of the tile's ToRGB product: [step][lane] for its sample, a row per instruction
                 if constexpr (RGB) {
                     const __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-                        (void*)(p.rgb_coef + (size_t)b * (G::kRgbSteps * 64)), 0, G::kRgbSteps * 256, 0x00020000);
+                        (void*)(p.rgb_coef + ((size_t)b * p.m_tiles + t.m_tile) * (G::kRgbSteps * 64)), 0, G::kRgbSteps * 256, 0x00020000);
 #pragma unroll
                     for (int i = 0; i < G::kRgbSteps / 4; ++i) {
                         const int step = wave + 4 * i;
@@ -470,7 +470,7 @@ __device__ __forceinline__ void winograd64_body(const ConvArgs& p) {
             for (int tg = 0; tg < TG; ++tg)
                 asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 3" : "+v"(rgbacc[tg][0][0]), "+v"(rgbacc[tg][0][1]), "+v"(rgbacc[tg][1][0]), "+v"(rgbacc[tg][1][1]));
             const __amdgpu_buffer_rsrc_t y_rsrc =
-                __builtin_amdgcn_make_buffer_rsrc((void*)(p.rgb_y + (size_t)t.b0 * 3 * p.OH * p.OW), 0, 0x7fffffff, 0x00020000);
+                __builtin_amdgcn_make_buffer_rsrc((void*)(p.rgb_y + ((size_t)t.m_tile * p.B + t.b0) * 3 * p.OH * p.OW), 0, 0x7fffffff, 0x00020000);
             if (kq == 0) {
 #pragma unroll
                 for (int tg = 0; tg < TG; ++tg)
@@ -654,32 +654,37 @@ static hipError_t launch_variant(void (*kernel)(const ConvArgs), const ConvArgs&
     return hipGetLastError();
 }
 
-bool winograd64_rgb_supported(int cout) { return cout == 64 || cout == 32; }  // one block holds every channel of its pixels
+// A block's channels are its whole share of the ToRGB product: with several channel tiles per pixel (Cout > 64) every
+// tile's block writes its OWN partial image and torgb_kernel adds them in a fixed order (no atomics: results stay
+// reproducible bit for bit).
+bool winograd64_rgb_supported(int cout) { return cout == 32 || (cout % 64 == 0 && cout <= 512); }
+int winograd64_rgb_partials(int cout) { return cout == 32 ? 1 : cout / 64; }
 
-// rgb_coef[b][step = 4 mt + r][lane] = style[b][ch] * w[ch][lane % 16] for lane % 16 < 3, else 0, ch = 16 mt + 4 (lane / 16) + r:
-// the A operand of the fused ToRGB product, lane by lane (see the epilogue)
-__global__ void winograd64_rgb_coef_kernel(const float* __restrict__ w, const float* __restrict__ s, int s_stride, int steps,
+// rgb_coef[b][m tile][step = 4 mt + r][lane] = style[b][ch] * w[ch][lane % 16] for lane % 16 < 3, else 0,
+// ch = BM m_tile + 16 mt + 4 (lane / 16) + r: the A operand of the fused ToRGB product, lane by lane (see the epilogue)
+__global__ void winograd64_rgb_coef_kernel(const float* __restrict__ w, const float* __restrict__ s, int s_stride, int steps, int m_tiles,
                                            float* __restrict__ out) {
     const int b = blockIdx.x;
-    for (int i = threadIdx.x; i < steps * 64; i += blockDim.x) {
-        const int lane = i & 63, step = i >> 6;
-        const int ch = 16 * (step >> 2) + 4 * (lane >> 4) + (step & 3), colour = lane & 15;
-        out[(size_t)b * steps * 64 + i] = colour < 3 ? s[(size_t)b * s_stride + ch] * w[ch * 3 + colour] : 0.f;
+    for (int i = threadIdx.x; i < m_tiles * steps * 64; i += blockDim.x) {
+        const int lane = i & 63, step = (i >> 6) % steps, m_tile = i / (64 * steps);
+        const int ch = 4 * steps * m_tile + 16 * (step >> 2) + 4 * (lane >> 4) + (step & 3), colour = lane & 15;
+        out[(size_t)b * m_tiles * steps * 64 + i] = colour < 3 ? s[(size_t)b * s_stride + ch] * w[ch * 3 + colour] : 0.f;
     }
 }
 
 hipError_t launch_winograd64_rgb_coef(const float* rgb_w, const float* rgb_s, int s_stride, int B, int cout, float* coef, hipStream_t stream) {
     if (!winograd64_rgb_supported(cout)) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(winograd64_rgb_coef_kernel, dim3(B), dim3(256), 0, stream, rgb_w, rgb_s, s_stride, cout / 4, coef);
+    const int m_tiles = winograd64_rgb_partials(cout);
+    hipLaunchKernelGGL(winograd64_rgb_coef_kernel, dim3(B), dim3(256), 0, stream, rgb_w, rgb_s, s_stride, cout / m_tiles / 4, m_tiles, coef);
     return hipGetLastError();
 }
 
 hipError_t launch_winograd64_conv(const ConvArgs& args, hipStream_t stream) {
     if (args.epilogue == kEpilogueFullRgbPart) {
-        // every channel of a pixel in one block; the partial image and the coefficient table are the caller's
+        // the partial image(s) [Cout / 64][B][3][OH][OW] and the coefficient table are the caller's
         if (!winograd64_rgb_supported(args.Cout) || args.rgb_coef == nullptr || args.rgb_y == nullptr) return hipErrorInvalidValue;
-        return args.Cout == 64 ? launch_variant<4, 1, true>(winograd64_rgb_kernel, args, stream)
-                               : launch_variant<2, 2, true>(winograd64_c32_rgb_kernel, args, stream);
+        return args.Cout % 64 == 0 ? launch_variant<4, 1, true>(winograd64_rgb_kernel, args, stream)
+                                   : launch_variant<2, 2, true>(winograd64_c32_rgb_kernel, args, stream);
     }
     if (args.epilogue != kEpilogueFull || args.out == nullptr) return hipErrorInvalidValue;
     return args.Cout % 64 == 0 ? launch_variant<4, 1, false>(winograd64_kernel, args, stream)
