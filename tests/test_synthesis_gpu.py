@@ -284,3 +284,42 @@ def test_calls_are_validated(library) -> None:
         engine.close()
     with pytest.raises(ValueError):
         engine.synthesize_z(np.zeros((1, 512), dtype=np.float32))  # closed
+
+
+_FORM_SCRIPT = """
+import sys
+import numpy as np
+from gance_amd import hip_lib
+from gance_amd.stylegan2 import spec as sg2_spec
+res = int(sys.argv[1])
+spec = sg2_spec.make_spec(res)
+variables = sg2_spec.make_random_variables(res, seed=3, perturb=True)
+dlatents = np.random.RandomState(5).randn(2, spec.num_layers, 512).astype(np.float32)
+engine = hip_lib.Engine(variables, res, max_batch=2, conv_form="winograd")
+frames, image = engine.synthesize_w(dlatents, want_float=True)
+np.savez(sys.argv[2], frames=frames, image=image)
+"""
+
+
+@pytest.mark.parametrize("variable,off_value", [("GANCE_TUNE_W64_RGB", "0"), ("GANCE_TUNE_WINO64", "0")])
+def test_winograd_kernel_fallback_forms_agree_with_the_default(library, tmp_path, variable: str, off_value: str) -> None:
+    """
+    The tuning switches read once per process select kernels the default path no longer runs (the
+    Winograd kernel without the ToRGB product in its epilogue; the round-1 32-channel Winograd kernel):
+    each in its own process, same network and latents, against the default form.
+    """
+    import os
+    import subprocess
+    import sys
+    from pathlib import Path
+
+    repo_root = Path(__file__).resolve().parent.parent
+    outputs = {}
+    for label, env_extra in (("default", {}), ("switched", {variable: off_value})):
+        path = tmp_path / f"{label}.npz"
+        env = dict(os.environ, PYTHONPATH=str(repo_root), **env_extra)
+        subprocess.run([sys.executable, "-c", _FORM_SCRIPT, "256", str(path)], check=True, env=env, cwd=repo_root, timeout=300)
+        outputs[label] = np.load(path)
+    scale = float(np.abs(outputs["default"]["image"]).max())
+    assert float(np.abs(outputs["switched"]["image"] - outputs["default"]["image"]).max()) < 5e-5 * max(1.0, scale)
+    _assert_same_frames(outputs["switched"]["frames"], outputs["default"]["frames"])
