@@ -262,6 +262,7 @@ __global__ __launch_bounds__(256) void fir_epilogue_kernel(const FirArgs p) {
     const int OW = 2 * p.W;
     const int OWp = OW + 8;  // zero-bordered activation [B][C][2H+2][2W+8], interior at [y+1][x+4]
     const float bs = p.bias[c];
+    const float sn = p.s_next != nullptr ? p.s_next[(size_t)b * p.s_next_stride + c] : 1.0f;  // the next layer's style
     float* op = p.out + (bc * (size_t)(2 * p.H + 2) + (2 * Y + 1)) * OWp + 2 * X + 4;
 #pragma unroll
     for (int k = 0; k < 2 * RQ; ++k) {  // output row 2Y + k uses T rows hrow[k .. k+3]
@@ -275,7 +276,7 @@ __global__ __launch_bounds__(256) void fir_epilogue_kernel(const FirArgs p) {
             for (int i = 0; i < 8; ++i) r[i] += nz[i] * p.noise_strength;
         }
 #pragma unroll
-        for (int i = 0; i < 8; ++i) r[i] = lrelu_gain(r[i] + bs);
+        for (int i = 0; i < 8; ++i) r[i] = lrelu_gain(r[i] + bs) * sn;
         *reinterpret_cast<float4*>(op + (size_t)k * OWp) = make_float4(r[0], r[1], r[2], r[3]);
         *reinterpret_cast<float4*>(op + (size_t)k * OWp + 4) = make_float4(r[4], r[5], r[6], r[7]);
     }

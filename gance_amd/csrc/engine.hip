@@ -345,7 +345,7 @@ int run_conv(gance_engine* e, const ConvLayerHost& c, int li, const LayerPlan& p
              long long x_b_stride, int H, int W, float* out, int epilogue, int out_row_stride,
              int out_y_off, int out_x_off, long long out_b_stride, long long out_c_stride,
              long long slab_stride, long long cls_stride, int B, hipStream_t stream,
-             const char* name, const FusedRgb* rgb = nullptr, bool winograd = false) {
+             const char* name, const FusedRgb* rgb = nullptr, bool winograd = false, bool wino64 = false) {
     gance::ConvArgs a{};
     if (epilogue == gance::kEpilogueFullRgbPart) {  // (rgb->y: the partial image; the coefficient table is the workspace's)
         a.rgb_y = rgb->y;
@@ -412,14 +412,9 @@ int run_conv(gance_engine* e, const ConvLayerHost& c, int li, const LayerPlan& p
     }
     StepScope scope(e, stream, name, flops, bytes);
     if (winograd) {
-        // layers with >= 64 output channels: the 64-channel kernel (GANCE_TUNE_WINO64=0 keeps the 32-channel one)
-        static const bool wino64_enabled = [] { const char* v = std::getenv("GANCE_TUNE_WINO64"); return !(v && std::atoi(v) == 0); }();
-        if (epilogue == gance::kEpilogueFullRgbPart) {
-            a.w = e->pool + e->wino64_w[li];
-            GANCE_HIP_CHECK(gance::launch_winograd64_conv(a, stream));
-            return GANCE_OK;
-        }
-        if (wino64_enabled && rgb == nullptr && epilogue == gance::kEpilogueFull && e->wino64_w[li] != SIZE_MAX) {
+        // the kernel on 16x16x4 MFMAs (in its 32-channel geometry the input arrives multiplied by this layer's style: the
+        // caller arranged that with the producing layer), else the round-1 32-channel kernel
+        if (wino64) {
             a.w = e->pool + e->wino64_w[li];
             GANCE_HIP_CHECK(gance::launch_winograd64_conv(a, stream));
             return GANCE_OK;
@@ -480,6 +475,49 @@ int synthesize_from_dlat(gance_engine* e, const float* d_dlat, int B, uint8_t* d
     const float* x_in = e->pool + e->const_off;  // zero-bordered [512][6][12], shared by the batch
     long long x_b_stride = 0;
 
+    // Which form conv layer idx (a stride-1 conv) runs in for this batch. Decided in one place because the layer BEFORE
+    // a conv on the 16x16x4 Winograd kernel has to know: that kernel takes its input multiplied by its own style.
+    struct ConvForm {
+        bool fused_rgb, winograd, winograd_last, wino64;
+    };
+    auto conv_form_of = [&](int idx, bool have_y_then) -> ConvForm {
+        const ConvLayerHost& c = e->convs[idx];
+        const int res = 1 << c.res_log2;
+        const LayerPlan p = plan_layer(c, B);
+        ConvForm form{};
+        // the network's last conv absorbs its ToRGB when one block holds all channels of a pixel
+        // (BM = Cout = 32, i.e. the 1024^2 generator): neither its activation nor the fp32 image is
+        // written, only the uint8 frame (GANCE_TUNE_FUSE_RGB=0 turns this off)
+        static const bool fuse_enabled = [] { const char* v = std::getenv("GANCE_TUNE_FUSE_RGB"); return !(v && std::atoi(v) == 0); }();
+        const auto& tile = gance::kConvTiles[p.tile_id];
+        form.fused_rgb = fuse_enabled && c.res_log2 == e->res_log2 && limit == num_convs && p.nsplit == 1 &&
+                         p.m_tiles == 1 && tile.TB == 1 && tile.BM == 32 && have_y_then;
+        // ... unless the layer runs in Winograd form on the 16x16x4 kernel's 32-channel geometry with the ToRGB product
+        // in its epilogue (GANCE_TUNE_LAST_WINO64 = 0 / 1; measured: see DESIGN.md §3)
+        static const int last_wino64 = [] { const char* v = std::getenv("GANCE_TUNE_LAST_WINO64"); return v ? std::atoi(v) : 1; }();
+        const long long last_tiles = (long long)(res / 16) * (res / 32) * B;
+        if (form.fused_rgb && last_wino64 != 0 && c.cout == 32 && e->wino64_w[idx] != SIZE_MAX && !(e->cfg.flags & GANCE_FLAG_DIRECT_CONV) &&
+            !(e->cfg.flags & GANCE_FLAG_FORCE_WINOGRAD) && last_tiles >= e->num_cus)
+            form.fused_rgb = false;
+        // Winograd F(2x2,3x3) form where the layer supports it and the launch fills the chip
+        // (one block per CU). Engine flags choose: DIRECT_CONV = never, FORCE_WINOGRAD = whatever
+        // the block count; GANCE_TUNE_WINOGRAD = 0 / 1 / 2 overrides them for tuning.
+        static const int env_mode = [] { const char* v = std::getenv("GANCE_TUNE_WINOGRAD"); return v ? std::atoi(v) : -1; }();
+        const int wino_mode = env_mode >= 0 ? env_mode
+                                            : ((e->cfg.flags & GANCE_FLAG_DIRECT_CONV) ? 0 : ((e->cfg.flags & GANCE_FLAG_FORCE_WINOGRAD) ? 2 : 1));
+        // (tiles of 8 x 64 pixels, or 16 x 32 on the 32-pixel-wide layer; the kernel has no split-K)
+        const long long wino_tiles = (long long)(c.cout / 32) * (res % 64 == 0 ? (res / 8) * (res / 64) : (res / 16) * (res / 32)) * B;
+        form.winograd = !c.up && wino_mode != 0 && e->wino_w[idx] != SIZE_MAX && (wino_mode == 2 || (p.nsplit == 1 && wino_tiles >= 256));
+        // the direct-form fused last layer stays unless Winograd is forced: the 32-channel Winograd kernel's own fused variant
+        // (built, parity-green) is register-starved in its epilogue and measured no faster; GANCE_TUNE_WINOGRAD_RGB=1 selects it
+        static const bool wino_rgb = [] { const char* v = std::getenv("GANCE_TUNE_WINOGRAD_RGB"); return v && std::atoi(v) != 0; }();
+        form.winograd_last = form.winograd && (wino_mode == 2 || wino_rgb);
+        // the kernel on 16x16x4 MFMAs (GANCE_TUNE_WINO64=0 keeps the round-1 32-channel kernel): every stride-1 conv it
+        // supports that follows an up layer (all of them do: Conv1 follows Conv0_up)
+        static const bool wino64_on = [] { const char* v = std::getenv("GANCE_TUNE_WINO64"); return !(v && std::atoi(v) == 0); }();
+        form.wino64 = !form.fused_rgb && form.winograd && wino64_on && e->wino64_w[idx] != SIZE_MAX && idx > 0 && e->convs[idx - 1].up;
+        return form;
+    };
     bool fused_rgb = false;
     for (int li = 0; li < limit; ++li) {
         const ConvLayerHost& c = e->convs[li];
@@ -496,35 +534,9 @@ int synthesize_from_dlat(gance_engine* e, const float* d_dlat, int B, uint8_t* d
         if (!c.up) {
             std::snprintf(name, sizeof(name), "conv%d_%dx%d_%d->%d", c.layer_idx, res, res, c.cin,
                           c.cout);
-            // the network's last conv absorbs its ToRGB when one block holds all channels of a pixel
-            // (BM = Cout = 32, i.e. the 1024^2 generator): neither its activation nor the fp32 image is
-            // written, only the uint8 frame (GANCE_TUNE_FUSE_RGB=0 turns this off)
-            static const bool fuse_enabled = [] { const char* v = std::getenv("GANCE_TUNE_FUSE_RGB"); return !(v && std::atoi(v) == 0); }();
-            const auto& tile = gance::kConvTiles[p.tile_id];
-            fused_rgb = fuse_enabled && c.res_log2 == e->res_log2 && limit == num_convs && p.nsplit == 1 &&
-                        p.m_tiles == 1 && tile.TB == 1 && tile.BM == 32 && have_y;
-            // ... unless the layer runs in Winograd form on the 64-channel kernel's 32-channel geometry followed by the
-            // separate ToRGB pass (GANCE_TUNE_LAST_WINO64 = 0 / 1; measured: see DESIGN.md §3)
-            static const int last_wino64 = [] { const char* v = std::getenv("GANCE_TUNE_LAST_WINO64"); return v ? std::atoi(v) : 1; }();
-            const long long last_tiles = (long long)(res / 16) * (res / 32) * B;
-            if (fused_rgb && last_wino64 != 0 && c.cout == 32 && e->wino64_w[li] != SIZE_MAX && !(e->cfg.flags & GANCE_FLAG_DIRECT_CONV) &&
-                !(e->cfg.flags & GANCE_FLAG_FORCE_WINOGRAD) && last_tiles >= e->num_cus)
-                fused_rgb = false;
-            // Winograd F(2x2,3x3) form where the layer supports it and the launch fills the chip
-            // (one block per CU). Engine flags choose: DIRECT_CONV = never, FORCE_WINOGRAD = whatever
-            // the block count; GANCE_TUNE_WINOGRAD = 0 / 1 / 2 overrides them for tuning.
-            static const int env_mode = [] { const char* v = std::getenv("GANCE_TUNE_WINOGRAD"); return v ? std::atoi(v) : -1; }();
-            const int wino_mode = env_mode >= 0 ? env_mode
-                                                : ((e->cfg.flags & GANCE_FLAG_DIRECT_CONV) ? 0 : ((e->cfg.flags & GANCE_FLAG_FORCE_WINOGRAD) ? 2 : 1));
-            // (tiles of 8 x 64 pixels, or 16 x 32 on the 32-pixel-wide layer; the kernel has no split-K)
-            const long long wino_tiles = (long long)(c.cout / 32) * (res % 64 == 0 ? (res / 8) * (res / 64) : (res / 16) * (res / 32)) * B;
-            const bool winograd = wino_mode != 0 && e->wino_w[li] != SIZE_MAX &&
-                                  (wino_mode == 2 || (p.nsplit == 1 && wino_tiles >= 256));
-            // the fused last layer stays in direct form unless Winograd is forced: its Winograd variant
-            // (built, parity-green) is register-starved in the fused epilogue and measured no faster
-            // (4.83 ms against 5.01 ms direct, 3.94 + 0.93 ms unfused); GANCE_TUNE_WINOGRAD_RGB=1 selects it
-            static const bool wino_rgb = [] { const char* v = std::getenv("GANCE_TUNE_WINOGRAD_RGB"); return v && std::atoi(v) != 0; }();
-            const bool winograd_last = winograd && (wino_mode == 2 || wino_rgb);
+            const ConvForm form = conv_form_of(li, have_y);
+            fused_rgb = form.fused_rgb;
+            const bool winograd = form.winograd, winograd_last = form.winograd_last;
             if (fused_rgb) {
                 const int ri = c.res_log2 - 2;
                 FusedRgb rgb{e->pool + e->rgb_w[ri], e->ws->styles + e->rgb_s_off[ri], e->pool + e->rgb_bias[ri],
@@ -540,8 +552,7 @@ int synthesize_from_dlat(gance_engine* e, const float* d_dlat, int B, uint8_t* d
                 // ToRGB pass below then only adds bias and skip image (and converts). The LAST layer's activation has no
                 // other reader and is not stored (unless a debug tap wants it). GANCE_TUNE_W64_RGB=0 turns this off.
                 static const bool w64_rgb_enabled = [] { const char* v = std::getenv("GANCE_TUNE_W64_RGB"); return !(v && std::atoi(v) == 0); }();
-                static const bool wino64_on = [] { const char* v = std::getenv("GANCE_TUNE_WINO64"); return !(v && std::atoi(v) == 0); }();
-                rgb_part = winograd && wino64_on && w64_rgb_enabled && e->wino64_w[li] != SIZE_MAX && gance::winograd64_rgb_supported(c.cout);
+                rgb_part = form.wino64 && w64_rgb_enabled && gance::winograd64_rgb_supported(c.cout);
                 if (winograd) std::snprintf(name, sizeof(name), rgb_part ? "convW%d+rgb_%dx%d_%d->%d" : "convW%d_%dx%d_%d->%d", c.layer_idx, res, res, c.cin, c.cout);
                 int rc;
                 if (rgb_part) {
@@ -553,11 +564,11 @@ int synthesize_from_dlat(gance_engine* e, const float* d_dlat, int B, uint8_t* d
                     FusedRgb part{nullptr, nullptr, nullptr, nullptr, rgb_partials == 1 ? e->ws->ybuf[have_y ? 1 - ycur : ycur] : e->ws->rgb_part, nullptr};
                     const bool last_unread = c.res_log2 == e->res_log2 && limit == num_convs && e->debug_stop_after <= 0;
                     rc = run_conv(e, c, li, p, x_in, x_b_stride, res, res, last_unread ? nullptr : x_out, gance::kEpilogueFullRgbPart,
-                                  res + 8, 1, 4, out_b, out_c, 0, 0, B, stream, name, &part, true);
+                                  res + 8, 1, 4, out_b, out_c, 0, 0, B, stream, name, &part, true, true);
                 } else {
                     rc = run_conv(e, c, li, p, x_in, x_b_stride, res, res, x_out,
                                   gance::kEpilogueFull, res + 8, 1, 4, out_b, out_c, 0, 0, B, stream,
-                                  name, nullptr, winograd);
+                                  name, nullptr, winograd, form.wino64);
                 }
                 if (rc) return rc;
             } else {
@@ -575,6 +586,11 @@ int synthesize_from_dlat(gance_engine* e, const float* d_dlat, int B, uint8_t* d
             }
         } else {
             const int H = res / 2, W = res / 2;
+            // the next layer's style rides on this layer's activation when that layer takes its input pre-scaled
+            const float* const s_next =
+                (li + 1 < limit && !e->convs[li + 1].up && conv_form_of(li + 1, true).wino64 && gance::winograd64_input_prescaled(e->convs[li + 1].cout))
+                    ? e->ws->styles + e->conv_s_off[li + 1]
+                    : nullptr;
             // the fused kernel (transposed conv + FIR in one launch) where it is supported and fills the chip;
             // GANCE_TUNE_UPFIR = 0 / 1 / 2 overrides the engine flags (never / auto / always)
             static const int upfir_env = [] { const char* v = std::getenv("GANCE_TUNE_UPFIR"); return v ? std::atoi(v) : -1; }();
@@ -602,6 +618,7 @@ int synthesize_from_dlat(gance_engine* e, const float* d_dlat, int B, uint8_t* d
                     u.d_stride = e->dtot;
                     u.noise_strength = e->conv_ns[li];
                     u.x_b_stride = x_b_stride;
+                    u.s_next = s_next;
                     std::snprintf(name, sizeof(name), "convTF%d_%dx%d_%d->%d", c.layer_idx, res, res, c.cin, c.cout);
                     {
                         const double flops = 2.0 * 9 * (double)c.cin * c.cout * H * W * B;
@@ -639,6 +656,8 @@ int synthesize_from_dlat(gance_engine* e, const float* d_dlat, int B, uint8_t* d
             f.H = H;
             f.W = W;
             f.nsplit = p.nsplit;
+            f.s_next = s_next;
+            f.s_next_stride = e->ctot;
             std::snprintf(name, sizeof(name), "fir%d_%dx%d", c.layer_idx, res, res);
             StepScope scope(e, stream, name, 0.0,
                             4.0 * (double)B * c.cout * res * res * (p.nsplit + 1));

@@ -144,6 +144,7 @@ bool winograd64_supported(int cin, int cout, int H, int W);
 size_t winograd64_weight_floats(int cin, int cout);
 void winograd64_transform_weights(const float* w_in /*[9][cin][cout]*/, int cin, int cout, float* w_out);
 hipError_t launch_winograd64_conv(const ConvArgs& args, hipStream_t stream);
+bool winograd64_input_prescaled(int cout);  // the geometry this Cout runs in expects x already multiplied by the layer's style
 bool winograd64_rgb_supported(int cout);
 int winograd64_rgb_partials(int cout);  // partial images the launch writes: [partials][B][3][OH][OW]
 hipError_t launch_winograd64_rgb_coef(const float* rgb_w, const float* rgb_s, int s_stride, int B, int cout, float* coef, hipStream_t stream);
@@ -165,6 +166,9 @@ struct UpFirArgs {
     int stagger_phases, stagger_ticks;                       // set by upfir_plan: start delay (phase * ticks of 10 ns)
     int debug_flags;  // timing ablations (GANCE_DEBUG_UPFIR): 1 no stores, 2 no epilogue at all, 4 no MFMA, 8 no DMA after the first chunk
     long long x_b_stride;
+    // nullptr, or the style of the NEXT layer, s_next[b * s_stride + co]: folded into the leaky ReLU, i.e. the stored
+    // activation is multiplied by it (the Winograd kernel on 16x16x4 MFMAs takes its input pre-scaled)
+    const float* s_next;
 };
 bool upfir_supported(int cin, int cout, int H, int W);
 size_t upfir_weight_floats(int cin, int cout);
@@ -210,6 +214,10 @@ struct FirArgs {
     float* out;
     float noise_strength;
     int B, C, H, W, nsplit;
+    // nullptr, or the style of the NEXT layer, s_next[b * s_next_stride + c]: the stored activation is multiplied by it
+    // (the Winograd kernel on 16x16x4 MFMAs takes its input pre-scaled: winograd64_conv.hip)
+    const float* s_next;
+    int s_next_stride;
 };
 hipError_t launch_fir_epilogue(const FirArgs& args, hipStream_t stream);
 

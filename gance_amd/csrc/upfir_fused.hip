@@ -106,7 +106,7 @@ __device__ __forceinline__ void lds_barrier() {
 constexpr int kStageOff = kSlot;
 constexpr int kCarryOff = kStageOff + (kStageFloats > kSlot ? kStageFloats : kSlot);
 constexpr int kConstOff = kCarryOff + kCarryFloats;
-size_t upfir_lds_bytes(int cin) { return sizeof(float) * ((size_t)kConstOff + cin + 2 * kBM + kStageRows * 2 * kSW); }
+size_t upfir_lds_bytes(int cin) { return sizeof(float) * ((size_t)kConstOff + cin + 3 * kBM + kStageRows * 2 * kSW); }
 
 __global__ __launch_bounds__(256, 1) void upfir_fused_kernel(const UpFirArgs p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -116,7 +116,8 @@ __global__ __launch_bounds__(256, 1) void upfir_fused_kernel(const UpFirArgs p) 
     float* const s_lds = smem + kConstOff;      // style [Cin]
     float* const d_lds = s_lds + p.Cin;         // demod [32]
     float* const b_lds = d_lds + kBM;           // bias [32]
-    float* const nz_lds = b_lds + kBM;          // noise tile of the step [16][128], already times strength * sqrt 2
+    float* const sn_lds = b_lds + kBM;          // the next layer's style of these 32 channels (or 1): rides on the leaky ReLU
+    float* const nz_lds = sn_lds + kBM;         // noise tile of the step [16][128], already times strength * sqrt 2
 
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -231,6 +232,7 @@ __global__ __launch_bounds__(256, 1) void upfir_fused_kernel(const UpFirArgs p) 
     if (tid < kBM) {
         d_lds[tid] = p.d[(size_t)b * p.d_stride + m0 + tid];
         b_lds[tid] = p.bias[m0 + tid];
+        sn_lds[tid] = p.s_next != nullptr ? p.s_next[(size_t)b * p.s_stride + m0 + tid] : 1.0f;
     }
     for (int i = tid; i < kCarryFloats; i += 256) carry[i] = 0.f;
 
@@ -468,6 +470,7 @@ __global__ __launch_bounds__(256, 1) void upfir_fused_kernel(const UpFirArgs p) 
             const float dsc = d_lds[ch] * kSqrt2f;
             const float kh0 = 0.25f * dsc, kh1 = 0.75f * dsc;
             const float bias2 = b_lds[ch] * kSqrt2f;
+            const float lr6 = 0.6f * sn_lds[ch], lr4 = 0.4f * sn_lds[ch];  // leaky ReLU x the next layer's style
             const float* const carry_c = carry + ch * (kCarryRows * kTW) + 4 * cg;
             const float* const stage_c = stage + fc * (kStageRows * kTW) + 4 * cg;
             const int o_soff_base = (int)((8 * g * oplane + (long long)(oy0 + 1) * OWp + 2 * X0 + 4) * 4);
@@ -495,7 +498,7 @@ __global__ __launch_bounds__(256, 1) void upfir_fused_kernel(const UpFirArgs p) 
                     for (int o = 0; o < 4; ++o) v[o] = fmaf(0.25f, hnew[o], fmaf(0.75f, hc[o], fmaf(0.75f, hb[o], fmaf(0.25f, ha[o], bias2))));
                     if (has_noise) v += *reinterpret_cast<const f32x4*>(nz_lds + r * (2 * kSW) + 4 * cg);
 #pragma unroll
-                    for (int o = 0; o < 4; ++o) v[o] = fmaf(0.6f, v[o], 0.4f * __builtin_fabsf(v[o]));
+                    for (int o = 0; o < 4; ++o) v[o] = fmaf(lr6, v[o], lr4 * __builtin_fabsf(v[o]));
                     if (!(UPFIR_DBG & 1) || v[0] == 12345.f)
                         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), o_rsrc, o_voff, o_soff_base + r * OWp * 4, 0);
                 }

@@ -110,6 +110,12 @@ __device__ __forceinline__ void winograd64_body(const ConvArgs& p) {
     using G = Geo<MT, TG>;
     constexpr int kBM = G::kBM, kTH = G::kTH, kPH = G::kPH, kPlane = G::kPlane, kUFloats = G::kUFloats, kPlF4 = G::kPlF4;
     constexpr int kConstFloats = G::const_floats(RGB), kRgbOff = kConstHead + G::kNoiseFloats;
+    // The <2, 2> geometry takes its input ALREADY multiplied by this layer's style (ConvArgs::x contract; the producing up
+    // layer folds s[b][ci] into its leaky ReLU for free: V is linear in d): 4 of the 24 packed transform instructions per
+    // window and the style read leave the k-step (-3 %). In <4, 1> the same change tipped hipcc's register allocation --
+    // 256 accumulators + 256 other registers, nothing to spare -- into keeping accumulator tiles in VGPRs for part of the
+    // loop (80 copies per trip, +20 %): that geometry keeps the scale in its transform.
+    constexpr bool kPrescaled = TG == 2;
     constexpr int kPlPieces = G::kPlPieces, kSlot = G::kSlot, kPiecesPerWave = G::kPiecesPerWave, kUSlots = G::kUSlots, kPlSlots = G::kPlSlots;
     typedef float afrag_t __attribute__((ext_vector_type(MT)));
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -198,10 +204,12 @@ __device__ __forceinline__ void winograd64_body(const ConvArgs& p) {
                 st_x = (t.y0 * Wp + t.x0) * 4;
                 // the tile's constants (style of the sample, demod and bias of the channel tile) by dword LDS-DMA
                 float* const set = const0 + (st_tile & 1) * kConstFloats;
-                const __amdgpu_buffer_rsrc_t s_rsrc =
-                    __builtin_amdgcn_make_buffer_rsrc((void*)(p.s + (size_t)b * p.s_stride), 0, p.Cin * 4, 0x00020000);
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(s_rsrc, (lds_ptr_t)(set + wave * 64), 4, l4 + wave * 256, 0, 0, 0);
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(s_rsrc, (lds_ptr_t)(set + (wave + 4) * 64), 4, l4 + (wave + 4) * 256, 0, 0, 0);  // (in the vector offset: the resource's bound clips Cin < 512)
+                if constexpr (!kPrescaled) {
+                    const __amdgpu_buffer_rsrc_t s_rsrc =
+                        __builtin_amdgcn_make_buffer_rsrc((void*)(p.s + (size_t)b * p.s_stride), 0, p.Cin * 4, 0x00020000);
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(s_rsrc, (lds_ptr_t)(set + wave * 64), 4, l4 + wave * 256, 0, 0, 0);
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(s_rsrc, (lds_ptr_t)(set + (wave + 4) * 64), 4, l4 + (wave + 4) * 256, 0, 0, 0);  // (in the vector offset: the resource's bound clips Cin < 512)
+                }
                 if (wave < 2) {
                     const __amdgpu_buffer_rsrc_t c_rsrc = __builtin_amdgcn_make_buffer_rsrc(
                         (void*)(wave == 0 ? p.d + (size_t)b * p.d_stride + t.m_tile * kBM : p.bias + t.m_tile * kBM), 0, kBM * 4, 0x00020000);
@@ -296,7 +304,7 @@ __device__ __forceinline__ void winograd64_body(const ConvArgs& p) {
 #pragma unroll
                 for (int cp = 0; cp < 2; ++cp) win[tg][y][cp] = *reinterpret_cast<const f32x2_lds*>(pc + y * kPW + 2 * cp);
         }
-        sval = smem[style_off + kq];
+        if constexpr (!kPrescaled) sval = smem[style_off + kq];
     };
     // V = B^T (s d) B, B^T = [[1,0,-1,0],[0,1,1,0],[0,-1,1,0],[0,1,0,-1]]; the style scale rides on the window (V is linear in d).
     // Packed fp32 (v_pk_*_f32, two columns per instruction): the row pass works on column pairs; in the column pass
@@ -325,17 +333,16 @@ __device__ __forceinline__ void winograd64_body(const ConvArgs& p) {
             }
             return;
         }
-        const f32x2 s2 = {sval, sval};
 #pragma unroll
         for (int tg = 0; tg < TG; ++tg) {
             f32x2 t[4][2];
 #pragma unroll
             for (int cp = 0; cp < 2; ++cp) {
-                const f32x2 e1 = s2 * win[tg][1][cp], e2 = s2 * win[tg][2][cp];
-                t[0][cp] = __builtin_elementwise_fma(s2, win[tg][0][cp], -e2);
-                t[1][cp] = e1 + e2;
-                t[2][cp] = e2 - e1;
-                t[3][cp] = __builtin_elementwise_fma(-s2, win[tg][3][cp], e1);
+                static_assert(TG == 1 || kPrescaled, "the packed transform is the <2, 2> geometry's: no style scale in it");
+                t[0][cp] = win[tg][0][cp] - win[tg][2][cp];
+                t[1][cp] = win[tg][1][cp] + win[tg][2][cp];
+                t[2][cp] = win[tg][2][cp] - win[tg][1][cp];
+                t[3][cp] = win[tg][1][cp] - win[tg][3][cp];
                 // (kept opaque: where a packed result is only read by element, hipcc splits the operation again)
 #pragma unroll
                 for (int y = 0; y < 4; ++y) asm("" : "+v"(t[y][cp]));
@@ -571,7 +578,7 @@ __device__ __forceinline__ void winograd64_body(const ConvArgs& p) {
 #pragma unroll
                 for (int i = 0; i < 48; ++i) {
                     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                              // 1 MFMA
-                    if (i < 17 + 9 * TG) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);          // 1 LDS read
+                    if (i < 17 + (kPrescaled ? 8 : 9) * TG) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // 1 LDS read
                     if (i >= 4) __builtin_amdgcn_sched_group_barrier(0x002, TG, 0);                  // 1 VALU per window
                     if (i % 8 == 7) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);               // 1 LDS-DMA issue
                 }
@@ -591,6 +598,8 @@ bool winograd64_supported(int cin, int cout, int H, int W) {
     const bool geometry = cout % 64 == 0 ? (H % 8 == 0 && W % kTW == 0) : (cout % 32 == 0 && H % 16 == 0 && W % kTW == 0);
     return cin % (2 * kKC) == 0 && cin <= 512 && cin / kKC >= kNBUF && geometry;
 }
+
+bool winograd64_input_prescaled(int cout) { return cout % 64 != 0; }  // (the <2, 2> geometry: kPrescaled)
 
 size_t winograd64_weight_floats(int cin, int cout) { return (size_t)16 * cin * cout; }
 
