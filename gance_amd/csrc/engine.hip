@@ -345,8 +345,10 @@ int run_conv(gance_engine* e, const ConvLayerHost& c, int li, const LayerPlan& p
              long long x_b_stride, int H, int W, float* out, int epilogue, int out_row_stride,
              int out_y_off, int out_x_off, long long out_b_stride, long long out_c_stride,
              long long slab_stride, long long cls_stride, int B, hipStream_t stream,
-             const char* name, const FusedRgb* rgb = nullptr, bool winograd = false, bool wino64 = false) {
+             const char* name, const FusedRgb* rgb = nullptr, bool winograd = false, bool wino64 = false,
+             const float* s_next = nullptr) {
     gance::ConvArgs a{};
+    a.s_next = wino64 ? s_next : nullptr;  // (only the 16x16x4 Winograd kernels scale their stores)
     if (epilogue == gance::kEpilogueFullRgbPart) {  // (rgb->y: the partial image; the coefficient table is the workspace's)
         a.rgb_y = rgb->y;
         a.rgb_coef = e->ws->rgb_coef;
@@ -518,6 +520,25 @@ int synthesize_from_dlat(gance_engine* e, const float* d_dlat, int B, uint8_t* d
         form.wino64 = !form.fused_rgb && form.winograd && wino64_on && e->wino64_w[idx] != SIZE_MAX && idx > 0 && e->convs[idx - 1].up;
         return form;
     };
+    // Whether up layer idx runs as the fused kernel (transposed conv + FIR in one launch): where it is supported and fills
+    // the chip; GANCE_TUNE_UPFIR = 0 / 1 / 2 overrides the engine flags (never / auto / always). Decided here because the
+    // layer BEFORE it has to know: fed by a 16x16x4 Winograd launch the fused kernel takes its input pre-scaled by its style.
+    auto up_runs_fused = [&](int idx, gance::UpFirArgs* plan) -> bool {
+        const ConvLayerHost& c = e->convs[idx];
+        const int H = (1 << c.res_log2) / 2;
+        static const int upfir_env = [] { const char* v = std::getenv("GANCE_TUNE_UPFIR"); return v ? std::atoi(v) : -1; }();
+        const int upfir_mode = upfir_env >= 0 ? upfir_env
+                                              : ((e->cfg.flags & GANCE_FLAG_SPLIT_UPFIR) ? 0 : ((e->cfg.flags & GANCE_FLAG_FORCE_FUSED_UPFIR) ? 2 : 1));
+        if (!c.up || upfir_mode == 0 || e->upfir_w[idx] == SIZE_MAX) return false;
+        gance::UpFirArgs u{};
+        u.Cin = c.cin;
+        gance::upfir_plan(B, c.cout, H, H, e->num_cus, &u);
+        const int steps_per_seg = u.rows_per_seg / 8;
+        if (plan != nullptr) *plan = u;
+        return upfir_mode == 2 || (u.total_blocks >= e->num_cus * 3 / 4 && (u.segs == 1 || steps_per_seg >= 4));
+    };
+    static const bool prescale_up = [] { const char* v = std::getenv("GANCE_TUNE_PRESCALE_UP"); return !(v && std::atoi(v) == 0); }();
+    bool x_prescaled = false;  // x_in carries the style of the layer about to read it
     bool fused_rgb = false;
     for (int li = 0; li < limit; ++li) {
         const ConvLayerHost& c = e->convs[li];
@@ -535,6 +556,7 @@ int synthesize_from_dlat(gance_engine* e, const float* d_dlat, int B, uint8_t* d
             std::snprintf(name, sizeof(name), "conv%d_%dx%d_%d->%d", c.layer_idx, res, res, c.cin,
                           c.cout);
             const ConvForm form = conv_form_of(li, have_y);
+            x_prescaled = false;  // (set below where this launch scales its stores for the next layer)
             fused_rgb = form.fused_rgb;
             const bool winograd = form.winograd, winograd_last = form.winograd_last;
             if (fused_rgb) {
@@ -554,6 +576,11 @@ int synthesize_from_dlat(gance_engine* e, const float* d_dlat, int B, uint8_t* d
                 static const bool w64_rgb_enabled = [] { const char* v = std::getenv("GANCE_TUNE_W64_RGB"); return !(v && std::atoi(v) == 0); }();
                 rgb_part = form.wino64 && w64_rgb_enabled && gance::winograd64_rgb_supported(c.cout);
                 if (winograd) std::snprintf(name, sizeof(name), rgb_part ? "convW%d+rgb_%dx%d_%d->%d" : "convW%d_%dx%d_%d->%d", c.layer_idx, res, res, c.cin, c.cout);
+                // the next layer's style rides on this launch's stores when that layer is a fused up kernel
+                const float* const s_next_up =
+                    (form.wino64 && c.cout % 64 == 0 && prescale_up && li + 1 < limit && up_runs_fused(li + 1, nullptr)) ? e->ws->styles + e->conv_s_off[li + 1]
+                                                                                                                          : nullptr;
+                x_prescaled = s_next_up != nullptr;
                 int rc;
                 if (rgb_part) {
                     const int ri = c.res_log2 - 2;
@@ -564,11 +591,11 @@ int synthesize_from_dlat(gance_engine* e, const float* d_dlat, int B, uint8_t* d
                     FusedRgb part{nullptr, nullptr, nullptr, nullptr, rgb_partials == 1 ? e->ws->ybuf[have_y ? 1 - ycur : ycur] : e->ws->rgb_part, nullptr};
                     const bool last_unread = c.res_log2 == e->res_log2 && limit == num_convs && e->debug_stop_after <= 0;
                     rc = run_conv(e, c, li, p, x_in, x_b_stride, res, res, last_unread ? nullptr : x_out, gance::kEpilogueFullRgbPart,
-                                  res + 8, 1, 4, out_b, out_c, 0, 0, B, stream, name, &part, true, true);
+                                  res + 8, 1, 4, out_b, out_c, 0, 0, B, stream, name, &part, true, true, s_next_up);
                 } else {
                     rc = run_conv(e, c, li, p, x_in, x_b_stride, res, res, x_out,
                                   gance::kEpilogueFull, res + 8, 1, 4, out_b, out_c, 0, 0, B, stream,
-                                  name, nullptr, winograd, form.wino64);
+                                  name, nullptr, winograd, form.wino64, s_next_up);
                 }
                 if (rc) return rc;
             } else {
@@ -591,17 +618,11 @@ int synthesize_from_dlat(gance_engine* e, const float* d_dlat, int B, uint8_t* d
                 (li + 1 < limit && !e->convs[li + 1].up && conv_form_of(li + 1, true).wino64 && gance::winograd64_input_prescaled(e->convs[li + 1].cout))
                     ? e->ws->styles + e->conv_s_off[li + 1]
                     : nullptr;
-            // the fused kernel (transposed conv + FIR in one launch) where it is supported and fills the chip;
-            // GANCE_TUNE_UPFIR = 0 / 1 / 2 overrides the engine flags (never / auto / always)
-            static const int upfir_env = [] { const char* v = std::getenv("GANCE_TUNE_UPFIR"); return v ? std::atoi(v) : -1; }();
-            const int upfir_mode = upfir_env >= 0 ? upfir_env
-                                                  : ((e->cfg.flags & GANCE_FLAG_SPLIT_UPFIR) ? 0 : ((e->cfg.flags & GANCE_FLAG_FORCE_FUSED_UPFIR) ? 2 : 1));
-            if (upfir_mode != 0 && e->upfir_w[li] != SIZE_MAX) {
+            const bool input_prescaled = x_prescaled;
+            x_prescaled = false;
+            {
                 gance::UpFirArgs u{};
-                u.Cin = c.cin;
-                gance::upfir_plan(B, c.cout, H, W, e->num_cus, &u);
-                const int steps_per_seg = u.rows_per_seg / 8;
-                if (upfir_mode == 2 || (u.total_blocks >= e->num_cus * 3 / 4 && (u.segs == 1 || steps_per_seg >= 4))) {
+                if (up_runs_fused(li, &u)) {
                     u.x = x_in;
                     u.w = e->pool + e->upfir_w[li];
                     u.s = e->ws->styles + e->conv_s_off[li];
@@ -619,6 +640,7 @@ int synthesize_from_dlat(gance_engine* e, const float* d_dlat, int B, uint8_t* d
                     u.noise_strength = e->conv_ns[li];
                     u.x_b_stride = x_b_stride;
                     u.s_next = s_next;
+                    u.input_prescaled = input_prescaled ? 1 : 0;
                     std::snprintf(name, sizeof(name), "convTF%d_%dx%d_%d->%d", c.layer_idx, res, res, c.cin, c.cout);
                     {
                         const double flops = 2.0 * 9 * (double)c.cin * c.cout * H * W * B;

@@ -118,6 +118,9 @@ struct ConvArgs {
     const float* rgb_y_prev;
     float* rgb_y;
     unsigned char* rgb_u8;
+    // winograd64 kernels: nullptr, or the style of the layer that reads `out`, s_next[b * s_stride + co]: the stored
+    // activation is multiplied by it (the fused up kernel then skips the style scale in its K loop)
+    const float* s_next;
     const float* rgb_coef;  // kEpilogueFullRgbPart: [B][Cout / 4][64], launch_winograd64_rgb_coef; rgb_y: [Cout / 64 or 1][B][3][OH][OW]
     unsigned long long* debug_stamps;  // [blocks][4] s_memrealtime stamps when debug_flags & 16
     int debug_flags;       // timing ablations only (GANCE_DEBUG_CONV): 1 no stores, 2 no DMA after chunk 0, 4 no MFMA
@@ -169,6 +172,7 @@ struct UpFirArgs {
     // nullptr, or the style of the NEXT layer, s_next[b * s_stride + co]: folded into the leaky ReLU, i.e. the stored
     // activation is multiplied by it (the Winograd kernel on 16x16x4 MFMAs takes its input pre-scaled)
     const float* s_next;
+    int input_prescaled;  // x arrives multiplied by this layer's own style (its producer was given s_next): no style scale in the K loop
 };
 bool upfir_supported(int cin, int cout, int H, int W);
 size_t upfir_weight_floats(int cin, int cout);

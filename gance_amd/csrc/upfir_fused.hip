@@ -108,7 +108,11 @@ constexpr int kCarryOff = kStageOff + (kStageFloats > kSlot ? kStageFloats : kSl
 constexpr int kConstOff = kCarryOff + kCarryFloats;
 size_t upfir_lds_bytes(int cin) { return sizeof(float) * ((size_t)kConstOff + cin + 3 * kBM + kStageRows * 2 * kSW); }
 
-__global__ __launch_bounds__(256, 1) void upfir_fused_kernel(const UpFirArgs p) {
+// kPre: the input arrives ALREADY multiplied by this layer's style (the Winograd kernel that produced it folded
+// s[b][ci] into its stores): the per-tap `weight fragment x style` multiply and the wait state hipcc puts between it
+// and the MFMAs -- nine of each per pair of input channels, sitting between the MFMA groups -- cost 5 ... 7 % of the layer.
+template <bool kPre>
+__device__ __forceinline__ void upfir_fused_body(const UpFirArgs& p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* const ring0 = smem;
     float* const stage = smem + kStageOff;      // [8 ch][16 rows][132], over ring slot 1
@@ -332,7 +336,7 @@ __global__ __launch_bounds__(256, 1) void upfir_fused_kernel(const UpFirArgs p) 
                 const float* const Wh = cur_buf + aoffh;
                 const float* const sph = s_lds + k * kKC + q4;
                 anext = Wl[0];
-                snext = sp[0];
+                snext = kPre ? 1.0f : sp[0];
                 load_b(0);
                 constexpr int kGroupFirst[4] = {0, 4, 6, 8}, kGroupTaps[4] = {4, 2, 2, 1};
 #pragma unroll
@@ -340,9 +344,13 @@ __global__ __launch_bounds__(256, 1) void upfir_fused_kernel(const UpFirArgs p) 
                     const float sv = snext;
                     if ((kk & 1) == 0) {
                         // the halo operands of channels 4 j .. 4 j + 3 (j = kk / 2), used after the main MFMAs of kk + 1
-                        const float sh4 = sph[2 * kk];
 #pragma unroll
-                        for (int sh = 0; sh < 4; ++sh) bhalo[sh] = Pl[boffh + 2 * kk * kPlane + shift_off(sh)] * sh4;
+                        for (int sh = 0; sh < 4; ++sh) bhalo[sh] = Pl[boffh + 2 * kk * kPlane + shift_off(sh)];
+                        if constexpr (!kPre) {
+                            const float sh4 = sph[2 * kk];
+#pragma unroll
+                            for (int sh = 0; sh < 4; ++sh) bhalo[sh] *= sh4;
+                        }
                     }
 #pragma unroll
                     for (int grp = 0; grp < 4; ++grp) {
@@ -355,11 +363,11 @@ __global__ __launch_bounds__(256, 1) void upfir_fused_kernel(const UpFirArgs p) 
                                 anext = Wl[((t + 1) * kKC + 2 * kk) * kBM];
                             } else if (kk + 1 < kKC / 2) {
                                 anext = Wl[(2 * (kk + 1)) * kBM];
-                                snext = sp[2 * (kk + 1)];
+                                if constexpr (!kPre) snext = sp[2 * (kk + 1)];
                                 load_b(kk + 1);
                             }
                             __builtin_amdgcn_sched_barrier(0);
-                            a[i] = araw * sv;
+                            a[i] = kPre ? araw : araw * sv;
 #pragma unroll
                             for (int jj = 0; jj < 4; ++jj)
                                 acc[grp][jj] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], bfrag[kk & 1][tap_shift(t)][jj], acc[grp][jj], 0, 0, 0);
@@ -399,7 +407,7 @@ __global__ __launch_bounds__(256, 1) void upfir_fused_kernel(const UpFirArgs p) 
                 // first position row and the halo tile) and EO tap 5 (wave 1: the halo tile; wave 0: its tiles)
 #pragma unroll
                 for (int kk = 0; kk < kKC / 2; ++kk) {
-                    const float sv = sp[2 * kk];
+                    const float sv = kPre ? 1.0f : sp[2 * kk];
 #pragma unroll
                     for (int t = 2; t <= 5; ++t) {
                         if (t == 4) continue;
@@ -411,7 +419,7 @@ __global__ __launch_bounds__(256, 1) void upfir_fused_kernel(const UpFirArgs p) 
                                     a, Pl[boff[jj] + 2 * kk * kPlane + shift_off(tap_shift(t))], acc[tap_cls(t)][jj], 0, 0, 0);
                         }
                         if ((kk & 1) == 1 && wave == tap_cls(t)) {  // the halo tile, four input channels at a time
-                            const float bh = Pl[boffh + 2 * (kk - 1) * kPlane + shift_off(tap_shift(t))] * s_lds[k * kKC + 2 * (kk - 1) + q4];
+                            const float bh = Pl[boffh + 2 * (kk - 1) * kPlane + shift_off(tap_shift(t))] * (kPre ? 1.0f : s_lds[k * kKC + 2 * (kk - 1) + q4]);
 #pragma unroll
                             for (int h = 0; h < 2; ++h) {
                                 const float ah = cur_buf[aoffh + (t * kKC + 2 * (kk - 1)) * kBM + 16 * h];
@@ -579,18 +587,26 @@ void upfir_plan(int B, int cout, int H, int W, int num_cus, UpFirArgs* a) {
     a->stagger_ticks = env_ticks >= 0 ? env_ticks : (int)(step_us * 100.0 / std::max(1, a->stagger_phases));
 }
 
+// (plain kernels around the templated body: see winograd64_conv.hip on kernel templates and the host pass)
+__global__ __launch_bounds__(256, 1) void upfir_fused_kernel(const UpFirArgs p) { upfir_fused_body<false>(p); }
+__global__ __launch_bounds__(256, 1) void upfir_fused_pre_kernel(const UpFirArgs p) { upfir_fused_body<true>(p); }
+
 hipError_t launch_upfir_fused(const UpFirArgs& args, hipStream_t stream) {
     static PerDeviceInt ready;  // the dynamic-LDS opt-in is per device
     int unused = 0;
     const hipError_t e = ready.get(
         [&](int, int* value) {
             *value = 1;
-            return hipFuncSetAttribute(reinterpret_cast<const void*>(upfir_fused_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+            hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(upfir_fused_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                 (int)upfir_lds_bytes(512));
+            if (err != hipSuccess) return err;
+            return hipFuncSetAttribute(reinterpret_cast<const void*>(upfir_fused_pre_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)upfir_lds_bytes(512));
         },
         &unused);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(upfir_fused_kernel, dim3(args.total_blocks), dim3(256), upfir_lds_bytes(args.Cin), stream, args);
+    hipLaunchKernelGGL(args.input_prescaled ? upfir_fused_pre_kernel : upfir_fused_kernel, dim3(args.total_blocks), dim3(256),
+                       upfir_lds_bytes(args.Cin), stream, args);
     return hipGetLastError();
 }
 

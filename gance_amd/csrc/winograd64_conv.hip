@@ -65,7 +65,7 @@ typedef __attribute__((address_space(3))) void* lds_ptr_t;
 constexpr int kKC = 4;                  // input channels per chunk = one k-step of the 16x16x4 MFMA
 constexpr int kTW = 32, kPW = kTW + 8;
 constexpr int kNBUF = 6;                // ring depth: a chunk is issued four k-steps before its first use
-constexpr int kConstHead = 512 + 64 + 64;  // style | demod | bias of a tile, then its noise [pixel row][32]
+constexpr int kConstHead = 512 + 64 + 64 + 64;  // style | demod | bias | the next layer's style of a tile, then its noise [pixel row][32]
 template <int MT, int TG>
 struct Geo {
     static_assert(MT * TG == 4, "256 accumulators");
@@ -214,6 +214,11 @@ __device__ __forceinline__ void winograd64_body(const ConvArgs& p) {
                     const __amdgpu_buffer_rsrc_t c_rsrc = __builtin_amdgcn_make_buffer_rsrc(
                         (void*)(wave == 0 ? p.d + (size_t)b * p.d_stride + t.m_tile * kBM : p.bias + t.m_tile * kBM), 0, kBM * 4, 0x00020000);
                     __builtin_amdgcn_raw_ptr_buffer_load_lds(c_rsrc, (lds_ptr_t)(set + 512 + wave * 64), 4, l4, 0, 0, 0);
+                } else if (TG == 1 && wave == 2 && p.s_next != nullptr) {  // (the 32-channel geometry only runs the last layer)
+                    // the style of the layer that reads this one's activation (an up layer taking its input pre-scaled)
+                    const __amdgpu_buffer_rsrc_t c_rsrc =
+                        __builtin_amdgcn_make_buffer_rsrc((void*)(p.s_next + (size_t)b * p.s_stride + t.m_tile * kBM), 0, kBM * 4, 0x00020000);
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(c_rsrc, (lds_ptr_t)(set + 640), 4, l4, 0, 0, 0);
                 }
                 // ... and its noise: the 2 TG pixel rows x 32 columns this wave's epilogue adds, two rows per instruction
                 // (fetched here, n k-steps ahead: a global load inside the epilogue cost its whole latency once per tile)
@@ -365,6 +370,7 @@ __device__ __forceinline__ void winograd64_body(const ConvArgs& p) {
         const Tile t = decode(i);
         const float* const d_lds = const0 + (i & 1) * kConstFloats + 512;
         const float* const b_lds = d_lds + 64;
+        const float* const sn_lds = b_lds + 64;
         const float* const nz_lds = const0 + (i & 1) * kConstFloats + kConstHead;
         const int le = fresh_lane();
         const int n16 = le & 15, kq = le >> 4;  // (shadow the kernel's: see fresh_lane)
@@ -456,6 +462,15 @@ __device__ __forceinline__ void winograd64_body(const ConvArgs& p) {
                 }
                 // (RGB: the network's last layer has no other reader: out == nullptr, nothing but the image leaves the chip)
                 if (!RGB || p.out != nullptr) {
+                    // (the stored activation carries the next layer's style when that layer wants it so: ConvArgs::s_next;
+                    // the ToRGB product above took the plain one)
+                    if (TG == 1 && p.s_next != nullptr) {
+                        const f32x4 sn = *reinterpret_cast<const f32x4*>(sn_lds + mt * 16 + 4 * kq);
+#pragma unroll
+                        for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+                            for (int dx = 0; dx < 2; ++dx) y[dy][dx] *= sn;
+                    }
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
 #pragma unroll
