@@ -112,9 +112,10 @@ __device__ __forceinline__ void winograd64_body(const ConvArgs& p) {
     constexpr int kConstFloats = G::const_floats(RGB), kRgbOff = kConstHead + G::kNoiseFloats;
     // The <2, 2> geometry takes its input ALREADY multiplied by this layer's style (ConvArgs::x contract; the producing up
     // layer folds s[b][ci] into its leaky ReLU for free: V is linear in d): 4 of the 24 packed transform instructions per
-    // window and the style read leave the k-step (-3 %). In <4, 1> the same change tipped hipcc's register allocation --
-    // 256 accumulators + 256 other registers, nothing to spare -- into keeping accumulator tiles in VGPRs for part of the
-    // loop (80 copies per trip, +20 %): that geometry keeps the scale in its transform.
+    // window and the style read leave the k-step (-3 %). In <4, 1> the same change (8 of 40 instructions) makes hipcc pick
+    // the untied form of 30 MFMAs (destination != accumulator input) although every AGPR is taken: it then stages those
+    // accumulators through VGPRs and one spare tuple, 120 copies in and out per loop trip (+20 %); that geometry keeps the
+    // scale in its transform. tools/check_w64_isa.py counts the accumulator moves of a build: run it after ANY edit here.
     constexpr bool kPrescaled = TG == 2;
     constexpr int kPlPieces = G::kPlPieces, kSlot = G::kSlot, kPiecesPerWave = G::kPiecesPerWave, kUSlots = G::kUSlots, kPlSlots = G::kPlSlots;
     typedef float afrag_t __attribute__((ext_vector_type(MT)));
@@ -323,11 +324,18 @@ __device__ __forceinline__ void winograd64_body(const ConvArgs& p) {
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
                 const float w0 = win[0][0][c >> 1][c & 1], w1 = win[0][1][c >> 1][c & 1], w2 = win[0][2][c >> 1][c & 1], w3 = win[0][3][c >> 1][c & 1];
-                const float e1 = sval * w1, e2 = sval * w2;
-                tcol[0][c] = fmaf(sval, w0, -e2);
-                tcol[1][c] = e1 + e2;
-                tcol[2][c] = e2 - e1;
-                tcol[3][c] = fmaf(-sval, w3, e1);
+                if constexpr (kPrescaled) {
+                    tcol[0][c] = w0 - w2;
+                    tcol[1][c] = w1 + w2;
+                    tcol[2][c] = w2 - w1;
+                    tcol[3][c] = w1 - w3;
+                } else {
+                    const float e1 = sval * w1, e2 = sval * w2;
+                    tcol[0][c] = fmaf(sval, w0, -e2);
+                    tcol[1][c] = e1 + e2;
+                    tcol[2][c] = e2 - e1;
+                    tcol[3][c] = fmaf(-sval, w3, e1);
+                }
             }
 #pragma unroll
             for (int y = 0; y < 4; ++y) {
