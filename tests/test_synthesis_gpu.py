@@ -301,11 +301,12 @@ np.savez(sys.argv[2], frames=frames, image=image)
 """
 
 
-@pytest.mark.parametrize("variable,off_value", [("GANCE_TUNE_W64_RGB", "0"), ("GANCE_TUNE_WINO64", "0")])
+@pytest.mark.parametrize("variable,off_value", [("GANCE_TUNE_W64_RGB", "0"), ("GANCE_TUNE_WINO64", "0"), ("GANCE_TUNE_PRESCALE_UP", "0")])
 def test_winograd_kernel_fallback_forms_agree_with_the_default(library, tmp_path, variable: str, off_value: str) -> None:
     """
     The tuning switches read once per process select kernels the default path no longer runs (the
-    Winograd kernel without the ToRGB product in its epilogue; the round-1 32-channel Winograd kernel):
+    Winograd kernel without the ToRGB product in its epilogue; the round-1 32-channel Winograd kernel; the
+    fused up kernel with the style scale in its own K loop instead of on its producer's stores):
     each in its own process, same network and latents, against the default form.
     """
     import os
