@@ -423,6 +423,15 @@ __device__ __forceinline__ void winograd64_body(const ConvArgs& p) {
                 // demodulation and bias of this lane's channels mt * 16 + 4 kq + (0 .. 3): one 16-byte read each
                 const f32x4 dm = *reinterpret_cast<const f32x4*>(d_lds + mt * 16 + 4 * kq);
                 const f32x4 bm = *reinterpret_cast<const f32x4*>(b_lds + mt * 16 + 4 * kq);
+                // (RGB) the A operands of the group's four ToRGB k-steps, read here with the other constants: read one by one
+                // in front of their MFMAs, each cost a full LDS round trip with nothing else to issue
+                float a_rgb[4] = {0.f, 0.f, 0.f, 0.f};
+                if constexpr (RGB) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) a_rgb[r] = rgb_lds[(mt * 4 + r) * 64 + le];
+                    // (pinned here: left alone hipcc sinks the reads back down to their first use)
+                    asm volatile("" : "+v"(a_rgb[0]), "+v"(a_rgb[1]), "+v"(a_rgb[2]), "+v"(a_rgb[3]));
+                }
                 f32x4 m[16];
 #pragma unroll
                 for (int pos = 0; pos < 16; ++pos) {
@@ -452,7 +461,7 @@ __device__ __forceinline__ void winograd64_body(const ConvArgs& p) {
                 if constexpr (RGB) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const float a_r = rgb_lds[(mt * 4 + r) * 64 + le];
+                        const float a_r = a_rgb[r];
                         // (the four pixels of a k-step back to back: independent accumulators between dependent ones)
 #pragma unroll
                         for (int dy = 0; dy < 2; ++dy)
