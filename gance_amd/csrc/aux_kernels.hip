@@ -243,7 +243,30 @@ __global__ __launch_bounds__(256) void fir_epilogue_kernel(const FirArgs p) {
         const float* to = te + p.cls_stride;  // class + 1 = odd columns of the same row parity
         float e[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
         float o[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        for (int sp = 0; sp < p.nsplit; ++sp) {
+        // (four slabs' loads in flight at a time, added in slab order)
+        int sp = 0;
+        for (; sp + 4 <= p.nsplit; sp += 4) {
+            float4 e4[4], o4[4];
+            float e5[4], o0[4], o5[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const size_t u = (size_t)((sp + j) * p.B + b) * p.unit_stride;
+                e4[j] = *reinterpret_cast<const float4*>(te + u);
+                o4[j] = *reinterpret_cast<const float4*>(to + u);
+                e5[j] = te[u + 4];
+                o0[j] = to[u - 1];
+                o5[j] = to[u + 4];
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                e[0] += e4[j].x; e[1] += e4[j].y; e[2] += e4[j].z; e[3] += e4[j].w;
+                e[4] += e5[j];
+                o[0] += o0[j];
+                o[1] += o4[j].x; o[2] += o4[j].y; o[3] += o4[j].z; o[4] += o4[j].w;
+                o[5] += o5[j];
+            }
+        }
+        for (; sp < p.nsplit; ++sp) {
             const size_t u = (size_t)(sp * p.B + b) * p.unit_stride;
             const float4 e4 = *reinterpret_cast<const float4*>(te + u);
             const float4 o4 = *reinterpret_cast<const float4*>(to + u);
@@ -308,8 +331,18 @@ __global__ __launch_bounds__(256) void splitk_finish_kernel(const float* __restr
                                                             int W, size_t total) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= total) return;
+    // (eight slabs' loads in flight at a time, added in slab order: one load per add made a one-frame call wait
+    // nsplit = up to 128 memory round trips here)
     float v = slabs[i];
-    for (int sp = 1; sp < nsplit; ++sp) v += slabs[(size_t)sp * slab_stride + i];
+    int sp = 1;
+    for (; sp + 8 <= nsplit; sp += 8) {
+        float t[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) t[j] = slabs[(size_t)(sp + j) * slab_stride + i];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v += t[j];
+    }
+    for (; sp < nsplit; ++sp) v += slabs[(size_t)sp * slab_stride + i];
     const int x = (int)(i % W);
     const int y = (int)((i / W) % H);
     const size_t bc = i / ((size_t)W * H);
