@@ -1,0 +1,21 @@
+"""
+The Winograd kernel's register allocation is a knife edge (256 accumulators + 256 other registers): small edits have
+made hipcc stage accumulator tiles through VGPRs, 80 ... 120 copies per loop trip, +13 ... +20 % run time, with every
+parity test still green. This check cross-compiles the kernel (no GPU needed) and counts accumulator moves per kernel:
+only the epilogue's 256 reads and the clears may be there (tools/check_w64_isa.py).
+"""
+import shutil
+import subprocess
+import sys
+from pathlib import Path
+
+import pytest
+
+REPO_ROOT = Path(__file__).resolve().parent.parent
+
+
+@pytest.mark.skipif(shutil.which("hipcc") is None and not Path("/opt/rocm/bin/hipcc").exists(), reason="needs hipcc")
+def test_winograd_kernels_keep_their_accumulators_in_agprs() -> None:
+    result = subprocess.run([sys.executable, str(REPO_ROOT / "tools" / "check_w64_isa.py")], capture_output=True, text=True, timeout=900)
+    assert result.returncode == 0, result.stdout + result.stderr
+    assert "winograd64_rgb_kernel" in result.stdout and "winograd64_c32_rgb_kernel" in result.stdout
