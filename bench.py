@@ -281,12 +281,6 @@ def main() -> int:
     device = torch.device("cuda", local_rank)
     if world_size > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        # The only collective is the gather of finished frames into rank 0 (< 25 GB/s over seven xGMI links at N = 8),
-        # overlapped with the next step's synthesis. RCCL moves data with copy kernels, one workgroup per channel, and
-        # the conv kernels are persistent grids of one block per CU: every CU RCCL holds on rank 0 is a CU a conv launch
-        # waits for. Four channels carry the traffic many times over (the default is sized for all-reduce bandwidth).
-        os.environ.setdefault("NCCL_MAX_NCHANNELS", "4")
-        os.environ.setdefault("NCCL_MIN_NCHANNELS", "1")
         if rehearsal:
             dist.init_process_group(backend="gloo")
         else:
