@@ -1,0 +1,44 @@
+"""
+bench.py's host-side bookkeeping (no GPU): how a launch of the engine's step table maps to a kernel and to the flops
+the matrix cores execute, and that the committed traffic record answers for the launches that can be dominant.
+"""
+import importlib.util
+import json
+from pathlib import Path
+
+REPO_ROOT = Path(__file__).resolve().parent.parent
+
+
+def _bench_module():
+    spec = importlib.util.spec_from_file_location("bench_under_test", REPO_ROOT / "bench.py")
+    module = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(module)
+    return module
+
+
+def test_step_names_map_to_kernels_and_executed_flops() -> None:
+    bench = _bench_module()
+    assert bench.kernel_of_step("convTF15_1024x1024_64->32") == "upfir_fused_kernel"
+    assert bench.kernel_of_step("convW16+rgb_1024x1024_32->32") == "winograd64_c32_rgb_kernel"
+    assert bench.kernel_of_step("convW8+rgb_64x64_512->512") == "winograd64_rgb_kernel"
+    assert bench.kernel_of_step("convW14_512x512_64->64") == "winograd64_kernel"
+    assert bench.kernel_of_step("conv16+torgb_1024x1024_32->32") == "modconv_mfma_kernel"
+    # Winograd F(2x2, 3x3): 16 multiplies per 2x2 tile and input channel instead of 36
+    assert abs(bench.executed_fraction("convW8+rgb_64x64_512->512") - 16.0 / 36.0) < 1e-12
+    assert bench.executed_fraction("convTF9_128x128_512->256") == 1.0
+    assert bench.executed_fraction("conv4_16x16_512->512") == 1.0
+
+
+def test_traffic_record_covers_the_dominant_launches_of_the_default_workload() -> None:
+    bench = _bench_module()
+    record = json.loads((REPO_ROOT / "profiles" / "traffic_latest.json").read_text())
+    workload = record["workload"]
+    for step in ("convW16+rgb_1024x1024_32->32", "convTF15_1024x1024_64->32"):
+        measured = bench.measured_traffic(step, workload["resolution"], workload["frames_per_step_per_gpu"])
+        assert measured is not None and measured > 0
+    for entry in record["launches"].values():
+        # HBM traffic within a quarter of the algorithmic bytes (tensors read once, written once): the kernels re-read little
+        assert 1.0 <= entry["hbm_bytes_per_launch"] / entry["algorithmic_bytes_per_launch"] < 1.25
+        assert 0.3 < entry["mfma_busy_fraction"] < 1.0
+    # another workload: no figure rather than a wrong one
+    assert bench.measured_traffic("convW16+rgb_1024x1024_32->32", 512, workload["frames_per_step_per_gpu"]) is None
