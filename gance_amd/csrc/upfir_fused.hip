@@ -121,7 +121,7 @@ __device__ __forceinline__ void upfir_fused_body(const UpFirArgs& p) {
     float* const d_lds = s_lds + p.Cin;         // demod [32]
     float* const b_lds = d_lds + kBM;           // bias [32]
     float* const sn_lds = b_lds + kBM;          // the next layer's style of these 32 channels (or 1): rides on the leaky ReLU
-    float* const nz_lds = sn_lds + kBM;         // noise tile of the step [16][128], already times strength * sqrt 2
+    float* const nz_lds = sn_lds + kBM;         // noise tile of the step [16][128] (raw: strength * sqrt 2 is applied where it is added)
 
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -272,6 +272,8 @@ __device__ __forceinline__ void upfir_fused_body(const UpFirArgs& p) {
         (void*)(p.out + ((size_t)b * p.Cout + m0) * oplane), 0, 0x7fffffff, 0x00020000);
     const int o_voff = (int)((fc * oplane + 4 * cg) * 4);
     const bool has_noise = p.noise != nullptr;
+    // (the noise plane [2H][2W] as a bounded resource: a row outside it reads as zeros instead of faulting)
+    const __amdgpu_buffer_rsrc_t nz_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.noise, 0, (2 * H) * (2 * W) * 4, 0x00020000);
     const float ns2 = p.noise_strength * kSqrt2f;
 
     int ring = 0;
@@ -281,6 +283,7 @@ __device__ __forceinline__ void upfir_fused_body(const UpFirArgs& p) {
     auto run_step = [&](auto flush_tag, const int si) {
         constexpr bool kFlush = decltype(flush_tag)::value;
         const int y0 = y_begin + kTH * si;
+        const int oy_noise = 2 * y0 - 2;  // output row of the epilogue's window row 0 (= oy0 there)
         f32x16 acc[4][4];
         f32x4 acch[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
@@ -295,6 +298,18 @@ __device__ __forceinline__ void upfir_fused_body(const UpFirArgs& p) {
             if (!(k == 0 && landed)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
+            if (k == 0 && has_noise && si >= 0) {
+                // The step's noise tile [16 rows][128 columns] by LDS-DMA, two 4 KB pieces per block: behind this barrier
+                // every wave has left the previous epilogue (the tile's last reader), and the data lands under the first
+                // chunk's MFMAs. (It used to be loaded into registers in the epilogue, a memory round trip in front of the
+                // first store of every step.) Rows above / below the image are outside the resource: they read as zero.
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const int row = oy_noise + 2 * wave + 8 * q + (lane >> 5);
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(nz_rsrc, (lds_ptr_t)(nz_lds + 4 * (wave * 64 + 256 * q)), 16,
+                                                             (row * (2 * W) + 2 * X0 + 4 * (lane & 31)) * 4, 0, 0, 0);
+                }
+            }
             float* const cur_buf = ring0 + ring * kSlot;
             float* const nxt_buf = ring0 + (ring ^ 1) * kSlot;
             // the next chunk of the stream (this step's k+1, or the first one of the next step): its eight DMA pieces
@@ -440,18 +455,7 @@ __device__ __forceinline__ void upfir_fused_body(const UpFirArgs& p) {
         const int oy0 = 2 * y0 - 2;                  // output row of window row r = 0
         const int r_lo = max(0, -oy0);               // first image step: rows -2, -1 do not exist
         const int r_hi = min(16, 2 * H - oy0);       // flush step: only rows 2H-2, 2H-1
-        if (has_noise && emit) {
-            // the step's noise tile [16 rows][128 columns] -> LDS (two float4 per thread), pre-scaled
-#pragma unroll
-            for (int q = 0; q < 2; ++q) {
-                const int f = tid + 256 * q;  // float4 index: 32 per row
-                const int r = f >> 5;
-                f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
-                if (r >= r_lo && r < r_hi) v = *reinterpret_cast<const f32x4*>(p.noise + (size_t)(oy0 + r) * OW + 2 * X0 + 4 * (f & 31));
-                *reinterpret_cast<f32x4*>(nz_lds + 4 * f) = v * ns2;
-            }
-        }
-        // the next step's first chunk (and the noise) must have landed before the first store is issued
+        // the next step's first chunk must have landed before the first store is issued
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         landed = true;
 
@@ -504,7 +508,7 @@ __device__ __forceinline__ void upfir_fused_body(const UpFirArgs& p) {
                     f32x4 v;
 #pragma unroll
                     for (int o = 0; o < 4; ++o) v[o] = fmaf(0.25f, hnew[o], fmaf(0.75f, hc[o], fmaf(0.75f, hb[o], fmaf(0.25f, ha[o], bias2))));
-                    if (has_noise) v += *reinterpret_cast<const f32x4*>(nz_lds + r * (2 * kSW) + 4 * cg);
+                    if (has_noise) v += ns2 * *reinterpret_cast<const f32x4*>(nz_lds + r * (2 * kSW) + 4 * cg);
 #pragma unroll
                     for (int o = 0; o < 4; ++o) v[o] = fmaf(lr6, v[o], lr4 * __builtin_fabsf(v[o]));
                     if (!(UPFIR_DBG & 1) || v[0] == 12345.f)
