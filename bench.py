@@ -254,6 +254,11 @@ def main() -> int:
     parser.add_argument("--batch", type=int, default=64, help="frames per step per GPU (the engine's maximum; 32: -2 %, 16: -8 %)")
     parser.add_argument("--resolution", type=int, default=1024)
     parser.add_argument("--no-cpu-baseline", action="store_true")
+    parser.add_argument(
+        "--all-terms", action="store_true",
+        help="random weights with every noise strength and bias non-zero (StyleGAN2's own init has them at zero and the engine skips "
+        "absent noise): what a trained network costs; not the contract line",
+    )
     parser.add_argument("--no-extras", action="store_true", help="skip the extra measurements (configs[2], 3 networks, 2160 output, one-frame latency) a 1-GPU run adds to the line")
     parser.add_argument("--print-steps", action="store_true", help="per-launch table on stderr")
     parser.add_argument(
@@ -289,7 +294,7 @@ def main() -> int:
     resolution, batch = args.resolution, args.batch
     if args.workload == "blend":
         return blend_workload(args, device)
-    variables = sg2_spec.make_random_variables(resolution, seed=0)
+    variables = sg2_spec.make_random_variables(resolution, seed=0, perturb=args.all_terms)
     engine = hip_lib.Engine(variables, resolution, max_batch=batch, device=local_rank, profile=True)
 
     # inputs resident in HBM before the timed region: rank 0 draws every rank's z and scatters them
@@ -389,7 +394,7 @@ def main() -> int:
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "f32",
-            "data": "synthetic (random-init weights seed 0, RandomState(1) z vectors)" + (" REHEARSAL: ranks share one GPU over gloo, not a measurement" if rehearsal else ""),
+            "data": "synthetic (random-init weights seed 0, RandomState(1) z vectors)" + (" --all-terms: noise strengths and biases non-zero" if args.all_terms else "") + (" REHEARSAL: ranks share one GPU over gloo, not a measurement" if rehearsal else ""),
             "config": {
                 "workload": "BASELINE.json configs[1]: FFHQ config-f %dx%d random-init, batched random-z synthesis (mapping + truncation psi=1.2 + synthesis + uint8 NHWC), frames resident in HBM" % (resolution, resolution),
                 "frames_per_step_per_gpu": batch,
