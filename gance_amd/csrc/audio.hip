@@ -279,9 +279,29 @@ __global__ void rms_kernel(const float* __restrict__ audio, size_t num_samples, 
         return __fmul_rn(v, v);
     };
     const float total = pairwise_sum_f32(sq, 0, L);
-    // correctly rounded float32 sqrt: sqrt in float64 then one rounding (53 >= 2*24+2 bits, so the
-    // double rounding is innocuous); the mean's division by L = 512 is exact
-    rms[t] = (float)sqrt((double)(total / (float)L));
+    // np.mean: the float32 sum divided by the count in float32 (exact when L is a power of two); correctly
+    // rounded float32 sqrt: sqrt in float64 then one rounding (53 >= 2*24+2 bits: the double rounding is innocuous)
+    rms[t] = (float)sqrt((double)__fdiv_rn(total, (float)L));
+}
+
+// scipy.ndimage.maximum_filter1d(series, size) (mode "reflect", origin 0) of reduce_vector_rms_rolling_max
+// (vector_reduction.py:38-58): out[i] = max over j in [i - size / 2, i - size / 2 + size) of the reflected series
+__global__ void rolling_max_kernel(const float* __restrict__ in, int n, int size, float* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float best = -INFINITY;
+    bool nan = false;
+    for (int k = 0; k < size; ++k) {
+        int j = i - size / 2 + k;
+        // reflect about the half-sample edges: (d c b a | a b c d | d c b a), period 2 n
+        j %= 2 * n;
+        if (j < 0) j += 2 * n;
+        if (j >= n) j = 2 * n - 1 - j;
+        const float v = in[j];
+        nan |= v != v;
+        best = fmaxf(best, v);
+    }
+    out[i] = nan ? NAN : best;
 }
 
 // a8 + a9: one thread walks the per-frame series: float32 mean (fill value), pandas rolling mean
@@ -990,6 +1010,29 @@ int gance_vec_rms_rolling_average(const float* d_audio, uint64_t num_samples, in
     hipLaunchKernelGGL(gance_audio::reduce_chain_kernel, dim3(1), dim3(64), 0, stream, chain, none);
     GANCE_AUDIO_CHECK(hipGetLastError());
     GANCE_AUDIO_CHECK(hipStreamSynchronize(stream));
+    return GANCE_OK;
+}
+
+int gance_vec_rms_rolling_max(const float* d_audio, uint64_t num_samples, int32_t vector_length, float* d_rms, float* d_out,
+                              int32_t num_values, void* stream_) {
+    if (d_audio == nullptr || d_rms == nullptr || d_out == nullptr || d_rms == d_out)
+        return audio_fail(GANCE_ERR_INVALID_ARGUMENT, "NULL or aliased argument to gance_vec_rms_rolling_max");
+    const int L = vector_length;
+    if (L < 1 || num_samples < (uint64_t)L) return audio_fail(GANCE_ERR_INVALID_ARGUMENT, "fewer samples than one frame");
+    const int n = (int)(1 + (num_samples - L) / 512);  // librosa's default hop of 512 whatever the frame length
+    if (num_values != n) return audio_fail(GANCE_ERR_INVALID_ARGUMENT, "num_values must be 1 + (num_samples - vector_length) // 512 = " + std::to_string(n));
+    hipStream_t stream;
+    if (int rc = vec_begin(d_audio, &stream, stream_)) return rc;
+    gance::DeviceGuard guard(gance::device_of_pointer(d_audio));
+    GANCE_AUDIO_CHECK(guard.status());
+    hipLaunchKernelGGL(gance_audio::rms_kernel, dim3((n + 63) / 64), dim3(64), 0, stream, d_audio, (size_t)num_samples, L, n, d_rms);
+    const int feature_length = n / 80;  // int(len(raw_rms) / 80), vector_reduction.py:51
+    if (feature_length > 0)
+        hipLaunchKernelGGL(gance_audio::rolling_max_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, (const float*)d_rms, n,
+                           feature_length, d_out);
+    else
+        GANCE_AUDIO_CHECK(hipMemcpyAsync(d_out, d_rms, (size_t)n * sizeof(float), hipMemcpyDeviceToDevice, stream));
+    GANCE_AUDIO_CHECK(hipGetLastError());
     return GANCE_OK;
 }
 

@@ -244,6 +244,7 @@ struct gance_workspace {
 struct GraphEntry {
     hipGraphExec_t exec = nullptr;
     bool warmed = false;
+    bool disabled = false;  // capture failed once: this combination stays on eager launches
 };
 
 struct gance_engine {
@@ -576,10 +577,12 @@ int synthesize_from_dlat(gance_engine* e, const float* d_dlat, int B, uint8_t* d
                 static const bool w64_rgb_enabled = [] { const char* v = std::getenv("GANCE_TUNE_W64_RGB"); return !(v && std::atoi(v) == 0); }();
                 rgb_part = form.wino64 && w64_rgb_enabled && gance::winograd64_rgb_supported(c.cout);
                 if (winograd) std::snprintf(name, sizeof(name), rgb_part ? "convW%d+rgb_%dx%d_%d->%d" : "convW%d_%dx%d_%d->%d", c.layer_idx, res, res, c.cin, c.cout);
-                // the next layer's style rides on this launch's stores when that layer is a fused up kernel
+                // the next layer's style rides on this launch's stores when that layer is a fused up kernel — and only when this
+                // launch also does the ToRGB channel sum (from the plain values): torgb_kernel would otherwise read the scaled ones
                 const float* const s_next_up =
-                    (form.wino64 && c.cout % 64 == 0 && prescale_up && li + 1 < limit && up_runs_fused(li + 1, nullptr)) ? e->ws->styles + e->conv_s_off[li + 1]
-                                                                                                                          : nullptr;
+                    (rgb_part && form.wino64 && c.cout % 64 == 0 && prescale_up && li + 1 < limit && up_runs_fused(li + 1, nullptr))
+                        ? e->ws->styles + e->conv_s_off[li + 1]
+                        : nullptr;
                 x_prescaled = s_next_up != nullptr;
                 int rc;
                 if (rgb_part) {
@@ -1153,6 +1156,10 @@ static int host_call(gance_engine* e, const float* h_in, size_t in_floats, int b
     std::memcpy(ws->pinned_in, h_in, in_floats * sizeof(float));
     GANCE_HIP_CHECK(hipMemcpyAsync(d_in, ws->pinned_in, in_floats * sizeof(float), hipMemcpyHostToDevice, hs));
     e->keep_skip_image = h_f32 != nullptr;
+    struct KeepSkipReset {  // every return path below leaves the flag cleared
+        gance_engine* engine;
+        ~KeepSkipReset() { engine->keep_skip_image = false; }
+    } keep_skip_reset{e};
     auto run = [&]() {
         return is_z ? synthesize_from_z(e, d_in, batch, psi, ws->u8buf, nullptr, hs)
                     : synthesize_from_dlat(e, d_in, batch, ws->u8buf, nullptr, hs);
@@ -1168,7 +1175,9 @@ static int host_call(gance_engine* e, const float* h_in, size_t in_floats, int b
         std::memcpy(&psi_bits, &psi, sizeof(psi_bits));
         const auto key = std::make_tuple(batch, is_z ? 1 : 0, is_z ? psi_bits : 0u, h_f32 != nullptr ? 1 : 0);
         GraphEntry& entry = e->graphs[key];
-        if (entry.exec != nullptr) {
+        if (entry.disabled) {
+            rc = run();
+        } else if (entry.exec != nullptr) {
             GANCE_HIP_CHECK(hipGraphLaunch(entry.exec, hs));
         } else if (!entry.warmed) {
             rc = run();
@@ -1182,16 +1191,15 @@ static int host_call(gance_engine* e, const float* h_in, size_t in_floats, int b
                 hipGraphDestroy(graph);
                 GANCE_HIP_CHECK(hipGraphLaunch(entry.exec, hs));
             } else {
-                // capture refused (it never should): fall back to eager launches for this combination for good
+                // capture refused (it never should): eager launches for this combination from now on
                 if (graph != nullptr) hipGraphDestroy(graph);
                 (void)hipGetLastError();
                 entry.exec = nullptr;
-                entry.warmed = false;
+                entry.disabled = true;
                 rc = run();
             }
         }
     }
-    e->keep_skip_image = false;
     if (rc) return rc;
     if (e->debug_stop_after > 0) {
         GANCE_HIP_CHECK(hipStreamSynchronize(hs));

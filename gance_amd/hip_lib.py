@@ -192,6 +192,15 @@ SIGNATURES = {
         ctypes.c_int,
         [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_double, ctypes.c_double, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p],
     ),
+    "gance_resample_audio_f64": (
+        ctypes.c_int,
+        [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_double, ctypes.c_double, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p],
+    ),
+    "gance_debug_resample_filter": (ctypes.c_int, [ctypes.POINTER(ctypes.c_double), ctypes.c_uint64]),
+    "gance_vec_rms_rolling_max": (
+        ctypes.c_int,
+        [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p],
+    ),
     "gance_gaussian_noise": (
         ctypes.c_int,
         [
@@ -651,10 +660,25 @@ def overlay_boxes_device(  # pylint: disable=too-many-arguments
     )
 
 
-def resample_audio_device(d_in: int, num_in: int, sr_orig: float, sr_new: float, d_out: int, num_out: int, stream: int = 0) -> None:
-    """Band-limited resampling of a mono float32 signal in HBM (raw device pointers); num_out = int(num_in * sr_new / sr_orig)."""
+def resample_audio_device(
+    d_in: int, num_in: int, sr_orig: float, sr_new: float, d_out: int, num_out: int, stream: int = 0, double_precision: bool = False
+) -> None:
+    """
+    resampy's kaiser_best resampling of a mono float32 (or float64) signal in HBM (raw device pointers);
+    num_out = int(num_in * sr_new / sr_orig). Returns once `stream` has drained.
+    :raises ValueError: for the arguments resampy rejects (non-positive rates, an output shorter than one sample).
+    """
     lib = load_library()
-    _check(lib, lib.gance_resample_audio_f32(d_in, num_in, float(sr_orig), float(sr_new), d_out, num_out, stream or None))
+    entry = lib.gance_resample_audio_f64 if double_precision else lib.gance_resample_audio_f32
+    _value_error_on_invalid_argument(lib, entry(d_in, num_in, float(sr_orig), float(sr_new), d_out, num_out, stream or None))
+
+
+def resample_filter_table() -> np.ndarray:
+    """The 32 769-entry kaiser_best half window the resampler interpolates (host only, no GPU needed)."""
+    lib = load_library()
+    table = np.empty(32769, dtype=np.float64)
+    _check(lib, lib.gance_debug_resample_filter(table.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), ctypes.c_uint64(table.size)))
+    return table
 
 
 # ---- stand-alone stages of the audio -> latent chain (gance_vec_*): numpy in, numpy out ------------
@@ -771,6 +795,26 @@ def vec_rms_rolling_average(
         ),
     )
     return d_rms.cpu().numpy(), d_rolling.cpu().numpy(), d_smoothed.cpu().numpy()
+
+
+def vec_rms_rolling_max(audio: np.ndarray, vector_length: int, device: int = 0) -> Tuple[np.ndarray, np.ndarray]:
+    """(raw RMS float32, its rolling maximum over len // 80 values), one value per hop of 512 samples."""
+    lib = load_library()
+    host = np.ascontiguousarray(audio, dtype=np.float32)
+    if host.shape[0] < vector_length:
+        raise ValueError("fewer samples than one frame")
+    count = 1 + (host.shape[0] - vector_length) // 512
+    d_audio = torch.from_numpy(host).to(_cuda(device))
+    d_rms = torch.empty((count,), dtype=torch.float32, device=d_audio.device)
+    d_out = torch.empty((count,), dtype=torch.float32, device=d_audio.device)
+    stream = torch.cuda.current_stream(d_audio.device).cuda_stream
+    _value_error_on_invalid_argument(
+        lib,
+        lib.gance_vec_rms_rolling_max(
+            d_audio.data_ptr(), ctypes.c_uint64(host.shape[0]), int(vector_length), d_rms.data_ptr(), d_out.data_ptr(), count, stream or None
+        ),
+    )
+    return d_rms.cpu().numpy(), d_out.cpu().numpy()
 
 
 def vec_quantize(data: np.ndarray, num_indices: int, device: int = 0) -> np.ndarray:

@@ -18,14 +18,16 @@ The ops are thin: they validate shapes, allocate the outputs with torch and pass
 ctypes binding (gance_amd/hip_lib.py). There is no CPU implementation: on a CPU tensor an op raises.
 """
 
-from typing import Dict, Tuple
+import weakref
+from typing import Tuple
 
 import torch
 
 from gance_amd import hip_lib
 
-_ENGINES: Dict[int, hip_lib.Engine] = {}
-_BLENDS: Dict[int, hip_lib.Blend] = {}
+# weak: a handle must not keep an engine's HBM (weights + its share of the workspace) alive after its owner let go
+_ENGINES: "weakref.WeakValueDictionary[int, hip_lib.Engine]" = weakref.WeakValueDictionary()
+_BLENDS: "weakref.WeakValueDictionary[int, hip_lib.Blend]" = weakref.WeakValueDictionary()
 _NEXT_HANDLE = [1]
 
 
@@ -55,7 +57,7 @@ def _engine(handle: int) -> hip_lib.Engine:
     try:
         return _ENGINES[handle]
     except KeyError:
-        raise ValueError(f"unknown engine handle {handle}") from None
+        raise ValueError(f"unknown engine handle {handle} (never registered, closed or garbage-collected)") from None
 
 
 def _require_cuda(tensor: torch.Tensor, dtype: torch.dtype, name: str) -> None:

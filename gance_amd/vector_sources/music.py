@@ -8,13 +8,12 @@ Same names, modes, error behaviour and output contract as gance/vector_sources/m
 * The integer -> [-1, 1] remap is one vectorised linear map (the same `interp1d` line,
   slope * (x - lo) + out_lo) instead of a `multiprocessing.Pool().map` over every sample
   (vector_sources_common.py:59-61), which is seconds of pure overhead on a 30 s file.
-* Time-stretching used `resampy.resample` (kaiser_best), a third-party dependency that is not
-  available here and whose sample values no reference test pins (SURVEY.md §8c: parity UNPINNED;
-  only the output length is pinned, test/test_vector_source_music.py:13-24). `resample_audio`
-  below is this implementation's own band-limited (Kaiser-windowed sinc) resampler, a HIP kernel
-  (gance_amd/csrc/resample.hip), with the same length rule, `int(len(x) * ratio)`; it is NOT
-  bit-compatible with resampy. When the ratio is exactly 1 (the benchmark synthesises its WAV at
-  L * fps Hz) the samples pass through unchanged and no GPU is touched.
+* Time-stretching is `resampy.resample` (0.2.2, kaiser_best), a third-party dependency that is not installed
+  here: its published algorithm is restated operation for operation as a HIP kernel
+  (gance_amd/csrc/resample.hip: the 32 769-entry filter table, linear interpolation between entries, the
+  running-sum time register, accumulation in the signal's dtype) and pinned by the reference's own known answer
+  on this path (test/test_dynamic_model_switching.py:15-39, reproduced in tests/test_music_gpu.py). As in
+  resampy, a ratio of exactly 1 still passes the samples through the low-pass filter.
 """
 
 import pickle
@@ -66,23 +65,28 @@ def read_wav_file(wav_path: Path, convert_to_32bit_float: bool = True) -> WavFil
 
 def resample_audio(samples: np.ndarray, sr_orig: float, sr_new: float) -> np.ndarray:
     """
-    Band-limited resampling by a Kaiser-windowed sinc (64 zero crossings, beta 14.77, roll-off
-    0.9476: the published kaiser_best design) on the GPU (gance_resample_audio_f32). Output length
-    int(len(samples) * sr_new / sr_orig). A ratio of exactly 1 passes the samples through.
+    `resampy.resample(samples, sr_orig, sr_new)` (kaiser_best) of a 1-D signal on the GPU
+    (gance_resample_audio_f32 / _f64). Output length int(len(samples) * sr_new / sr_orig), output dtype = input
+    dtype for float32 / float64 (the accumulation runs in it, as resampy's does); other dtypes go through float32.
+    :raises ValueError: non-positive sample rates, or a signal too short to give one output sample (resampy's checks).
     """
-    ratio = float(sr_new) / float(sr_orig)
-    if ratio <= 0:
-        raise ValueError("sample rates must be positive")
+    if sr_orig <= 0:
+        raise ValueError(f"Invalid sample rate: sr_orig={sr_orig}")
+    if sr_new <= 0:
+        raise ValueError(f"Invalid sample rate: sr_new={sr_new}")
+    ratio = float(sr_new) / sr_orig
     count = int(samples.shape[0] * ratio)
-    if ratio == 1.0 or count == 0:
-        return np.array(samples[:count], copy=True)
-    out_dtype = samples.dtype if np.issubdtype(samples.dtype, np.floating) else np.float32
-    d_in = torch.from_numpy(np.ascontiguousarray(samples, dtype=np.float32)).cuda()
-    d_out = torch.empty((count,), dtype=torch.float32, device=d_in.device)
+    if count < 1:
+        raise ValueError(f"Input signal length={samples.shape[0]} is too small to resample from {sr_orig}->{sr_new}")
+    double_precision = samples.dtype == np.float64
+    dtype = np.float64 if double_precision else np.float32
+    d_in = torch.from_numpy(np.ascontiguousarray(samples, dtype=dtype)).cuda()
+    d_out = torch.empty((count,), dtype=d_in.dtype, device=d_in.device)
     hip_lib.resample_audio_device(
-        d_in.data_ptr(), int(d_in.shape[0]), sr_orig, sr_new, d_out.data_ptr(), count, torch.cuda.current_stream().cuda_stream
+        d_in.data_ptr(), int(d_in.shape[0]), sr_orig, sr_new, d_out.data_ptr(), count,
+        torch.cuda.current_stream().cuda_stream, double_precision=double_precision,
     )
-    return d_out.cpu().numpy().astype(out_dtype, copy=False)
+    return d_out.cpu().numpy()
 
 
 def _scale_wav_to_sample_rate(wav_file: WavFileProperties, new_sample_rate: float) -> WavFileProperties:

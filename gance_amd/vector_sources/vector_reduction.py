@@ -5,8 +5,8 @@ Same names and results as gance/vector_sources/vector_reduction.py for `track_le
 (:261-273), `rolling_sum_results_layers` (:243-258), `absolute_value_results_layers` (:227-240),
 `derive_results_layers` (:210-224) and `reduce_vector_gzip_compression_rolling_average`
 (:138-158), the chain projection_file_blend.py:192-217 builds the music-complexity skip mask
-from. `reduce_vector_rms_rolling_average` (:102-124) and `quantize_results_layers` (:161-194), the
-reductions that pick networks and roll amounts, run on the GPU (`gance_vec_*` of gance_amd/csrc/audio.hip:
+from. `reduce_vector_rms_rolling_average` (:102-124), `reduce_vector_rms_rolling_max` (:38-58) and
+`quantize_results_layers` (:161-194), the reductions that pick networks and roll amounts, run on the GPU (`gance_vec_*` of gance_amd/csrc/audio.hip:
 numpy's float32 pairwise RMS sums and pandas' rolling-mean update order are followed there, so the integers
 come out identical); the blend runs the same arithmetic fused.
 
@@ -79,6 +79,16 @@ def reduce_vector_rms_rolling_average(
         result=DataLabel(smoothed_average, f"Savgol Smoothing Filter (window={savgol_window_length}, polyorder={savgol_polyorder})"),
         layers=[DataLabel(rolling_average, f"Rolling Average (window={rolling_average_window})"), DataLabel(raw_rms, "Raw RMS Power")],
     )
+
+
+def reduce_vector_rms_rolling_max(time_series_audio_vectors: ConcatenatedVectors, vector_length: int) -> ResultLayers:
+    """
+    One RMS value per hop of audio (librosa.feature.rms, frame `vector_length`, hop 512, center=False), then a
+    rolling maximum over len // 80 values (scipy.ndimage.maximum_filter1d) when that is at least one value
+    (vector_reduction.py:38-58 -> :22-35). Same layers and labels as the reference.
+    """
+    raw_rms, output = hip_lib.vec_rms_rolling_max(time_series_audio_vectors, vector_length)
+    return ResultLayers(result=DataLabel(output, "Rolling Max"), layers=[DataLabel(raw_rms, "Raw RMS Power")])
 
 
 def quantize_results_layers(results_layers: ResultLayers, network_indices: List[int]) -> ResultLayers:

@@ -19,7 +19,7 @@
 extern "C" {
 #endif
 
-#define GANCE_ABI_VERSION 3
+#define GANCE_ABI_VERSION 4
 
 enum gance_status {
     GANCE_OK = 0,
@@ -233,6 +233,8 @@ int gance_blend_read_stage(gance_blend* blend, int32_t stage, void* h_out, uint6
  * gance_vec_rms_rolling_average   reduce_vector_rms_rolling_average (gance/vector_sources/vector_reduction.py:102-124):
  *                                 librosa RMS (hop 512) -> pandas rolling mean, NaN head = series mean -> savgol;
  *                                 num_values = 1 + (num_samples - vector_length) / 512 entries per output
+ * gance_vec_rms_rolling_max       reduce_vector_rms_rolling_max (:38-58): the same RMS, then scipy.ndimage.maximum_filter1d
+ *                                 of size num_values / 80 (mode "reflect") when that is > 0, else a copy (asynchronous)
  * gance_vec_quantize_f64          quantize_results_layers (:161-194): remap [min, max] -> [0, K - 1], np.rint (asynchronous)
  * gance_debug_fourier_resample_matrix  host only: the [in_length][out_length] operator the resample kernel applies */
 int gance_vec_savgol_f64(const double* d_in, int32_t num_vectors, int32_t vector_length, int32_t axis, int32_t window_length,
@@ -246,6 +248,8 @@ int gance_vec_remap_f64(const double* d_in, uint64_t count, double in_lo, double
 int gance_vec_rms_rolling_average(const float* d_audio, uint64_t num_samples, int32_t vector_length, int32_t rolling_window,
                                   int32_t savgol_window_length, int32_t savgol_polyorder, float* d_rms, double* d_rolling,
                                   double* d_smoothed, int32_t num_values, void* stream);
+int gance_vec_rms_rolling_max(const float* d_audio, uint64_t num_samples, int32_t vector_length, float* d_rms, float* d_out,
+                              int32_t num_values, void* stream);
 int gance_vec_quantize_f64(const double* d_in, int32_t count, int32_t num_indices, int64_t* d_out, void* stream);
 int gance_debug_fourier_resample_matrix(int32_t in_length, int32_t out_length, double* h_out);
 
@@ -300,13 +304,21 @@ int gance_overlay_boxes_u8(const uint8_t* d_foreground, const uint8_t* d_backgro
                            int32_t side, const int32_t* h_boxes, int32_t num_boxes, void* stream);
 
 /* ---- audio time-stretch ---------------------------------------------------------------------
- * Replaces resampy.resample(wav, sr_orig, sr_new) of _scale_wav_to_sample_rate
- * (gance/vector_sources/music.py:212-230) inside read_wavs_scale_for_video (:60-169): band-limited
- * (Kaiser-windowed sinc, 64 zero crossings) resampling of a mono float32 signal on the device.
- * num_out must equal (uint64_t)(num_in * sr_new / sr_orig), the reference's length rule
- * (test/test_vector_source_music.py:13-24). Asynchronous on `stream` after a short internal sync. */
+ * Replaces resampy.resample(wav, sr_orig, sr_new) (resampy 0.2.2, filter "kaiser_best") of
+ * _scale_wav_to_sample_rate (gance/vector_sources/music.py:212-230) inside read_wavs_scale_for_video
+ * (:60-169), restated operation for operation: the 32 769-entry Kaiser-windowed-sinc half window
+ * (64 zero crossings x 512 entries, beta 14.769656459379492, roll-off 0.9475937167399596), linear
+ * interpolation between table entries, the running-sum time register, left wing then right wing, and the
+ * accumulation in the signal's own dtype (one rounding to float32 per tap for a float32 signal). A ratio of
+ * exactly 1 still filters. num_out must equal (uint64_t)(num_in * sr_new / sr_orig), resampy's length rule
+ * (test/test_vector_source_music.py:13-24). Pinned by test/test_dynamic_model_switching.py:15-39 (claps.wav,
+ * RMS of the first vector = 0.00298562). Device pointers; returns after `stream` has drained. */
 int gance_resample_audio_f32(const float* d_in, uint64_t num_in, double sr_orig, double sr_new, float* d_out,
                              uint64_t num_out, void* stream);
+int gance_resample_audio_f64(const double* d_in, uint64_t num_in, double sr_orig, double sr_new, double* d_out,
+                             uint64_t num_out, void* stream);
+/* host only: the filter table the resampler interpolates (count must be 32769) */
+int gance_debug_resample_filter(double* h_out, uint64_t count);
 
 #ifdef __cplusplus
 }

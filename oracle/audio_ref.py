@@ -8,8 +8,8 @@ oracle/ref_stubs.py), and, when /root/reference is mounted, against the live ref
 
 Third-party leaves: scipy.signal.resample / savgol_filter, sklearn minmax_scale and pandas rolling
 mean are restated from their published algorithms (cited per function); librosa.feature.rms as in
-oracle/ref_stubs.py. resampy (music.py:222-227) is NOT restated: the parity entry point is the
-post-resample `time_series_audio_vectors` array (parity unpinned upstream of it).
+oracle/ref_stubs.py. resampy 0.2.2 (music.py:222-227; absent here) is restated from its published algorithm
+and pinned by the reference's known answer through it (test/test_dynamic_model_switching.py:15-39).
 
 Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.
 """
@@ -18,7 +18,8 @@ from typing import List, NamedTuple, Optional, Tuple
 
 import numpy as np
 import pandas as pd
-from scipy.ndimage import gaussian_filter
+import scipy.signal.windows
+from scipy.ndimage import gaussian_filter, maximum_filter1d
 from scipy.signal import resample, savgol_filter
 
 
@@ -350,47 +351,83 @@ def alpha_blend_vectors_max_rms_power_audio(
 
 
 # ----------------------------------------------------------------------------------------------
-# a2  time-stretch (music.py:212-230). resampy is absent and unpinned by any reference test: this is
-#     the numpy statement of THIS implementation's Kaiser-windowed-sinc design, the checker of the
-#     HIP kernel (gance_amd/csrc/resample.hip). PARITY UNPINNED against resampy.
+# a2  time-stretch (music.py:212-230 -> resampy.resample). resampy (pinned 0.2.2, requirements/prod.txt:25)
+#     is a third-party dependency that is NOT under /root/reference and is not installed here: its published
+#     algorithm (filters.sinc_window + core.resample + interpn.resample_f) is restated below, vectorised over
+#     output samples but with resampy's tap order and its per-tap rounding to the signal's dtype.
+#     Pinned by the reference's own known answer on this path (test/test_dynamic_model_switching.py:15-39:
+#     claps.wav, 60 fps, L = 1000 -> RMS of the first vector 0.00298562): tests/test_oracle_audio.py.
 # ----------------------------------------------------------------------------------------------
 SINC_ZERO_CROSSINGS = 64
+SINC_PRECISION = 9
 KAISER_BETA = 14.769656459379492
 ROLLOFF = 0.9475937167399596
 
 
+def kaiser_best_half_window() -> Tuple[np.ndarray, int]:
+    """
+    resampy.filters.sinc_window(num_zeros=64, precision=9, window=kaiser(beta), rolloff): the right wing of the
+    windowed sinc, 512 entries per zero crossing (the array resampy ships as data/kaiser_best.npz).
+    """
+    num_bits = 2**SINC_PRECISION
+    n = num_bits * SINC_ZERO_CROSSINGS
+    sinc_win = ROLLOFF * np.sinc(ROLLOFF * np.linspace(0, SINC_ZERO_CROSSINGS, num=n + 1, endpoint=True))
+    taper = scipy.signal.windows.kaiser(2 * n + 1, KAISER_BETA)[n:]
+    return taper * sinc_win, num_bits
+
+
 def resample_audio(samples: np.ndarray, sr_orig: float, sr_new: float) -> np.ndarray:
     """
-    Band-limited resampling by a Kaiser-windowed sinc (64 zero crossings, beta 14.77, roll-off
-    0.9476: the published kaiser_best design). Output length int(len(samples) * sr_new / sr_orig).
+    resampy.resample(samples, sr_orig, sr_new, filter="kaiser_best") of a 1-D signal: output length
+    int(len * ratio) in the input's dtype; interp_win scaled by the ratio when down-sampling; per output sample the
+    running-sum time register, left wing then right wing, linear interpolation between table entries, and
+    `y[t] += weight * x[...]` rounded to y's dtype after every tap (resample_f).
     """
-    ratio = float(sr_new) / float(sr_orig)
-    if ratio <= 0:
-        raise ValueError("sample rates must be positive")
-    count = int(samples.shape[0] * ratio)
-    if ratio == 1.0:
-        return np.array(samples[:count], copy=True)
-    x = np.asarray(samples, dtype=np.float64)
-    # resampy's published design (`sinc_window`, `resample_f`): with x = (position - index) * min(1, ratio),
-    # weight = rolloff * sinc(rolloff * x) * kaiser(x / crossings) * min(1, ratio) for |x| < crossings; the roll-off
-    # narrows the sinc only, the taper spans the un-scaled 64 zero crossings
-    scale = min(1.0, ratio)
-    half_width = int(np.ceil(SINC_ZERO_CROSSINGS / scale))
-    out = np.empty(count, dtype=np.float64)
-    taps = np.arange(-half_width, half_width + 1)
-    for start in range(0, count, 16384):  # bounded working set: chunk x taps
-        positions = np.arange(start, min(count, start + 16384)) / ratio
-        centre = np.floor(positions).astype(np.int64)
-        index = centre[:, None] + taps[None, :]
-        offset = (positions[:, None] - index) * scale
-        window_arg = offset / SINC_ZERO_CROSSINGS
-        inside = np.abs(window_arg) < 1.0
-        kaiser = np.i0(KAISER_BETA * np.sqrt(np.clip(1.0 - window_arg * window_arg, 0.0, None))) / np.i0(KAISER_BETA)
-        kernel = np.where(inside, np.sinc(ROLLOFF * offset) * kaiser, 0.0) * (ROLLOFF * scale)
-        valid = (index >= 0) & (index < len(x))
-        out[start : start + len(positions)] = np.sum(np.where(valid, x[np.clip(index, 0, len(x) - 1)], 0.0) * kernel, axis=1)
-    return out.astype(samples.dtype if np.issubdtype(samples.dtype, np.floating) else np.float32)
+    if sr_orig <= 0 or sr_new <= 0:
+        raise ValueError("Invalid sample rate")
+    x = np.asarray(samples)
+    if not np.issubdtype(x.dtype, np.floating):
+        x = x.astype(np.float32)
+    sample_ratio = float(sr_new) / sr_orig
+    n_out = int(x.shape[0] * sample_ratio)
+    if n_out < 1:
+        raise ValueError("Input signal length is too small to resample")
+    interp_win, num_table = kaiser_best_half_window()
+    if sample_ratio < 1:
+        interp_win = interp_win * sample_ratio
+    interp_delta = np.zeros_like(interp_win)
+    interp_delta[:-1] = np.diff(interp_win)
+    scale = min(1.0, sample_ratio)
+    time_increment = 1.0 / sample_ratio
+    index_step = int(scale * num_table)
+    # time_register += time_increment per output sample (np.cumsum adds sequentially, like the loop)
+    time_register = np.concatenate([[0.0], np.cumsum(np.full(n_out - 1, time_increment))])
+    n = time_register.astype(np.int64)
+    nwin, n_orig = interp_win.shape[0], x.shape[0]
+    y = np.zeros(n_out, dtype=x.dtype)
 
+    def wing(frac: np.ndarray, limit: np.ndarray, sign: int, first: int) -> None:
+        index_frac = frac * num_table
+        offset = index_frac.astype(np.int64)
+        eta = index_frac - offset
+        count = np.minimum(limit, (nwin - offset) // index_step)
+        for i in range(int(count.max(initial=0))):
+            live = i < count
+            index = offset[live] + i * index_step
+            weight = interp_win[index] + eta[live] * interp_delta[index]
+            y[live] = (y[live].astype(np.float64) + weight * x[n[live] + sign * i + first].astype(np.float64)).astype(x.dtype)
+
+    frac = scale * (time_register - n)
+    wing(frac, n + 1, -1, 0)  # x[n - i]
+    wing(scale - frac, n_orig - n - 1, +1, 1)  # x[n + k + 1]
+    return y
+
+
+def reduce_vector_rms_rolling_max(audio: np.ndarray, vector_length: int) -> Tuple[np.ndarray, np.ndarray]:
+    """vector_reduction.py:38-58: raw RMS (hop 512) and its maximum_filter1d over len // 80 values (or itself)."""
+    raw = compute_raw_rms(audio, vector_length)
+    feature_length = int(len(raw) / 80)
+    return raw, (maximum_filter1d(input=raw, size=feature_length) if feature_length > 0 else raw)
 
 
 def sub_vectors(data: np.ndarray, vector_length: int) -> np.ndarray:

@@ -14,12 +14,33 @@ from gance_amd.vector_sources import music
 from oracle import audio_ref
 
 
-def test_resampler_oracle_preserves_a_tone_and_is_identity_at_ratio_one() -> None:
+def test_resampler_oracle_reproduces_the_reference_known_answer(golden_dir) -> None:
+    """
+    test/test_dynamic_model_switching.py:15-39 through the ORACLE: claps.wav (the reference's own test asset,
+    44.1 kHz int16) -> read_wavs_scale_for_video(vector_length=1000, frames_per_second=60) -> first vector ->
+    reduce_vector_rms_rolling_max -> 0.00298562 at np.isclose's defaults. This is the one number the reference
+    holds on the resampy path; it pins the restatement of resampy in oracle/audio_ref.py.
+    """
+    wav = music.read_wav_file(golden_dir / "claps.wav")
+    assert wav.sample_rate == 44100 and wav.wav_data.shape == (73728,)
+    samples = wav.wav_data.shape[0]
+    new_rate = int(wav.sample_rate * (1000 * (60.0 * (samples / wav.sample_rate))) / samples)  # music.py:127-132
+    assert new_rate == 60000
+    scaled = audio_ref.resample_audio(wav.wav_data, wav.sample_rate, new_rate)
+    assert scaled.dtype == np.float32 and scaled.shape == (int(samples * (60000 / 44100)),)
+    raw, reduced = audio_ref.reduce_vector_rms_rolling_max(scaled[:1000], 1000)
+    assert reduced.shape == (1,) and reduced.dtype == np.float32
+    assert np.isclose(0.00298562, reduced[0])
+
+
+def test_resampler_oracle_preserves_a_tone_and_filters_at_ratio_one() -> None:
     rate, tone = 8000, 440.0
     t = np.arange(8000) / rate
     x = np.sin(2 * np.pi * tone * t).astype(np.float32)
-    assert np.array_equal(audio_ref.resample_audio(x, rate, rate), x)
-    assert np.array_equal(music.resample_audio(x, rate, rate), x)  # ratio 1 never reaches the GPU
+    # resampy at ratio 1 is a pass through its low-pass filter (roll-off 0.9476), not a copy
+    same_rate = audio_ref.resample_audio(x, rate, rate)
+    assert same_rate.shape == x.shape and same_rate.dtype == np.float32 and not np.array_equal(same_rate, x)
+    assert np.abs(same_rate[200:-200] - x[200:-200]).max() < 2e-3
     for new_rate in (12000, 5000):
         y = audio_ref.resample_audio(x, rate, new_rate)
         assert len(y) == int(len(x) * new_rate / rate)
@@ -29,6 +50,26 @@ def test_resampler_oracle_preserves_a_tone_and_is_identity_at_ratio_one() -> Non
     # a tone above the new Nyquist is removed, not aliased
     high = np.sin(2 * np.pi * 3500.0 * t).astype(np.float32)
     assert np.abs(audio_ref.resample_audio(high, rate, 4000)[100:-100]).max() < 5e-3
+    # float64 signals are accumulated in float64 (y takes x's dtype)
+    assert audio_ref.resample_audio(x.astype(np.float64), rate, 12000).dtype == np.float64
+    with pytest.raises(ValueError):
+        audio_ref.resample_audio(x[:3], 8000, 1000)  # int(3 / 8) = 0 output samples
+
+
+def test_resampler_filter_table_is_the_published_kaiser_best_window() -> None:
+    """
+    The table libgance_hip builds on the host (Cephes I0, libm sin) against resampy's recipe evaluated with
+    numpy / scipy (sinc_window(64, 9, kaiser(14.7697), 0.9476)): 32 769 entries, identical to the last bit here,
+    bar 4 ulp (library exp / sin may differ by an ulp between builds). No GPU involved.
+    """
+    from gance_amd import hip_lib  # pylint: disable=import-outside-toplevel
+
+    table = hip_lib.resample_filter_table()
+    want, num_table = audio_ref.kaiser_best_half_window()
+    assert num_table == 512 and table.shape == want.shape == (64 * 512 + 1,)
+    assert table[0] == audio_ref.ROLLOFF and abs(table[-1]) < 1e-7  # the Kaiser taper ends at 1 / I0(beta), not at zero
+    ulps = np.abs(table.view(np.int64) - want.view(np.int64))
+    assert ulps[np.abs(want) > 1e-300].max() <= 4
 
 
 def _write(path: Path, rate: int, data: np.ndarray) -> Path:
@@ -51,16 +92,18 @@ def test_read_wav_file_remaps_integers_to_unit_floats(tmp_path: Path) -> None:
         music.read_wav_file(_write(tmp_path / "e.wav", 8000, np.zeros(4, dtype=np.uint8)))
 
 
-def test_scale_for_video_modes_padding_mono_and_errors(tmp_path: Path) -> None:
+def test_scale_for_video_modes_padding_mono_and_errors(tmp_path: Path, monkeypatch) -> None:
+    # host logic only: the resampling kernel (tests/test_music_gpu.py) is stood in for by its oracle
+    monkeypatch.setattr(music, "resample_audio", audio_ref.resample_audio)
     L, rate = 512, 30720
     stereo = np.stack([np.full(rate, 8192, dtype=np.int16), np.full(rate, -8192, dtype=np.int16)], axis=1)
     mono = (np.sin(np.arange(rate) / 20.0) * 20000).astype(np.int16)
     paths = [_write(tmp_path / "s.wav", rate, stereo), _write(tmp_path / "m.wav", rate, mono)]
-    # 2 s at 60 fps and L * fps == rate: exactly 120 vectors, untouched samples
+    # 2 s at 60 fps and L * fps == rate: exactly 120 vectors (ratio 1: filtered, not copied)
     by_fps = music.read_wavs_scale_for_video(paths, L, frames_per_second=60.0)
     assert by_fps.wav_data.shape == (120 * L,) and by_fps.sample_rate == rate and by_fps.name == "s_m_mono_scaled_padded"
-    np.testing.assert_allclose(by_fps.wav_data[:rate], 0.0, atol=2e-5)  # stereo halves cancel in the mono mix
-    by_count = music.read_wavs_scale_for_video(paths, L, target_num_vectors=120)  # still the identity stretch
+    np.testing.assert_allclose(by_fps.wav_data[: rate - 200], 0.0, atol=2e-5)  # stereo halves cancel in the mono mix (the filter rings at the seam)
+    by_count = music.read_wavs_scale_for_video(paths, L, target_num_vectors=120)  # the same ratio of 1
     assert by_count.wav_data.shape == (120 * L,) and np.array_equal(by_count.wav_data, by_fps.wav_data)
     unpadded = music.read_wavs_scale_for_video(paths[1:], L, target_num_vectors=60, pad_to_length=False)
     assert len(unpadded.wav_data) == 60 * L

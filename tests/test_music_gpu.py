@@ -1,8 +1,10 @@
 """
-GPU tests of the audio time-stretch (gance_resample_audio_f32 through the C ABI) against its CPU
-oracle (oracle/audio_ref.resample_audio, float64 numpy) and the reference's own length rule
-(test/test_vector_source_music.py:13-24). Bar: 2e-6 absolute on [-1, 1] audio (float32 output of
-float64 sums; the kernel and numpy evaluate sin / I0 with different library routines).
+GPU tests of the audio time-stretch (gance_resample_audio_f32 / _f64 through the C ABI) against its CPU
+oracle (oracle/audio_ref.resample_audio: resampy 0.2.2's kaiser_best algorithm restated in numpy), the
+reference's own length rule (test/test_vector_source_music.py:13-24) and the reference's own known answer
+through the resampler (test/test_dynamic_model_switching.py:15-39). Bar: BIT-EXACT — the kernel follows
+resampy's tap order and its per-tap rounding to the signal's dtype, and its filter table is identical to
+numpy's (tests/test_music.py).
 """
 
 from pathlib import Path
@@ -17,7 +19,7 @@ from oracle import audio_ref
 
 pytestmark = pytest.mark.gpu
 
-RESAMPLE_ATOL = 2e-6
+RESAMPLE_ATOL = 0.0  # same operations in the same order on the same table
 
 
 @pytest.mark.parametrize("multiplier", [2, 1.5, 0.3, 0.1, 10])
@@ -44,15 +46,67 @@ def test_resampler_matches_oracle_on_a_long_signal_and_preserves_a_tone() -> Non
     assert np.abs(y[inner] - np.sin(2 * np.pi * 440.0 * np.arange(len(y)) / 12000)[inner]).max() < 2e-3
 
 
+def test_reduce_vector_rms_alignment_known_answer_of_the_reference(golden_dir) -> None:
+    """
+    test/test_dynamic_model_switching.py:15-39 reproduced call for call on the product path (claps.wav is that
+    test's own asset): WAV -> read_wavs_scale_for_video (resampler on the GPU, 44.1 kHz -> 60 kHz) -> first vector
+    of 1000 samples -> reduce_vector_rms_rolling_max (RMS kernel) -> 0.00298562 at np.isclose's defaults.
+    """
+    from gance_amd.vector_sources.vector_reduction import reduce_vector_rms_rolling_max  # pylint: disable=import-outside-toplevel
+    from gance_amd.vector_sources.vector_sources_common import sub_vectors  # pylint: disable=import-outside-toplevel
+
+    vector_length = 1000
+    audio = music.read_wavs_scale_for_video(
+        wavs=[golden_dir / "claps.wav"], vector_length=vector_length, frames_per_second=60.0
+    ).wav_data
+    assert audio.dtype == np.float32 and audio.shape == (101000,)  # 100 310 samples padded to whole vectors
+    single_audio_vector = sub_vectors(data=audio, vector_length=vector_length)[0]
+    reduced = reduce_vector_rms_rolling_max(time_series_audio_vectors=single_audio_vector, vector_length=vector_length)
+    assert reduced.result.data.shape[0] == 1
+    # Known value.
+    assert np.isclose(0.00298562, reduced.result.data[0])
+    assert reduced.result.label == "Rolling Max" and reduced.layers[0].label == "Raw RMS Power"
+    # and sample for sample the oracle's restatement of resampy
+    wav = music.read_wav_file(golden_dir / "claps.wav")
+    want = audio_ref.resample_audio(wav.wav_data, wav.sample_rate, 60000)
+    assert np.array_equal(audio[: len(want)], want) and not audio[len(want) :].any()
+
+
+def test_rms_rolling_max_matches_oracle_on_a_long_series() -> None:
+    """Frames of 1000 samples every 512 (librosa's fixed hop), 200 values: a rolling maximum over two values."""
+    from gance_amd.vector_sources.vector_reduction import reduce_vector_rms_rolling_max  # pylint: disable=import-outside-toplevel
+
+    audio = synthetic.synthetic_audio(201, 512, seed=5)
+    for vector_length in (1000, 512):
+        got = reduce_vector_rms_rolling_max(audio, vector_length)
+        raw, want = audio_ref.reduce_vector_rms_rolling_max(audio, vector_length)
+        assert len(raw) == 1 + (len(audio) - vector_length) // 512 and len(raw) // 80 == 2
+        assert got.layers[0].data.dtype == np.float32 and np.array_equal(got.layers[0].data, raw)
+        assert np.array_equal(got.result.data, want)
+
+
+def test_resampler_accumulates_float64_signals_in_float64() -> None:
+    x = synthetic.synthetic_audio(40, 512, seed=9).astype(np.float64)
+    for new_rate in (30720, 48000):
+        got = music.resample_audio(x, 44100, new_rate)
+        want = audio_ref.resample_audio(x, 44100, new_rate)
+        assert got.dtype == np.float64 and np.array_equal(got, want)
+    # ratio 1: still the low-pass filter
+    same = music.resample_audio(x.astype(np.float32), 30720, 30720)
+    assert np.array_equal(same, audio_ref.resample_audio(x.astype(np.float32), 30720, 30720)) and not np.array_equal(same, x)
+
+
 def test_resampler_rejects_a_wrong_output_length() -> None:
     import torch  # pylint: disable=import-outside-toplevel
 
     d_in = torch.zeros(1000, dtype=torch.float32, device="cuda")
     d_out = torch.zeros(1500, dtype=torch.float32, device="cuda")
-    with pytest.raises(hip_lib.GanceHipError, match="num_out"):
+    with pytest.raises(ValueError, match="num_out"):
         hip_lib.resample_audio_device(d_in.data_ptr(), 1000, 8000, 12000, d_out.data_ptr(), 1499)
-    with pytest.raises(hip_lib.GanceHipError):
+    with pytest.raises(ValueError, match="Invalid sample rate"):
         hip_lib.resample_audio_device(d_in.data_ptr(), 1000, 0, 12000, d_out.data_ptr(), 1500)
+    with pytest.raises(ValueError, match="too small"):
+        music.resample_audio(np.zeros(3, dtype=np.float32), 8000, 1000)
 
 
 def test_scale_for_video_stretches_to_the_requested_vector_count(tmp_path: Path) -> None:

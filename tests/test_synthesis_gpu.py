@@ -198,9 +198,10 @@ def test_matrix_path_512_both_upsampling_forms(library, up_form: str) -> None:
 @pytest.mark.parametrize("conv_form,up_form", [("auto", "auto"), ("direct", "split"), ("auto", "fused")])
 def test_config_f_1024_every_term_on_default_kernels(library, conv_form: str, up_form: str) -> None:
     """
-    1024^2 with non-zero noise strengths and biases through the kernels that ship by default: the last
-    conv in direct form fused with its ToRGB + uint8 (conv_mfma.hip emit_rgb, reached only at Cout = 32 =
-    1024^2), with and without Winograd / the fused up kernel on the layers below.
+    1024^2 with non-zero noise strengths and biases, one frame per call: at this batch the last conv runs in
+    direct form fused with its ToRGB + uint8 (conv_mfma.hip emit_rgb, reached only at Cout = 32 = 1024^2; at the
+    batches that fill the chip the default is the Winograd form with the ToRGB product, covered by
+    test_bench_configuration_batch_64...), with and without Winograd / the fused up kernel on the layers below.
     """
     resolution = 1024
     variables = sg2_spec.make_random_variables(resolution, seed=0, perturb=True)
@@ -213,22 +214,28 @@ def test_config_f_1024_every_term_on_default_kernels(library, conv_form: str, up
     _check_frames(frames, image, ref.synthesize_z(z, variables, resolution, truncation_psi=1.2))
 
 
-def test_bench_configuration_batch_64_matches_oracle_and_single_calls(library) -> None:
+@pytest.mark.parametrize("perturb", [True, False])
+def test_bench_configuration_batch_64_matches_oracle_and_single_calls(library, perturb: bool) -> None:
     """
     The configuration bench.py times (1024^2, 64 frames per call, auto kernel selection: Winograd layers,
-    fused up kernels, fused last layer): first and last frame against the oracle, and against the same z alone.
+    fused up kernels, fused last layer): first and last frame against the oracle, those and the two frames either
+    side of the middle of the batch (31, 32) against the same z alone. `perturb=False` is the network bench.py
+    builds (StyleGAN2's own init: noise strengths and biases zero, so the kernels take their no-noise branches);
+    `perturb=True` switches every term on.
     """
     resolution, batch = 1024, 64
-    variables = sg2_spec.make_random_variables(resolution, seed=0, perturb=True)
+    variables = sg2_spec.make_random_variables(resolution, seed=0, perturb=perturb)
     z = np.random.RandomState(1).randn(batch, 512).astype(np.float32)
     engine = hip_lib.Engine(variables, resolution, max_batch=batch)
+    picks = (0, batch // 2 - 1, batch // 2, batch - 1)
     try:
         frames, image = engine.synthesize_z(z, truncation_psi=1.2, want_float=True)
-        alone = [engine.synthesize_z(z[i : i + 1], truncation_psi=1.2) for i in (0, batch - 1)]
+        alone = [engine.synthesize_z(z[i : i + 1], truncation_psi=1.2) for i in picks]
     finally:
         engine.close()
-    for k, i in enumerate((0, batch - 1)):
-        _check_frames(frames[i : i + 1], image[i : i + 1], ref.synthesize_z(z[i : i + 1], variables, resolution, truncation_psi=1.2))
+    for k, i in enumerate(picks):
+        if i in (0, batch - 1):
+            _check_frames(frames[i : i + 1], image[i : i + 1], ref.synthesize_z(z[i : i + 1], variables, resolution, truncation_psi=1.2))
         _assert_same_frames(alone[k][0], frames[i])
 
 
@@ -295,19 +302,24 @@ res = int(sys.argv[1])
 spec = sg2_spec.make_spec(res)
 variables = sg2_spec.make_random_variables(res, seed=3, perturb=True)
 dlatents = np.random.RandomState(5).randn(2, spec.num_layers, 512).astype(np.float32)
-engine = hip_lib.Engine(variables, res, max_batch=2, conv_form="winograd")
+engine = hip_lib.Engine(variables, res, max_batch=2, conv_form="winograd", up_form=sys.argv[3])
 frames, image = engine.synthesize_w(dlatents, want_float=True)
 np.savez(sys.argv[2], frames=frames, image=image)
 """
 
 
-@pytest.mark.parametrize("variable,off_value", [("GANCE_TUNE_W64_RGB", "0"), ("GANCE_TUNE_WINO64", "0"), ("GANCE_TUNE_PRESCALE_UP", "0")])
-def test_winograd_kernel_fallback_forms_agree_with_the_default(library, tmp_path, variable: str, off_value: str) -> None:
+@pytest.mark.parametrize(
+    "variable,off_value,up_form",
+    [("GANCE_TUNE_W64_RGB", "0", "auto"), ("GANCE_TUNE_W64_RGB", "0", "fused"), ("GANCE_TUNE_WINO64", "0", "auto"), ("GANCE_TUNE_PRESCALE_UP", "0", "fused")],
+)
+def test_winograd_kernel_fallback_forms_agree_with_the_default(library, tmp_path, variable: str, off_value: str, up_form: str) -> None:
     """
     The tuning switches read once per process select kernels the default path no longer runs (the
     Winograd kernel without the ToRGB product in its epilogue; the round-1 32-channel Winograd kernel; the
     fused up kernel with the style scale in its own K loop instead of on its producer's stores):
-    each in its own process, same network and latents, against the default form.
+    each in its own process, same network and latents, against the default form. `up_form="fused"` forces the fused
+    up kernel at this small batch: with it, a Winograd launch WITHOUT the ToRGB product must not scale its stores by the
+    next layer's style (torgb_kernel reads them), and the fused up kernel must then scale in its own K loop.
     """
     import os
     import subprocess
@@ -319,7 +331,7 @@ def test_winograd_kernel_fallback_forms_agree_with_the_default(library, tmp_path
     for label, env_extra in (("default", {}), ("switched", {variable: off_value})):
         path = tmp_path / f"{label}.npz"
         env = dict(os.environ, PYTHONPATH=str(repo_root), **env_extra)
-        subprocess.run([sys.executable, "-c", _FORM_SCRIPT, "256", str(path)], check=True, env=env, cwd=repo_root, timeout=300)
+        subprocess.run([sys.executable, "-c", _FORM_SCRIPT, "256", str(path), up_form], check=True, env=env, cwd=repo_root, timeout=300)
         outputs[label] = np.load(path)
     scale = float(np.abs(outputs["default"]["image"]).max())
     assert float(np.abs(outputs["switched"]["image"] - outputs["default"]["image"]).max()) < 5e-5 * max(1.0, scale)
