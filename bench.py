@@ -37,6 +37,10 @@ sys.path.insert(0, str(REPO_ROOT))
 from gance_amd import frame_sharding, hip_lib  # noqa: E402
 from gance_amd.stylegan2 import spec as sg2_spec  # noqa: E402
 
+import datetime  # noqa: E402
+
+# a rank that dies must not leave the others in a collective for ever (default: 10 minutes for RCCL, 30 for gloo)
+PROCESS_GROUP_TIMEOUT = datetime.timedelta(seconds=int(os.environ.get("GANCE_PROCESS_GROUP_TIMEOUT_S", "180")))
 FP32_MFMA_PEAK_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
 HBM_PEAK_GBS = 8000.0
 ALGORITHMIC_GFLOP_PER_FRAME_1024 = 148.5
@@ -56,6 +60,8 @@ def usable_cores() -> int:
 
 def kernel_of_step(step_name: str) -> str:
     """The HIP kernel behind a conv launch of the engine's step table (names: engine.hip)."""
+    if step_name.startswith("convTFp"):
+        return "upfir_fused_pre_kernel"  # input pre-scaled by the Winograd launch before it
     if step_name.startswith("convTF"):
         return "upfir_fused_kernel"
     if step_name.startswith("convW"):
@@ -71,24 +77,38 @@ def executed_fraction(step_name: str) -> float:
     return 4.0 / 9.0 if step_name.startswith("convW") else 1.0
 
 
+def kernel_sources_digest() -> str:
+    """sha256 over the HIP sources: a traffic record taken on other kernels is reported as stale."""
+    import hashlib  # pylint: disable=import-outside-toplevel
+
+    digest = hashlib.sha256()
+    for path in sorted((REPO_ROOT / "gance_amd" / "csrc").glob("*.hip")) + [REPO_ROOT / "gance_amd" / "csrc" / "kernels.h"]:
+        digest.update(path.read_bytes())
+    return digest.hexdigest()[:16]
+
+
 def measured_traffic(step_name: str, resolution: int, batch: int):
     """
     HBM bytes per launch of the dominant kernel from the committed PMC pass (rocprofv3 cannot run
-    inside this process): profiles/traffic_latest.json, only if it was taken on this workload and
-    holds this launch (the two largest launches trade places from run to run: both are recorded).
+    inside this process): profiles/traffic_latest.json, written by tools/make_traffic_record.py from the
+    round's --pmc CSVs; only if it was taken on this workload and holds this launch (the two largest launches
+    trade places from run to run: both are recorded). Returns (bytes or None, note).
     """
     path = REPO_ROOT / "profiles" / "traffic_latest.json"
     try:
         record = json.loads(path.read_text())
     except (OSError, ValueError):
-        return None
+        return None, "no profiles/traffic_latest.json"
     workload = record.get("workload", {})
     if workload.get("resolution") != resolution or workload.get("frames_per_step_per_gpu") != batch:
-        return None
+        return None, "profiles/traffic_latest.json was taken on another workload"
+    stale = record.get("kernel_sources_digest") not in (None, kernel_sources_digest())
+    lookup = step_name.replace("convTFp", "convTF", 1)  # (the record keys both forms of the fused up kernel as convTF)
     for prefix, entry in record.get("launches", {}).items():
-        if step_name.startswith(prefix):
-            return entry.get("hbm_bytes_per_launch")
-    return None
+        if lookup.startswith(prefix):
+            note = "from %s" % record.get("source", "profiles/traffic_latest.json")
+            return entry.get("hbm_bytes_per_launch"), note + (" -- STALE: the kernels changed since that PMC pass" if stale else "")
+    return None, "profiles/traffic_latest.json does not hold this launch"
 
 
 def cpu_baseline(resolution: int, variables, budget_seconds: float = 15.0) -> dict:
@@ -119,74 +139,120 @@ def cpu_baseline(resolution: int, variables, budget_seconds: float = 15.0) -> di
     }
 
 
-def blend_measurement(resolution: int, batch: int, num_networks: int, output_side, device, with_cpu_baseline: bool) -> dict:
+class SyntheticFaceFinder:  # pylint: disable=too-few-public-methods
     """
-    BASELINE.json configs[2] on one GPU: 30 s synthetic WAV (30 720 Hz) + 900 projected latents
-    -> spectrogram, fft-roll, alpha blend (alpha 0.25, amplitude +-5, depth 12) -> 1800 frames at
-    1024^2, frames left in HBM. Timed: host audio array -> last uint8 frame in HBM. With `num_networks` > 1 the
-    RMS-driven index switches between resident networks (configs[4] without the overlay); `output_side` adds
-    the bicubic resize in HBM (configs[3] on one GPU).
+    Stand-in for the landmark detector of the overlay gate (face_recognition / dlib is external and absent: SURVEY.md
+    §8 f-4 has the benchmark feed synthetic boxes): every picture whose top-left pixel is bright enough "has a face"
+    with the same two eye boxes. Costs what a table look-up costs; the gate's GPU work (phash of both eye regions,
+    the overlay write) and the run-length filter are the real ones.
     """
-    from types import SimpleNamespace  # pylint: disable=import-outside-toplevel
 
-    from gance_amd import projection_file_blend, synthetic  # pylint: disable=import-outside-toplevel
-    from gance_amd.data_into_network_visualization import visualization_inputs  # pylint: disable=import-outside-toplevel
+    def __init__(self, side: int) -> None:
+        scale = side / 128.0
+        self._landmarks = [{
+            "left_eye": ((int(30 * scale), int(40 * scale)), (int(50 * scale), int(52 * scale))),
+            "right_eye": ((int(70 * scale), int(41 * scale)), (int(95 * scale), int(55 * scale))),
+        }]
 
-    num_frames = 1800
-    engines = [
-        hip_lib.Engine(sg2_spec.make_random_variables(resolution, seed=seed), resolution, max_batch=batch, device=device.index, profile=True)
-        for seed in range(num_networks)
-    ]
-    # the network's last conv launch, whatever form the engine runs it in (names: engine.hip)
-    last_conv_pattern = re.compile(r"^conv[A-Z]*%d[+_].*_%dx%d_" % (2 * int(np.log2(resolution)) - 4, resolution, resolution))
-    audio, latents = synthetic.benchmark_blend_inputs(num_frames)
-    frames = torch.empty((batch, resolution, resolution, 3), dtype=torch.uint8, device=device)
-    stream = torch.cuda.current_stream(device)
-    rows = engines[0].num_layers
-    # what synthesize_device_frames_network_major needs of a MultiNetwork
-    resident = SimpleNamespace(_network_at=lambda index: SimpleNamespace(engine=engines[index]))
-    switches = 0
+    def face_landmarks(self, face_image):
+        """One face, unless the picture's first pixel is dark."""
+        return self._landmarks if int(face_image[0, 0].sum()) >= 96 else []
 
-    def run_once():
-        nonlocal switches
-        t0 = time.perf_counter()
-        blend = visualization_inputs.alpha_blend_projection_file_device(
-            latents, 0.25, True, (-5, 5), 12, audio, 512, num_networks, device=device.index
+
+def product_stream_measurement(  # pylint: disable=too-many-arguments,too-many-locals,too-many-statements
+    label: str, resolution: int, batch: int, num_networks: int, output_side, device, with_cpu_baseline: bool, overlay: bool = False
+) -> dict:
+    """
+    BASELINE.json configs[2] / [3] / [4] on one GPU THROUGH THE PRODUCT: a 30 s synthetic WAV and a projection file of
+    900 projected latents ON DISK -> `projection_file_blend_frame_chunks` (read + stretch the WAV, audio -> latents on
+    the GPU, chunked synthesis with resident networks, optional bicubic resize / overlay gate in HBM, ordered chunks
+    drained to the pinned host ring) -> every chunk consumed on the host. Timed: the call -> the last uint8 frame on
+    the host; the networks are resident before the call (the reference loads them before
+    its frame loop too, projection_file_blend.py:122). A first, short run warms the process (operator tables,
+    kernel attributes, pinned ring) and names the last conv launch; the second, full run is the one reported.
+    """
+    import tempfile  # pylint: disable=import-outside-toplevel
+
+    from scipy.io import wavfile  # pylint: disable=import-outside-toplevel
+
+    from gance_amd import network_file, projection_file_blend, synthetic  # pylint: disable=import-outside-toplevel
+    from gance_amd.network_interface.network_functions import MultiNetwork  # pylint: disable=import-outside-toplevel
+    from gance_amd.projection import projection_file_reader as pfr  # pylint: disable=import-outside-toplevel
+
+    num_frames, vector_length, fps_in, fps_out = 1800, 512, 30.0, 60.0
+    side = output_side or resolution
+    with tempfile.TemporaryDirectory(prefix="gance_bench_") as directory:
+        directory = Path(directory)
+        audio, latents = synthetic.benchmark_blend_inputs(num_frames)
+        wav_path = directory / "audio.wav"
+        wavfile.write(str(wav_path), int(vector_length * fps_out), audio)
+        targets = None
+        if overlay:  # target frames of the projection: blocky pictures at 128^2, the gate scales them to the output side
+            rng = np.random.RandomState(73)
+            targets = (np.kron(rng.rand(num_frames // 2, 8, 8, 3), np.ones((1, 16, 16, 1))) * 255).astype(np.uint8)
+        projection_path = directory / "projection.npz"
+        pfr.write_projection_npz(
+            projection_path, latents.reshape(18, num_frames // 2, vector_length).transpose(1, 0, 2), projection_fps=fps_in, target_images=targets
         )
-        torch.cuda.synchronize(device)
-        t1 = time.perf_counter()
-        if num_networks == 1 and output_side is None:
-            dlat = blend.dlatents[:, :rows, :].contiguous()
-            for start in range(0, num_frames, batch):
-                count = min(batch, num_frames - start)
-                engines[0].synthesize_w_device(dlat[start : start + count].data_ptr(), count, frames.data_ptr(), 0, stream.cuda_stream)
-        else:  # the RMS-driven index switches networks; every network is resident, frames come back in order
-            ordered = projection_file_blend.synthesize_device_frames_network_major(
-                blend.dlatents, blend.network_indices, resident, output_side, batch
-            )
-            assert ordered.shape[0] == num_frames
-            chosen = blend.network_indices.cpu().numpy()
-            switches = int((chosen[1:] != chosen[:-1]).sum())
-        torch.cuda.synchronize(device)
-        t2 = time.perf_counter()
-        blend.blend.close()
-        return t1 - t0, t2 - t1
+        network_paths = []
+        for seed in range(num_networks):
+            network_paths.append(directory / f"net_{seed}.pkl")
+            network_file.write_random_network(network_paths[-1], resolution, seed=seed)
+        networks = MultiNetwork(network_paths=network_paths, load=True, max_batch=batch)
+        engines = [networks._network_at(index).engine for index in range(num_networks)]  # pylint: disable=protected-access
+        overlay_parameters = (
+            projection_file_blend.OverlayParameters(phash_distance=64, bbox_distance=5.0, track_length=5, face_finder=SyntheticFaceFinder(side))
+            if overlay
+            else None
+        )
+        last_conv_pattern = re.compile(r"^conv[A-Z]*%d[+_].*_%dx%d_" % (2 * int(np.log2(resolution)) - 4, resolution, resolution))
 
-    run_once()  # warm-up (LDS attribute setup, allocator), every launch bracketed: it names the last conv launch
-    last_conv = next((s.name for s in engines[0].steps() if last_conv_pattern.match(s.name)), "conv")
-    for engine in engines:
-        engine.set_profiling(True, only_step=last_conv)
-    audio_s, synth_s = run_once()
-    timed = [s for engine in engines for s in engine.steps() if s.name.startswith(last_conv)]
+        def run(frames_to_visualize, timings):
+            start = time.perf_counter()
+            checksum, chunks, last_index = 0, 0, -1
+            for first, _total, frames in projection_file_blend.projection_file_blend_frame_chunks(
+                wav=[str(wav_path)], network_paths=network_paths, frames_to_visualize=frames_to_visualize, output_fps=fps_out,
+                output_side_length=side, alpha=0.25, fft_roll_enabled=True, fft_amplitude_range=(-5, 5),
+                projection_file_path=str(projection_path), blend_depth=12, frames_per_call=batch, overlay=overlay_parameters,
+                networks=networks, timings=timings,
+            ):
+                assert first == last_index + 1
+                last_index = first + len(frames) - 1
+                checksum += int(frames[-1, -1, -1, 0]) + int(frames[0, 0, 0, 0])  # the chunk is on the host: touch both ends
+                chunks += 1
+            return time.perf_counter() - start, last_index + 1, chunks, checksum
+
+        try:
+            for engine in engines:
+                engine.set_profiling(True)
+            run(4 * batch, {})  # warm-up, every launch bracketed: it names the last conv launch
+            last_conv = next((s.name for s in engines[0].steps() if last_conv_pattern.match(s.name)), "conv")
+            for engine in engines:
+                engine.set_profiling(True, only_step=last_conv)
+            timings: dict = {}
+            elapsed, produced, chunks, _ = run(None, timings)
+            assert produced == num_frames
+            timed = [s for engine in engines for s in engine.steps() if s.name.startswith(last_conv)]
+        finally:
+            networks.unload()
+    split = timings.get("audio_to_latents_split_ms", {})
+    audio_ms = float(timings.get("audio_to_latents_ms", 0.0))
     # audio -> latents: algorithmic bytes = the samples read once + the per-frame latent rows written once
     # (two distinct rows per frame, SURVEY.md §8e) + the [N][L] float64 spectrogram written and read once per stage (5 stages)
     audio_bytes = num_frames * 512 * 4 + num_frames * 18 * 512 * 4 + 5 * 2 * num_frames * 512 * 8
+    kernels_ms = float(split.get("kernels_ms", 0.0)) or audio_ms
     result = {
-        "metric": "projection-file-blend frames/sec at 1024x1024 (BASELINE.json configs[2]: 30 s WAV -> FFT + fft-roll -> alpha-blended latents -> synthesis), host audio -> frames in HBM",
-        "value": round(num_frames / (audio_s + synth_s), 3), "unit": "frames/s", "n_gpus": 1,
-        "frames": num_frames, "audio_to_latents_ms": round(audio_s * 1e3, 3), "synthesis_ms": round(synth_s * 1e3, 3),
-        "frames_per_call": batch, "networks_resident": num_networks, "network_switches": switches,
-        "output_side_length": output_side or resolution,
+        "metric": label,
+        "value": round(num_frames / elapsed, 3), "unit": "frames/s", "n_gpus": 1,
+        "timed": "WAV + projection file on disk -> last uint8 frame on the host, through projection_file_blend_frame_chunks (networks resident)",
+        "frames": num_frames, "chunks": chunks, "frames_per_call": batch, "seconds": round(elapsed, 4),
+        "read_projection_file_ms": round(float(timings.get("read_projection_file_ms", 0.0)), 3),
+        "read_and_stretch_wav_ms": round(float(timings.get("read_and_stretch_wav_ms", 0.0)), 3),
+        "audio_to_latents_ms": round(audio_ms, 3),
+        "audio_to_latents_split_ms": {key: round(float(value), 3) for key, value in split.items()},
+        "synthesis_to_host_ms": round(float(timings.get("synthesis_to_host_ms", 0.0)), 3),
+        "d2h_gb_per_s": round(float(timings.get("d2h_gb_per_s") or 0.0), 3),
+        "networks_resident": num_networks, "output_side_length": side,
         "dtype": "f64 (audio) / f32 (synthesis)", "data": "synthetic",
         "roofline": {
             "bound": "mfma",
@@ -196,12 +262,18 @@ def blend_measurement(resolution: int, batch: int, num_networks: int, output_sid
             "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
             "frac": round(executed_fraction(last_conv) * timed[0].flops / (sum(s.ms for s in timed) / len(timed) * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4) if timed else None,
             "audio_stage": {
-                "bound": "hbm (launch-latency in practice: six kernels over < 60 MB)", "algorithmic_bytes": audio_bytes,
-                "achieved": round(audio_bytes / audio_s / 1e9, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(audio_bytes / audio_s / 1e9 / HBM_PEAK_GBS, 6),
+                "bound": "hbm (launch-latency in practice: six kernels over < 60 MB; rocprofv3 per-kernel times: profiles/r03_audio_kernel_stats.csv)",
+                "algorithmic_bytes": audio_bytes,
+                "achieved": round(audio_bytes / (kernels_ms * 1e-3) / 1e9, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s over the six kernels (stream drained)",
+                "frac": round(audio_bytes / (kernels_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 6),
             },
         },
     }
+    if overlay:
+        result["overlay"] = {
+            "gate": "synthetic landmark detector (the real one is external: dlib), real phash + box distance + track_length 5 + overlay write",
+            "chunks_held_max": timings.get("overlay_chunks_held_max"), "overlays_written": timings.get("overlays_written"),
+        }
     if with_cpu_baseline:
         from oracle import audio_ref  # pylint: disable=import-outside-toplevel
 
@@ -210,11 +282,17 @@ def blend_measurement(resolution: int, batch: int, num_networks: int, output_sid
         cpu_s = time.perf_counter() - t0
         result["cpu_baseline"] = {
             "value": round(cpu_s * 1e3, 1), "unit": "ms for audio -> latents of the same 1800 frames (lower is better)", "cores": 1, "kind": "port",
-            "sample": "oracle/audio_ref.alpha_blend_projection_file (numpy / scipy restatement of the reference's chain, its Python loops vectorised), the whole 30 s workload once, single thread; the GPU stage beside it: %.1f ms" % (audio_s * 1e3),
+            "sample": "oracle/audio_ref.alpha_blend_projection_file (numpy / scipy restatement of the reference's chain, its Python loops vectorised), the whole 30 s workload once, single thread; the GPU stage beside it: %.1f ms" % audio_ms,
         }
-    for engine in engines:
-        engine.close()
     return result
+
+
+def guarded(measure, *args, **kwargs) -> dict:
+    """An extra measurement must never cost the contract line: its failure is recorded in its slot."""
+    try:
+        return measure(*args, **kwargs)
+    except Exception as error:  # pylint: disable=broad-except
+        return {"error": f"{type(error).__name__}: {error}"}
 
 
 def one_frame_latency(resolution: int, device) -> dict:
@@ -240,9 +318,16 @@ def one_frame_latency(resolution: int, device) -> dict:
     return out
 
 
+METRIC_CONFIG_2 = "projection-file-blend frames/sec at 1024x1024 through the product stream (BASELINE.json configs[2]: 30 s WAV -> FFT + fft-roll -> alpha-blended latents -> synthesis @60 fps), files on disk -> frames on the host"
+METRIC_CONFIG_3 = "projection-file-blend frames/sec at --output-side-length 2160 on ONE GPU through the product stream (BASELINE.json configs[3] without the 8-GPU sharding), files on disk -> 2160x2160 frames on the host"
+METRIC_CONFIG_4 = "projection-file-blend frames/sec at 1024x1024 with three resident networks switched by the RMS index, through the product stream (BASELINE.json configs[4] on one GPU, no overlay)"
+METRIC_CONFIG_4_OVERLAY = "projection-file-blend frames/sec at 1024x1024 with three resident networks AND the streaming phash / bbox overlay gate (BASELINE.json configs[4] on one GPU; synthetic landmark detector)"
+
+
 def blend_workload(args, device) -> int:
-    """`--workload blend`: only the configs[2] line (with --networks / --output-side: configs[4] / configs[3] on one GPU)."""
-    print(json.dumps(blend_measurement(args.resolution, args.batch, args.networks, args.output_side, device, not args.no_cpu_baseline)), flush=True)
+    """`--workload blend`: only the configs[2] line (with --networks / --output-side / --overlay: configs[4] / configs[3] on one GPU)."""
+    label = METRIC_CONFIG_4_OVERLAY if args.overlay else (METRIC_CONFIG_4 if args.networks > 1 else (METRIC_CONFIG_3 if args.output_side else METRIC_CONFIG_2))
+    print(json.dumps(product_stream_measurement(label, args.resolution, args.batch, args.networks, args.output_side, device, not args.no_cpu_baseline, args.overlay)), flush=True)
     return 0
 
 
@@ -268,6 +353,7 @@ def main() -> int:
     )
     parser.add_argument("--networks", type=int, default=1, help="blend workload: resident networks the RMS index switches between")
     parser.add_argument("--output-side", type=int, default=None, help="blend workload: --output-side-length (bicubic resize in HBM), e.g. 2160")
+    parser.add_argument("--overlay", action="store_true", help="blend workload: the streaming phash / bbox overlay gate (synthetic landmark detector)")
     args = parser.parse_args()
 
     world_size = int(os.environ.get("WORLD_SIZE", "1"))
@@ -287,9 +373,9 @@ def main() -> int:
     if world_size > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if rehearsal:
-            dist.init_process_group(backend="gloo")
+            dist.init_process_group(backend="gloo", timeout=PROCESS_GROUP_TIMEOUT)
         else:
-            dist.init_process_group(backend="nccl", device_id=device)
+            dist.init_process_group(backend="nccl", device_id=device, timeout=PROCESS_GROUP_TIMEOUT)
 
     resolution, batch = args.resolution, args.batch
     if args.workload == "blend":
@@ -410,8 +496,9 @@ def main() -> int:
                 "unit": "TFLOP/s",
                 "frac": round(executed_fraction(dominant.name) * dominant.flops / (dominant.ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4),
                 "algorithmic_direct_form": round(dominant.flops / (dominant.ms * 1e-3) / 1e12, 3),
-                "traffic": measured_traffic(dominant.name, resolution, batch),
-                "traffic_note": "HBM bytes per launch from profiles/traffic_latest.json (2*FETCH_SIZE + WRITE_SIZE, separate --pmc passes); algorithmic bytes per launch = %d" % int(dominant.bytes),
+                "traffic": measured_traffic(dominant.name, resolution, batch)[0],
+                "traffic_note": "HBM bytes per launch (2*FETCH_SIZE + WRITE_SIZE, separate --pmc passes) %s; algorithmic bytes per launch = %d"
+                % (measured_traffic(dominant.name, resolution, batch)[1], int(dominant.bytes)),
                 "all_conv_launches": {
                     # executed matrix-core flops of all conv launches over their summed durations (Winograd launches
                     # count 4/9 of their direct-form flops: that is what runs)
@@ -438,10 +525,11 @@ def main() -> int:
         if world_size == 1 and not args.no_extras:
             # measured beside the contract line, same process, same GPU (each is also reachable alone: --workload blend)
             result["extras"] = {
-                "config_3_blend": blend_measurement(resolution, batch, 1, None, device, not args.no_cpu_baseline),
-                "config_5_three_resident_networks": blend_measurement(resolution, batch, 3, None, device, False),
-                "config_4_output_side_2160_one_gpu": blend_measurement(resolution, batch, 1, 2160, device, False),
-                "one_frame_latency": one_frame_latency(resolution, device),
+                "config_2_blend_stream": guarded(product_stream_measurement, METRIC_CONFIG_2, resolution, batch, 1, None, device, not args.no_cpu_baseline),
+                "config_4_three_networks_stream": guarded(product_stream_measurement, METRIC_CONFIG_4, resolution, batch, 3, None, device, False),
+                "config_4_three_networks_overlay_stream": guarded(product_stream_measurement, METRIC_CONFIG_4_OVERLAY, resolution, batch, 3, None, device, False, True),
+                "config_3_output_side_2160_one_gpu_stream": guarded(product_stream_measurement, METRIC_CONFIG_3, resolution, batch, 1, 2160, device, False),
+                "one_frame_latency": guarded(one_frame_latency, resolution, device),
             }
         print(json.dumps(result), flush=True)
 

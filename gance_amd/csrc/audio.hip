@@ -23,7 +23,10 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <map>
+#include <mutex>
 #include <string>
+#include <tuple>
 #include <vector>
 
 #include "../../include/gance_hip.h"
@@ -99,6 +102,26 @@ __device__ __forceinline__ double key_value(unsigned long long k) {
     return __longlong_as_double((long long)b);
 }
 
+// wavefront (64 lanes) reductions by butterfly shuffles; every lane ends up with the result
+__device__ __forceinline__ unsigned long long wave_max_key(unsigned long long k) {
+#pragma unroll
+    for (int offset = 32; offset > 0; offset >>= 1) {
+        const unsigned long long other = __shfl_xor(k, offset, 64);
+        k = other > k ? other : k;
+    }
+    return k;
+}
+__device__ __forceinline__ double wave_min_f64(double v) {
+#pragma unroll
+    for (int offset = 32; offset > 0; offset >>= 1) v = fmin(v, __shfl_xor(v, offset, 64));
+    return v;
+}
+__device__ __forceinline__ double wave_max_f64(double v) {
+#pragma unroll
+    for (int offset = 32; offset > 0; offset >>= 1) v = fmax(v, __shfl_xor(v, offset, 64));
+    return v;
+}
+
 // Savitzky-Golay at position i of a line x[0..n-1] (stride in elements), mode 'interp'.
 // Interior: folded symmetric sum in scipy.ndimage.correlate1d's order, no fused multiply-add.
 template <typename Load>
@@ -151,7 +174,8 @@ __device__ float pairwise_sum_f32(Load a, int lo, int n) {
 // kernels
 // ------------------------------------------------------------------------------------------
 
-// a3: windowed DFT magnitude. One block per frame, thread k = frequency bin. |X| max -> *max_key.
+// a3: windowed DFT magnitude. One block per frame, thread k = frequency bin. |X| max -> *max_key: the block's
+// maximum by wavefront shuffles, then ONE global atomic per block.
 __global__ __launch_bounds__(256) void dft_magnitude_kernel(const float* __restrict__ audio, int L, int m,
                                                             const double* __restrict__ window,
                                                             const double* __restrict__ twiddle,  // cos[m], sin[m]
@@ -160,16 +184,16 @@ __global__ __launch_bounds__(256) void dft_magnitude_kernel(const float* __restr
     double* xs = lds;          // [m]
     double* tc = lds + m;      // [m]
     double* ts = lds + 2 * m;  // [m]
-    __shared__ unsigned long long block_max;
+    __shared__ unsigned long long wave_best[4];
     const int t = blockIdx.x;
     const int bins = m / 2;
-    if (threadIdx.x == 0) block_max = 0ull;
     for (int n = threadIdx.x; n < m; n += blockDim.x) {
         xs[n] = __dmul_rn((double)audio[(size_t)t * L + n], window[n]);
         tc[n] = twiddle[n];
         ts[n] = twiddle[m + n];
     }
     __syncthreads();
+    unsigned long long best = 0ull;
     for (int k = threadIdx.x; k < bins; k += blockDim.x) {
         double re = 0.0, im = 0.0;
         int idx = 0;
@@ -181,10 +205,16 @@ __global__ __launch_bounds__(256) void dft_magnitude_kernel(const float* __restr
         }
         const double a = hypot(re, im);
         mag[(size_t)t * bins + k] = a;
-        atomicMax(&block_max, order_key(a));
+        const unsigned long long key = order_key(a);
+        best = key > best ? key : best;
     }
+    best = wave_max_key(best);
+    if ((threadIdx.x & 63) == 0) wave_best[threadIdx.x >> 6] = best;
     __syncthreads();
-    if (threadIdx.x == 0) atomicMax(max_key, block_max);
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < (int)(blockDim.x >> 6); ++w) best = wave_best[w] > best ? wave_best[w] : best;
+        atomicMax(max_key, best);
+    }
 }
 
 // a3 tail + a4: dB against the global max, Fourier resample bins -> L (matrix RT[bins][L]),
@@ -226,7 +256,10 @@ __global__ __launch_bounds__(512) void db_resample_kernel(const double* __restri
                 hi = fmax(hi, acc[f]);
             }
     }
-    if (lo <= hi) {
+    // the wavefront's extrema by shuffles, one pair of global atomics per wavefront
+    lo = wave_min_f64(lo);
+    hi = wave_max_f64(hi);
+    if ((threadIdx.x & 63) == 0 && lo <= hi) {
         atomicMin(&minmax_key[0], order_key(lo));
         atomicMax(&minmax_key[1], order_key(hi));
     }
@@ -268,7 +301,7 @@ __global__ __launch_bounds__(512) void smooth_kernel(const double* __restrict__ 
     }
 }
 
-// a7: float32 RMS per frame, numpy pairwise order (librosa hop is 512 whatever L is).
+// a7: float32 RMS per frame, numpy pairwise order (librosa hop is 512 whatever L is). Generic form: one thread per frame.
 __global__ void rms_kernel(const float* __restrict__ audio, size_t num_samples, int L, int n_frames,
                            float* __restrict__ rms) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -282,6 +315,31 @@ __global__ void rms_kernel(const float* __restrict__ audio, size_t num_samples, 
     // np.mean: the float32 sum divided by the count in float32 (exact when L is a power of two); correctly
     // rounded float32 sqrt: sqrt in float64 then one rounding (53 >= 2*24+2 bits: the double rounding is innocuous)
     rms[t] = (float)sqrt((double)__fdiv_rn(total, (float)L));
+}
+
+// The same for L = 512 (the blend's only frame length), two frames per wavefront. numpy's pairwise sum of 512
+// values is a fixed tree: four runs of 128, each accumulated into 8 interleaved partial sums r[j] += a[i + j]
+// (i = 8, 16, ... 120), the eight combined as ((r0 + r1) + (r2 + r3)) + ((r4 + r5) + (r6 + r7)), the four runs as
+// (b0 + b1) + (b2 + b3). That is 32 independent chains of 16 additions: one per lane of half a wavefront, and the
+// tree is five butterfly shuffles (x + y is commutative bit for bit, so both partners hold the same sum).
+__global__ __launch_bounds__(256) void rms512_wave_kernel(const float* __restrict__ audio, int n_frames, float* __restrict__ rms) {
+    const int lane = threadIdx.x & 63;
+    const int frame = (blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 2 + (lane >> 5);
+    const int j = lane & 7, run = (lane >> 3) & 3;
+    float r = 0.f;
+    if (frame < n_frames) {
+        const float* a = audio + (size_t)frame * 512 + run * 128 + j;
+        const float v0 = a[0];
+        r = __fmul_rn(v0, v0);
+#pragma unroll
+        for (int i = 8; i < 128; i += 8) {
+            const float v = a[i];
+            r = __fadd_rn(r, __fmul_rn(v, v));
+        }
+    }
+#pragma unroll
+    for (int offset = 1; offset <= 16; offset <<= 1) r = __fadd_rn(r, __shfl_xor(r, offset, 64));
+    if (frame < n_frames && (lane & 31) == 0) rms[frame] = (float)sqrt((double)__fdiv_rn(r, 512.f));
 }
 
 // scipy.ndimage.maximum_filter1d(series, size) (mode "reflect", origin 0) of reduce_vector_rms_rolling_max
@@ -319,64 +377,104 @@ struct ChainArgs {
     int* values;         // [n] quantised integers
     int* cumulative;     // [n] or nullptr
 };
-__global__ void reduce_chain_kernel(ChainArgs a0, ChainArgs a1) {
-    if (threadIdx.x != 0) return;
+// One block of 256 threads per series. The float32 mean (numpy's pairwise order) and pandas' rolling mean (a Kahan
+// sum carried from window to window) are sequential by definition: one lane each, in two different wavefronts so
+// that they run side by side. Everything after them is data parallel: the Savitzky-Golay filter per element, the
+// series' extrema by wavefront shuffles, the remap + rint per element, and the running sum of the roll amounts as
+// a block-wide scan (per-thread runs, shuffle scan inside a wavefront, wavefront totals through LDS).
+constexpr int kChainThreads = 256;
+__global__ __launch_bounds__(kChainThreads) void reduce_chain_kernel(ChainArgs a0, ChainArgs a1) {
     const ChainArgs a = blockIdx.x == 0 ? a0 : a1;
     if (a.n <= 0) return;
     const int n = a.n;
-    auto r = [&](int i) { return a.rms[i]; };
-    const float fill32 = __fdiv_rn(pairwise_sum_f32(r, 0, n), (float)n);
-    const double fill = (double)fill32;
-    // pandas roll_mean, fixed window, min_periods = window
-    int nobs = 0, neg_ct = 0, same = 0;
-    double sum_x = 0.0, comp_add = 0.0, comp_remove = 0.0, prev = NAN;
-    for (int i = 0; i < n; ++i) {
-        if (i >= a.rolling_window) {
-            const double val = (double)a.rms[i - a.rolling_window];
-            nobs -= 1;
-            const double y = __dsub_rn(-val, comp_remove);
-            const double t = __dadd_rn(sum_x, y);
-            comp_remove = __dsub_rn(__dsub_rn(t, sum_x), y);
-            sum_x = t;
-            if (signbit(val)) neg_ct -= 1;
-        }
-        const double val = (double)a.rms[i];
-        nobs += 1;
-        const double y = __dsub_rn(val, comp_add);
-        const double t = __dadd_rn(sum_x, y);
-        comp_add = __dsub_rn(__dsub_rn(t, sum_x), y);
-        sum_x = t;
-        if (signbit(val)) neg_ct += 1;
-        same = (val == prev) ? same + 1 : 1;
-        prev = val;
-        double result = fill;  // NaN head -> fillna(series.mean())
-        if (nobs >= a.rolling_window) {
-            result = __ddiv_rn(sum_x, (double)nobs);
-            if (same >= nobs) result = prev;
-            else if (neg_ct == 0 && result < 0) result = 0.0;
-            else if (neg_ct == nobs && result > 0) result = 0.0;
-        }
-        a.rolling[i] = result;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    __shared__ double fill_shared;
+    __shared__ double wave_lo[kChainThreads / 64], wave_hi[kChainThreads / 64];
+    __shared__ long long wave_total[kChainThreads / 64];
+    if (tid == 64) {  // wavefront 1: fill value = float32 mean of the raw series
+        auto r = [&](int i) { return a.rms[i]; };
+        fill_shared = (double)__fdiv_rn(pairwise_sum_f32(r, 0, n), (float)n);
     }
+    if (tid == 0) {  // wavefront 0: pandas roll_mean, fixed window, min_periods = window (head entries set below)
+        int nobs = 0, neg_ct = 0, same = 0;
+        double sum_x = 0.0, comp_add = 0.0, comp_remove = 0.0, prev = NAN;
+        for (int i = 0; i < n; ++i) {
+            if (i >= a.rolling_window) {
+                const double val = (double)a.rms[i - a.rolling_window];
+                nobs -= 1;
+                const double y = __dsub_rn(-val, comp_remove);
+                const double t = __dadd_rn(sum_x, y);
+                comp_remove = __dsub_rn(__dsub_rn(t, sum_x), y);
+                sum_x = t;
+                if (signbit(val)) neg_ct -= 1;
+            }
+            const double val = (double)a.rms[i];
+            nobs += 1;
+            const double y = __dsub_rn(val, comp_add);
+            const double t = __dadd_rn(sum_x, y);
+            comp_add = __dsub_rn(__dsub_rn(t, sum_x), y);
+            sum_x = t;
+            if (signbit(val)) neg_ct += 1;
+            same = (val == prev) ? same + 1 : 1;
+            prev = val;
+            if (nobs >= a.rolling_window) {
+                double result = __ddiv_rn(sum_x, (double)nobs);
+                if (same >= nobs) result = prev;
+                else if (neg_ct == 0 && result < 0) result = 0.0;
+                else if (neg_ct == nobs && result > 0) result = 0.0;
+                a.rolling[i] = result;
+            }
+        }
+    }
+    __syncthreads();
+    // NaN head -> fillna(series.mean())
+    for (int i = tid; i < n && i < a.rolling_window - 1; i += kChainThreads) a.rolling[i] = fill_shared;
+    __threadfence_block();
+    __syncthreads();
     double lo = INFINITY, hi = -INFINITY;
-    for (int i = 0; i < n; ++i) {
+    for (int i = tid; i < n; i += kChainThreads) {
         auto x = [&](int ii) { return a.rolling[ii]; };
         const double v = savgol_at(x, i, n, a.sg, a.w);
         a.smoothed[i] = v;
         lo = fmin(lo, v);
         hi = fmax(hi, v);
     }
+    lo = wave_min_f64(lo);
+    hi = wave_max_f64(hi);
+    if (lane == 0) {
+        wave_lo[wave] = lo;
+        wave_hi[wave] = hi;
+    }
+    __syncthreads();
+    for (int w = 0; w < kChainThreads / 64; ++w) {
+        lo = fmin(lo, wave_lo[w]);
+        hi = fmax(hi, wave_hi[w]);
+    }
     // scipy interp1d linear: slope * (x - x_lo) + y_lo with y_lo = 0, y_hi = K - 1
     const double slope = __ddiv_rn((double)(a.num_indices - 1), __dsub_rn(hi, lo));
-    long long running = 0;
-    for (int i = 0; i < n; ++i) {
-        const double q = rint(__dadd_rn(__dmul_rn(slope, __dsub_rn(a.smoothed[i], lo)), 0.0));
-        const int v = (int)q;
+    // contiguous runs per thread, so that the running sum is a scan over threads
+    const int per_thread = (n + kChainThreads - 1) / kChainThreads;
+    const int first = tid * per_thread, last = min(n, first + per_thread);
+    long long local = 0;
+    for (int i = first; i < last; ++i) {
+        const int v = (int)rint(__dadd_rn(__dmul_rn(slope, __dsub_rn(a.smoothed[i], lo)), 0.0));
         a.values[i] = v;
-        if (a.cumulative != nullptr) {
-            running += v;
-            a.cumulative[i] = (int)(running % a.cumulative_mod);
-        }
+        local += v;
+    }
+    if (a.cumulative == nullptr) return;  // (uniform over the block)
+    long long inclusive = local;
+#pragma unroll
+    for (int offset = 1; offset < 64; offset <<= 1) {
+        const long long other = __shfl_up(inclusive, offset, 64);
+        if (lane >= offset) inclusive += other;
+    }
+    if (lane == 63) wave_total[wave] = inclusive;
+    __syncthreads();
+    long long running = inclusive - local;  // exclusive prefix of this thread's run
+    for (int w = 0; w < wave; ++w) running += wave_total[w];
+    for (int i = first; i < last; ++i) {
+        running += a.values[i];
+        a.cumulative[i] = (int)(running % a.cumulative_mod);
     }
 }
 
@@ -579,6 +677,41 @@ int audio_fail(int code, const std::string& message) { return gance::set_last_er
     } while (0)
 }  // namespace
 
+// Operator tables depend on (vector length, filter parameters) only, never on the audio: built once per process and
+// device (the Dirichlet resampling matrix alone is 130 000 long-double sines) and shared by every gance_blend; a
+// warm gance_blend_create is one hipMalloc. Never freed (about 1.1 MB per device).
+namespace {
+struct TableKey {
+    int device, kind, a, b;
+    bool operator<(const TableKey& o) const { return std::tie(device, kind, a, b) < std::tie(o.device, o.kind, o.a, o.b); }
+};
+enum TableKind { kTableWindow = 0, kTableTwiddle = 1, kTableResample = 2, kTableSavgol = 3 };
+std::mutex g_tables_mutex;
+std::map<TableKey, double*> g_tables;
+
+template <typename Build>
+hipError_t cached_table(int device, int kind, int a, int b, Build build, double** out) {
+    std::lock_guard<std::mutex> lock(g_tables_mutex);
+    const TableKey key{device, kind, a, b};
+    auto found = g_tables.find(key);
+    if (found != g_tables.end()) {
+        *out = found->second;
+        return hipSuccess;
+    }
+    const std::vector<double> host = build();
+    double* ptr = nullptr;
+    hipError_t e = hipMalloc((void**)&ptr, host.size() * sizeof(double));
+    if (e != hipSuccess) return e;
+    if ((e = hipMemcpy(ptr, host.data(), host.size() * sizeof(double), hipMemcpyHostToDevice)) != hipSuccess) {
+        hipFree(ptr);
+        return e;
+    }
+    g_tables[key] = ptr;
+    *out = ptr;
+    return hipSuccess;
+}
+}  // namespace
+
 struct gance_blend {
     gance_blend_config cfg{};
     int device = 0;
@@ -595,17 +728,14 @@ struct gance_blend {
     float* rms = nullptr;
     int *roll_values = nullptr, *cumulative = nullptr, *net_indices = nullptr;
     unsigned long long* keys = nullptr;  // [0] max |X|, [1] min resampled, [2] max resampled
+    void* workspace = nullptr;           // ONE allocation behind every pointer of the group above
 };
 
 extern "C" {
 
 void gance_blend_destroy(gance_blend* b) {
     if (!b) return;
-    void* ptrs[] = {b->window, b->twiddle, b->RT, b->sg_time, b->sg_bins, b->sg_roll_bins, b->sg_chain_roll,
-                    b->sg_chain_index, b->mag, b->db, b->resampled, b->scaled, b->time_smoothed, b->spec,
-                    b->rolled, b->final_spec, b->blend_row, b->rolling[0], b->rolling[1], b->smoothed[0],
-                    b->smoothed[1], b->rms, b->roll_values, b->cumulative, b->net_indices, b->keys};
-    for (void* p : ptrs) hipFree(p);
+    hipFree(b->workspace);  // the operator tables belong to the process-wide cache (cached_table)
     delete b;
 }
 
@@ -637,93 +767,98 @@ int gance_blend_create(const gance_blend_config* config, int32_t device, gance_b
     gance::DeviceGuard guard(device);
     GANCE_AUDIO_CHECK(guard.status());
 
+    const int L = c.vector_length, N = c.num_frames;
+    const int m = L - 2, bins = m / 2;
+    if (bins % 2 == 0) return audio_fail(GANCE_ERR_INVALID_ARGUMENT, "vector_length with an even bin count is not supported");
+    const int index_w = c.index_savgol_window_length == 0 ? 3 : c.index_savgol_window_length;
+    const int index_p = c.index_savgol_window_length == 0 ? 2 : c.index_savgol_polyorder;
+
     gance_blend* b = new gance_blend();
     b->cfg = c;
     b->device = device;
-    const int L = c.vector_length, N = c.num_frames;
-    const int m = L - 2, bins = m / 2;
     b->m = m;
     b->bins = bins;
-    const long double two_pi = 6.283185307179586476925286766559L;
-
-    std::vector<double> window(m), twiddle(2 * (size_t)m), RT((size_t)bins * L);
-    for (int n = 0; n < m; ++n) {
-        window[n] = (double)(0.5L - 0.5L * cosl(two_pi * n / m));  // np.hanning(m + 1)[:-1]
-        twiddle[n] = (double)cosl(two_pi * n / m);
-        twiddle[m + n] = (double)sinl(two_pi * n / m);
-    }
-    // scipy.signal.resample of a real length-`bins` line to L points: keep bins//2+1 rfft terms,
-    // y[j] = (1/bins) * sum_n x[n] * D(theta), D = sin((M + 1/2) theta) / sin(theta / 2),
-    // M = (bins - 1) / 2 (bins odd), theta = 2 pi (j / L - n / bins)
-    const int M = (bins - 1) / 2;
-    for (int n = 0; n < bins; ++n)
-        for (int j = 0; j < L; ++j) {
-            const long double theta = two_pi * ((long double)j / L - (long double)n / bins);
-            const long double half = theta / 2;
-            const long double s = sinl(half);
-            long double d;
-            if (fabsl(s) < 1e-18L) d = 2.0L * M + 1.0L;
-            else d = sinl((M + 0.5L) * theta) / s;
-            RT[(size_t)n * L + j] = (double)(d / bins);
-        }
-    if (bins % 2 == 0) {
-        delete b;
-        return audio_fail(GANCE_ERR_INVALID_ARGUMENT, "vector_length with an even bin count is not supported");
-    }
-    const std::vector<double> sg_time = gance_audio::savgol_table(7, 3);
-    const std::vector<double> sg_bins = gance_audio::savgol_table(5, 3);
-    const std::vector<double> sg_roll_bins = gance_audio::savgol_table(51, 2);
-    const std::vector<double> sg_chain_roll = gance_audio::savgol_table(7, 3);
-    const int index_w = c.index_savgol_window_length == 0 ? 3 : c.index_savgol_window_length;
-    const int index_p = c.index_savgol_window_length == 0 ? 2 : c.index_savgol_polyorder;
-    const std::vector<double> sg_chain_index = gance_audio::savgol_table(index_w, index_p);
-
-#define GANCE_ALLOC(ptr, count, type)                                                        \
-    do {                                                                                     \
-        hipError_t gance_err_ = hipMalloc((void**)&(ptr), (size_t)(count) * sizeof(type));   \
-        if (gance_err_ != hipSuccess) {                                                      \
-            gance_blend_destroy(b);                                                          \
-            return audio_fail(GANCE_ERR_OUT_OF_MEMORY, "hipMalloc failed in gance_blend_create"); \
-        }                                                                                    \
-    } while (0)
-#define GANCE_UPLOAD(ptr, vec)                                                               \
-    do {                                                                                     \
-        GANCE_ALLOC(ptr, (vec).size(), double);                                              \
-        if (hipMemcpy(ptr, (vec).data(), (vec).size() * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) { \
-            gance_blend_destroy(b);                                                          \
-            return audio_fail(GANCE_ERR_HIP, "hipMemcpy failed in gance_blend_create");      \
-        }                                                                                    \
-    } while (0)
-    GANCE_UPLOAD(b->window, window);
-    GANCE_UPLOAD(b->twiddle, twiddle);
-    GANCE_UPLOAD(b->RT, RT);
-    GANCE_UPLOAD(b->sg_time, sg_time);
-    GANCE_UPLOAD(b->sg_bins, sg_bins);
-    GANCE_UPLOAD(b->sg_roll_bins, sg_roll_bins);
-    GANCE_UPLOAD(b->sg_chain_roll, sg_chain_roll);
-    GANCE_UPLOAD(b->sg_chain_index, sg_chain_index);
     b->index_w = index_w;
-    const size_t NL = (size_t)N * L;
-    GANCE_ALLOC(b->mag, (size_t)N * bins, double);
-    GANCE_ALLOC(b->db, (size_t)N * bins, double);
-    GANCE_ALLOC(b->resampled, NL, double);
-    GANCE_ALLOC(b->scaled, NL, double);
-    GANCE_ALLOC(b->time_smoothed, NL, double);
-    GANCE_ALLOC(b->spec, NL, double);
-    GANCE_ALLOC(b->rolled, NL, double);
-    GANCE_ALLOC(b->final_spec, NL, double);
-    GANCE_ALLOC(b->blend_row, NL, double);
-    for (int i = 0; i < 2; ++i) {
-        GANCE_ALLOC(b->rolling[i], N, double);
-        GANCE_ALLOC(b->smoothed[i], N, double);
+    const long double two_pi = 6.283185307179586476925286766559L;
+    auto fail_tables = [&](hipError_t e) {
+        gance_blend_destroy(b);
+        return audio_fail(e == hipErrorOutOfMemory ? GANCE_ERR_OUT_OF_MEMORY : GANCE_ERR_HIP,
+                          std::string("operator tables: ") + hipGetErrorString(e));
+    };
+    hipError_t te = cached_table(device, kTableWindow, m, 0, [&] {
+        std::vector<double> window(m);
+        for (int n = 0; n < m; ++n) window[n] = (double)(0.5L - 0.5L * cosl(two_pi * n / m));  // np.hanning(m + 1)[:-1]
+        return window;
+    }, &b->window);
+    if (te != hipSuccess) return fail_tables(te);
+    te = cached_table(device, kTableTwiddle, m, 0, [&] {
+        std::vector<double> twiddle(2 * (size_t)m);
+        for (int n = 0; n < m; ++n) {
+            twiddle[n] = (double)cosl(two_pi * n / m);
+            twiddle[m + n] = (double)sinl(two_pi * n / m);
+        }
+        return twiddle;
+    }, &b->twiddle);
+    if (te != hipSuccess) return fail_tables(te);
+    te = cached_table(device, kTableResample, bins, L, [&] {
+        // scipy.signal.resample of a real length-`bins` line to L points: keep bins//2+1 rfft terms,
+        // y[j] = (1/bins) * sum_n x[n] * D(theta), D = sin((M + 1/2) theta) / sin(theta / 2),
+        // M = (bins - 1) / 2 (bins odd), theta = 2 pi (j / L - n / bins)
+        std::vector<double> RT((size_t)bins * L);
+        const int M = (bins - 1) / 2;
+        for (int n = 0; n < bins; ++n)
+            for (int j = 0; j < L; ++j) {
+                const long double theta = two_pi * ((long double)j / L - (long double)n / bins);
+                const long double s = sinl(theta / 2);
+                const long double d = fabsl(s) < 1e-18L ? 2.0L * M + 1.0L : sinl((M + 0.5L) * theta) / s;
+                RT[(size_t)n * L + j] = (double)(d / bins);
+            }
+        return RT;
+    }, &b->RT);
+    if (te != hipSuccess) return fail_tables(te);
+    struct { int w, p; double** out; } const filters[] = {
+        {7, 3, &b->sg_time}, {5, 3, &b->sg_bins}, {51, 2, &b->sg_roll_bins}, {7, 3, &b->sg_chain_roll}, {index_w, index_p, &b->sg_chain_index}};
+    for (const auto& f : filters) {
+        te = cached_table(device, kTableSavgol, f.w, f.p, [&] { return gance_audio::savgol_table(f.w, f.p); }, f.out);
+        if (te != hipSuccess) return fail_tables(te);
     }
-    GANCE_ALLOC(b->rms, N, float);
-    GANCE_ALLOC(b->roll_values, N, int);
-    GANCE_ALLOC(b->cumulative, N, int);
-    GANCE_ALLOC(b->net_indices, N, int);
-    GANCE_ALLOC(b->keys, 3, unsigned long long);
-#undef GANCE_ALLOC
-#undef GANCE_UPLOAD
+
+    // workspace: one allocation, carved into 256-byte aligned pieces
+    const size_t NL = (size_t)N * L;
+    size_t total = 0;
+    auto reserve = [&](size_t bytes) {
+        const size_t at = total;
+        total += (bytes + 255) / 256 * 256;
+        return at;
+    };
+    const size_t o_mag = reserve((size_t)N * bins * 8), o_db = reserve((size_t)N * bins * 8), o_resampled = reserve(NL * 8),
+                 o_scaled = reserve(NL * 8), o_time = reserve(NL * 8), o_spec = reserve(NL * 8), o_rolled = reserve(NL * 8),
+                 o_final = reserve(NL * 8), o_blend = reserve(NL * 8), o_rolling0 = reserve((size_t)N * 8), o_rolling1 = reserve((size_t)N * 8),
+                 o_smoothed0 = reserve((size_t)N * 8), o_smoothed1 = reserve((size_t)N * 8), o_rms = reserve((size_t)N * 4),
+                 o_roll = reserve((size_t)N * 4), o_cumulative = reserve((size_t)N * 4), o_net = reserve((size_t)N * 4), o_keys = reserve(3 * 8);
+    if (hipMalloc(&b->workspace, total) != hipSuccess) {
+        gance_blend_destroy(b);
+        return audio_fail(GANCE_ERR_OUT_OF_MEMORY, "hipMalloc failed in gance_blend_create");
+    }
+    char* const base = (char*)b->workspace;
+    b->mag = (double*)(base + o_mag);
+    b->db = (double*)(base + o_db);
+    b->resampled = (double*)(base + o_resampled);
+    b->scaled = (double*)(base + o_scaled);
+    b->time_smoothed = (double*)(base + o_time);
+    b->spec = (double*)(base + o_spec);
+    b->rolled = (double*)(base + o_rolled);
+    b->final_spec = (double*)(base + o_final);
+    b->blend_row = (double*)(base + o_blend);
+    b->rolling[0] = (double*)(base + o_rolling0);
+    b->rolling[1] = (double*)(base + o_rolling1);
+    b->smoothed[0] = (double*)(base + o_smoothed0);
+    b->smoothed[1] = (double*)(base + o_smoothed1);
+    b->rms = (float*)(base + o_rms);
+    b->roll_values = (int*)(base + o_roll);
+    b->cumulative = (int*)(base + o_cumulative);
+    b->net_indices = (int*)(base + o_net);
+    b->keys = (unsigned long long*)(base + o_keys);
     *out = b;
     return GANCE_OK;
 }
@@ -753,13 +888,12 @@ int gance_blend_run(gance_blend* b, const float* d_audio, uint64_t num_samples, 
                        b->resampled, N, L, b->keys + 1, c.amplitude_lo, c.amplitude_hi, has_range, b->sg_time, 7,
                        b->sg_bins, 5, debug_stages ? b->scaled : nullptr, debug_stages ? b->time_smoothed : nullptr,
                        b->spec);
-    hipLaunchKernelGGL(gance_audio::rms_kernel, dim3((N + 63) / 64), dim3(64), 0, stream, d_audio, (size_t)num_samples,
-                       L, N, b->rms);
+    hipLaunchKernelGGL(gance_audio::rms512_wave_kernel, dim3((N + 7) / 8), dim3(256), 0, stream, d_audio, N, b->rms);
     gance_audio::ChainArgs roll{b->rms, c.fft_roll_enabled ? N : 0, 3, b->sg_chain_roll, 7, 3, L,
                                 b->rolling[0], b->smoothed[0], b->roll_values, b->cumulative};
     gance_audio::ChainArgs index{b->rms, N, 3, b->sg_chain_index, b->index_w, c.num_networks, 0,
                                  b->rolling[1], b->smoothed[1], b->net_indices, nullptr};
-    hipLaunchKernelGGL(gance_audio::reduce_chain_kernel, dim3(2), dim3(64), 0, stream, roll, index);
+    hipLaunchKernelGGL(gance_audio::reduce_chain_kernel, dim3(2), dim3(gance_audio::kChainThreads), 0, stream, roll, index);
     gance_audio::BlendArgs blend{};
     blend.spec = b->spec;
     blend.cumulative = c.fft_roll_enabled ? b->cumulative : nullptr;
@@ -1007,7 +1141,7 @@ int gance_vec_rms_rolling_average(const float* d_audio, uint64_t num_samples, in
     gance_audio::ChainArgs chain{d_rms, n, rolling_window, (const double*)d_table.ptr, savgol_window_length, 2, 0,
                                  d_rolling, d_smoothed, (int*)d_values.ptr, nullptr};
     gance_audio::ChainArgs none{};
-    hipLaunchKernelGGL(gance_audio::reduce_chain_kernel, dim3(1), dim3(64), 0, stream, chain, none);
+    hipLaunchKernelGGL(gance_audio::reduce_chain_kernel, dim3(1), dim3(gance_audio::kChainThreads), 0, stream, chain, none);
     GANCE_AUDIO_CHECK(hipGetLastError());
     GANCE_AUDIO_CHECK(hipStreamSynchronize(stream));
     return GANCE_OK;

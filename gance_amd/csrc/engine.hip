@@ -644,7 +644,8 @@ int synthesize_from_dlat(gance_engine* e, const float* d_dlat, int B, uint8_t* d
                     u.x_b_stride = x_b_stride;
                     u.s_next = s_next;
                     u.input_prescaled = input_prescaled ? 1 : 0;
-                    std::snprintf(name, sizeof(name), "convTF%d_%dx%d_%d->%d", c.layer_idx, res, res, c.cin, c.cout);
+                    // ("convTFp": upfir_fused_pre_kernel, the input arrives multiplied by this layer's style)
+                    std::snprintf(name, sizeof(name), input_prescaled ? "convTFp%d_%dx%d_%d->%d" : "convTF%d_%dx%d_%d->%d", c.layer_idx, res, res, c.cin, c.cout);
                     {
                         const double flops = 2.0 * 9 * (double)c.cin * c.cout * H * W * B;
                         const double bytes = 4.0 * ((double)B * c.cin * H * W + (double)B * c.cout * res * res + 9.0 * c.cin * c.cout);

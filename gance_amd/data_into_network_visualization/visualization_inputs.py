@@ -13,7 +13,8 @@ scipy / pandas / librosa calls. `alpha_blend_projection_file_device` is the same
 in HBM for the frame-sharded synthesis pipeline (no 133 MB float64 `combined` round trip).
 """
 
-from typing import List, NamedTuple, Optional, Tuple
+import time
+from typing import Dict, List, NamedTuple, Optional, Tuple
 
 import numpy as np
 import torch
@@ -48,11 +49,15 @@ def alpha_blend_projection_file_device(
     num_networks: int,
     device: int = 0,
     keep_stages: bool = False,
+    timings: Optional[Dict[str, float]] = None,
 ) -> DeviceBlend:
     """
     Run the blend on `device` and leave the per-frame latent matrices there.
     :param final_latents: (depth, F*L) float32 concatenated final latents; only row 0 is read,
     as in the reference (visualization_inputs.py:220-231).
+    :param timings: if given, filled with the wall-clock split of the call in milliseconds: `create_ms` (operator
+    tables -- cached per process after the first call -- and the workspace allocation), `h2d_ms` (audio + latent
+    row to HBM), `kernels_ms` (the six kernels, stream drained), `check_ms` (the 24-byte read-back of the extrema).
     :raises ValueError: if the frame count is not a multiple of the projected-latent count.
     """
     if vector_length != 512:
@@ -63,26 +68,40 @@ def alpha_blend_projection_file_device(
     num_frames = int(audio.shape[0] / vector_length)
     row0 = np.ascontiguousarray(final_latents[0], dtype=np.float32)
     num_projection = int(row0.shape[0] / vector_length)
+    clock = [time.perf_counter()]
+
+    def lap(name: str) -> None:
+        now = time.perf_counter()
+        if timings is not None:
+            timings[name] = (now - clock[0]) * 1e3
+        clock[0] = now
+
     blend = hip_lib.Blend(
         num_frames, num_projection, alpha, fft_roll_enabled, fft_amplitude_range, blend_depth, num_networks,
         vector_length=vector_length, latent_depth=int(final_latents.shape[0]), device=device,
     )
+    lap("create_ms")
     cuda = torch.device("cuda", device)
+    stream = torch.cuda.current_stream(cuda)
     d_audio = torch.from_numpy(audio).to(cuda)
     d_row0 = torch.from_numpy(row0).to(cuda)
     dlatents = torch.empty((num_frames, int(final_latents.shape[0]), vector_length), dtype=torch.float32, device=cuda)
     indices = torch.empty((num_frames,), dtype=torch.int32, device=cuda)
-    stream = torch.cuda.current_stream(cuda)
+    if timings is not None:
+        stream.synchronize()
+    lap("h2d_ms")
     blend.run_device(
         d_audio.data_ptr(), audio.size, d_row0.data_ptr(), dlatents.data_ptr(), indices.data_ptr(),
         debug_stages=keep_stages, stream=stream.cuda_stream,
     )
     stream.synchronize()  # d_audio / d_row0 go out of scope here
+    lap("kernels_ms")
     try:
         blend.check_finite()
     except ValueError:
         blend.close()
         raise
+    lap("check_ms")
     return DeviceBlend(dlatents, indices, blend)
 
 

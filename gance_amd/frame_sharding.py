@@ -90,7 +90,9 @@ def gather_frames(
 # frames exist at once. The sharded equivalent: the frame sequence is cut into chunks of world_size * C
 # frames; rank g synthesises frames [g*C, (g+1)*C) of every chunk, so ONE gather per chunk lands that chunk
 # in frame order on rank 0, while every rank already synthesises the next chunk. Rank 0 drains each
-# gathered chunk to a pinned-host ring on a copy stream. HBM holds two chunks, the host three.
+# gathered chunk to a pinned-host ring on a side stream. HBM holds two chunks, the host three. With a
+# per-chunk stage between gather and drain (the eye-tracking overlay: `ordered_device_chunks` + `HostRing`) the
+# same pieces are used with that stage in the middle.
 
 
 def stream_piece(num_frames: int, world_size: int, frames_per_rank: int, chunk: int, rank: int) -> Tuple[int, int]:
@@ -147,80 +149,181 @@ def scatter_for_stream(all_inputs: Optional[torch.Tensor], num_frames: int, fram
     return recv[: len(stream_order(num_frames, world_size, frames_per_rank, rank))]
 
 
-def ordered_frame_stream(synthesize_piece, num_frames: int, frames_per_rank: int, frame_shape: Tuple[int, int, int], device: torch.device):
+class StreamRankError(RuntimeError):
+    """Another rank of the frame stream failed (or this one did and is telling the others); the job cannot continue."""
+
+
+_CONTROL_GROUP = [None]  # the host-side (gloo) group the ranks exchange their per-chunk status word on
+
+
+def control_group():
+    """
+    A gloo group over all ranks for host-side control messages (one status word per chunk), created on first use.
+    Collective. With a gloo default group that one is used. Status words must not ride on RCCL: reading them back
+    would put a stream synchronisation into every chunk, and a rank that died leaves an RCCL collective hanging until
+    the watchdog aborts the process, whereas a gloo collective raises after the group's timeout.
+    """
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return None
+    if dist.get_backend() == "gloo":
+        return dist.group.WORLD
+    if _CONTROL_GROUP[0] is None:
+        _CONTROL_GROUP[0] = dist.new_group(backend="gloo")
+    return _CONTROL_GROUP[0]
+
+
+def exchange_status(failed: bool, where: str) -> None:
+    """
+    Every rank contributes one word; if any rank reports a failure every rank leaves with StreamRankError (the
+    failing rank re-raises its own exception instead: the caller does that). The reference relays a worker's
+    start-up error to its parent the same way (network_functions.py:270-278). A rank that has died makes the
+    exchange time out (the process group's timeout) and raise on the survivors.
+    """
+    group = control_group()
+    if group is None:
+        return
+    status = torch.tensor([dist.get_rank() + 1 if failed else 0], dtype=torch.int32)
+    dist.all_reduce(status, op=dist.ReduceOp.MAX, group=group)
+    if int(status.item()) != 0 and not failed:
+        raise StreamRankError(f"rank {int(status.item()) - 1} failed {where}; rank {dist.get_rank()} stops")
+
+
+def ordered_device_chunks(synthesize_piece, num_frames: int, frames_per_rank: int, frame_shape: Tuple[int, int, int], device: torch.device):
     """
     Generator (collective: every rank must exhaust it). `synthesize_piece(offset, count)` returns this rank's
     next `count` frames as a uint8 tensor [count, *frame_shape] on `device`, where `offset` counts the frames
     the rank has produced so far (an index into its `scatter_for_stream` inputs).
-    On rank 0 it yields (first_frame_index, frames) per chunk, in frame order, `frames` a uint8 numpy view of
-    a pinned host ring slot [n, *frame_shape] that stays valid until the generator is advanced twice more;
-    other ranks yield nothing. Chunk k's gather and host drain overlap chunk k+1's synthesis.
+    On rank 0 it yields (first_frame_index, frames, reader_stream) per chunk, in frame order: `frames` is a view of
+    one of two gather buffers in HBM, [n, *frame_shape] uint8. It is valid until the generator is advanced TWICE
+    more, and whoever reads it must do so on `reader_stream` (a side stream that already waits for the gather; None
+    on the CPU): the generator makes the gather that overwrites the buffer wait for that stream. Other ranks yield
+    nothing. Chunk k is handed out after chunk k+1's synthesis and gather have been issued, so the consumer's work
+    on it (overlay, host drain) overlaps them.
+    Failure handling: every rank exchanges one status word per chunk on the host-side control group; an exception in
+    `synthesize_piece` on any rank ends the generator on EVERY rank (the failing rank re-raises its exception, the
+    others raise StreamRankError) instead of leaving them blocked in the next gather.
     """
     world_size = dist.get_world_size() if dist.is_initialized() else 1
     rank = dist.get_rank() if dist.is_initialized() else 0
     chunks = stream_chunks(num_frames, world_size, frames_per_rank)
     per_chunk = world_size * frames_per_rank
     on_gpu = device.type == "cuda"
-    ring_slots = 3
     gathered = [torch.empty((per_chunk, *frame_shape), dtype=torch.uint8, device=device) for _ in range(2)] if rank == 0 else None
     local = [torch.zeros((frames_per_rank, *frame_shape), dtype=torch.uint8, device=device) for _ in range(2)]
-    host_ring = (
-        [torch.empty((per_chunk, *frame_shape), dtype=torch.uint8, pin_memory=on_gpu) for _ in range(ring_slots)] if rank == 0 else None
-    )
-    copy_stream = torch.cuda.Stream(device) if on_gpu else None
-    copied = [None] * ring_slots  # events: ring slot filled
+    reader_stream = torch.cuda.Stream(device) if on_gpu and rank == 0 else None
     works = [None, None]
     produced = 0
 
-    def drain(chunk: int) -> None:
-        """Gather of `chunk` done -> copy it to its host ring slot (rank 0)."""
+    def hand_out(chunk: int):
+        """Gather of `chunk` done (in stream order on the reader stream) -> its view of the gather buffer."""
         slot = chunk & 1
         if works[slot] is not None:
             works[slot].wait()
             works[slot] = None
-        if rank != 0:
-            return
-        ring = chunk % ring_slots
-        if on_gpu:
-            copy_stream.wait_stream(torch.cuda.current_stream(device))
-            with torch.cuda.stream(copy_stream):
-                host_ring[ring].copy_(gathered[slot], non_blocking=True)
-                event = torch.cuda.Event()
-                event.record(copy_stream)
-            copied[ring] = event
-        else:
-            host_ring[ring].copy_(gathered[slot])
-
-    def emit(chunk: int):
-        ring = chunk % ring_slots
-        if copied[ring] is not None:
-            copied[ring].synchronize()
-            copied[ring] = None
         first = chunk * per_chunk
         count = min(num_frames, first + per_chunk) - first
-        return first, host_ring[ring][:count].numpy()
+        if reader_stream is not None:
+            reader_stream.wait_stream(torch.cuda.current_stream(device))
+        return first, gathered[slot][:count], reader_stream
 
     for chunk in range(chunks):
         slot = chunk & 1
         start, end = stream_piece(num_frames, world_size, frames_per_rank, chunk, rank)
         count = end - start
-        if on_gpu and copy_stream is not None and rank == 0 and chunk >= 2:
-            # the drain of chunk-2 read gathered[slot]: the gather below may only overwrite it afterwards
-            torch.cuda.current_stream(device).wait_stream(copy_stream)
+        if reader_stream is not None and chunk >= 2:
+            # the consumer of chunk-2 read gathered[slot] on the reader stream: the gather below may only overwrite it afterwards
+            torch.cuda.current_stream(device).wait_stream(reader_stream)
+        if works[slot] is not None:  # (ranks > 0 hand nothing out: retire the gather that last read local[slot] here)
+            works[slot].wait()
+            works[slot] = None
+        failure = None
         if count:
-            frames = synthesize_piece(produced, count)
-            local[slot][:count].copy_(frames)
+            try:
+                frames = synthesize_piece(produced, count)
+                local[slot][:count].copy_(frames)
+            except Exception as error:  # pylint: disable=broad-except
+                failure = error
             produced += count
+        try:
+            exchange_status(failure is not None, f"synthesising chunk {chunk}")
+        except StreamRankError:
+            if failure is None:
+                raise
+        if failure is not None:
+            raise failure
         if world_size > 1:
             works[slot] = dist.gather(local[slot], gather_list=list(gathered[slot].chunk(world_size, dim=0)) if rank == 0 else None, dst=0, async_op=True)
         elif rank == 0:
             gathered[slot][:frames_per_rank].copy_(local[slot])
-        if chunk >= 1:
-            drain(chunk - 1)
-        if rank == 0 and chunk >= 2:
-            yield emit(chunk - 2)
-    if chunks >= 1:
-        drain(chunks - 1)
-    if rank == 0:
-        for chunk in range(max(0, chunks - 2), chunks):
-            yield emit(chunk)
+        if rank == 0 and chunk >= 1:
+            yield hand_out(chunk - 1)
+    if rank == 0 and chunks >= 1:
+        yield hand_out(chunks - 1)
+    for work in works:
+        if work is not None:
+            work.wait()
+
+
+class HostRing:
+    """
+    Pinned host buffers that device chunks are drained to on the reader stream, one chunk behind: `push` starts the
+    copy of a chunk and returns the PREVIOUS chunk as a numpy view once its copy has landed (None the first time),
+    `flush` returns the last one. A returned view stays valid until `push` has been called `slots - 1` more times.
+    """
+
+    def __init__(self, chunk_frames: int, frame_shape: Tuple[int, int, int], device: torch.device, slots: int = 3) -> None:
+        self._on_gpu = device.type == "cuda"
+        self._ring = [torch.empty((chunk_frames, *frame_shape), dtype=torch.uint8, pin_memory=self._on_gpu) for _ in range(slots)]
+        self._next = 0
+        self._pending = None  # (first, count, slot, event)
+
+    def _finish(self):
+        if self._pending is None:
+            return None
+        first, count, slot, event = self._pending
+        self._pending = None
+        if event is not None:
+            event.synchronize()
+        return first, self._ring[slot][:count].numpy()
+
+    def push(self, first: int, frames: torch.Tensor, reader_stream):
+        """Start draining `frames` (device) into the next slot; returns the previous chunk (first, numpy view) or None."""
+        done = self._finish()
+        slot = self._next
+        self._next = (self._next + 1) % len(self._ring)
+        count = int(frames.shape[0])
+        event = None
+        if self._on_gpu and reader_stream is not None:
+            with torch.cuda.stream(reader_stream):
+                self._ring[slot][:count].copy_(frames, non_blocking=True)
+                event = torch.cuda.Event()
+                event.record(reader_stream)
+        else:
+            self._ring[slot][:count].copy_(frames)
+        self._pending = (first, count, slot, event)
+        return done
+
+    def flush(self):
+        """The last chunk pushed (first, numpy view), or None."""
+        return self._finish()
+
+
+def ordered_frame_stream(synthesize_piece, num_frames: int, frames_per_rank: int, frame_shape: Tuple[int, int, int], device: torch.device):
+    """
+    `ordered_device_chunks` drained to the host (collective: every rank must exhaust it). On rank 0 it yields
+    (first_frame_index, frames) per chunk, in frame order, `frames` a uint8 numpy view of a pinned host ring slot
+    [n, *frame_shape] that stays valid until the generator is advanced twice more; other ranks yield nothing.
+    Chunk k's gather and host drain overlap chunk k+1's synthesis. HBM holds two chunks, the host three.
+    """
+    world_size = dist.get_world_size() if dist.is_initialized() else 1
+    ring = None
+    for first, frames, reader_stream in ordered_device_chunks(synthesize_piece, num_frames, frames_per_rank, frame_shape, device):
+        if ring is None:
+            ring = HostRing(world_size * frames_per_rank, frame_shape, device)
+        done = ring.push(first, frames, reader_stream)
+        if done is not None:
+            yield done
+    if ring is not None:
+        last = ring.flush()
+        if last is not None:
+            yield last

@@ -7,15 +7,18 @@ projection-file-blend end to end: WAV(s) + projection file + network(s) -> frame
 * synthesis is batched, every network is resident, and with `torch.distributed` initialised the
   frames are sharded across ranks and gathered in order on rank 0 (gance_amd/frame_sharding.py);
 * the resize to `output_side_length` is the HIP bicubic kernel, on the frames still in HBM;
-* the eye-tracking overlay runs on rank 0 on the gathered frames while they are still in HBM
-  (perceptual hashes and the overlay write are HIP kernels; the landmark detector is external);
+* the eye-tracking overlay runs on rank 0, chunk by chunk, on the gathered frames while they are still in HBM
+  (perceptual hashes and the overlay write are HIP kernels; the landmark detector is external); the stream stays
+  lazy with the overlay on, as the reference's iterator chain does (gance/projection_file_blend.py:223-275): the
+  run-length filter only ever holds back the frames of a run that is still shorter than `track_length`;
 * video encoding (ffmpeg / x264) and the matplotlib debug video are out of scope here: frames are
   returned / written as a `.npy` uint8 array [N][S][S][3], and asking for the debug video raises
   NotImplementedError.
 """
 
+import time
 from pathlib import Path
-from typing import Iterator, List, NamedTuple, Optional, Tuple
+from typing import Dict, Iterator, List, NamedTuple, Optional, Tuple
 
 import numpy as np
 import pandas as pd
@@ -27,6 +30,10 @@ from gance_amd.data_into_network_visualization import visualization_inputs
 from gance_amd.data_into_network_visualization.visualization_common import DataLabel, ResultLayers
 from gance_amd.logger_common import LOGGER
 from gance_amd.network_interface.network_functions import DEFAULT_MAX_BATCH, TRUNCATION_PSI, MultiNetwork
+
+# frames per engine call and rank of the frame stream: the batch the kernels are tuned for (one block per CU on every
+# layer from 64^2 up; 32: -2 %, 16: -8 %); the activation workspace it needs is 51 GB of the 288 GB at 1024^2
+DEFAULT_STREAM_BATCH = 64
 from gance_amd.projection import projection_file_reader
 from gance_amd.overlay import overlay_common, overlay_eye_tracking
 from gance_amd.vector_sources import music, vector_reduction
@@ -265,10 +272,12 @@ def _prepare_blend_inputs(  # pylint: disable=too-many-arguments,too-many-locals
     blend_depth: int,
     want_target_images: bool,
     device: torch.device,
+    timings: Optional[Dict[str, float]] = None,
 ) -> _BlendInputs:
     """Rank 0: projection file + WAV -> per-frame latent matrices and network indices in HBM (the reference's checks included)."""
     vector_length = networks.expected_vector_length
     target_images = None
+    clock = time.perf_counter()
     # the audio -> latent stage has global dependencies over a few MB: once, on rank 0
     with projection_file_reader.load_projection_file(Path(projection_file_path)) as reader:
         final_latents = projection_file_reader.final_latents_matrices_label(reader)
@@ -284,21 +293,141 @@ def _prepare_blend_inputs(  # pylint: disable=too-many-arguments,too-many-locals
         raise ValueError("Invalid Projection File, cannot continue.")
     frame_multiplier = divisor.divide_no_remainder(numerator=output_fps, denominator=attributes.projection_fps)
     num_output_frames = int(frame_multiplier * final_latents_in_file)
+    if timings is not None:
+        timings["read_projection_file_ms"] = (time.perf_counter() - clock) * 1e3
+        clock = time.perf_counter()
     audio = music.read_wavs_scale_for_video(
         wavs=[Path(path) for path in wav], vector_length=vector_length, target_num_vectors=num_output_frames
     ).wav_data
+    if timings is not None:
+        timings["read_and_stretch_wav_ms"] = (time.perf_counter() - clock) * 1e3
+        clock = time.perf_counter()
+    blend_timings: Optional[Dict[str, float]] = {} if timings is not None else None
     blend = visualization_inputs.alpha_blend_projection_file_device(
         final_latents.data, alpha, fft_roll_enabled, fft_amplitude_range, blend_depth, audio, vector_length,
-        len(networks.network_indices), device=device.index,
+        len(networks.network_indices), device=device.index, timings=blend_timings,
     )
     dlatents, indices = blend.dlatents, blend.network_indices
     blend.blend.close()
+    if timings is not None:
+        timings["audio_to_latents_ms"] = (time.perf_counter() - clock) * 1e3
+        timings["audio_to_latents_split_ms"] = blend_timings
     if frames_to_visualize is not None:
         dlatents, indices = dlatents[:frames_to_visualize], indices[:frames_to_visualize]
     return _BlendInputs(dlatents, indices, int(dlatents.shape[0]), target_images, audio, int(frame_multiplier))
 
 
-def projection_file_blend_frame_chunks(  # pylint: disable=too-many-arguments,too-many-locals
+class _WindowSynthesizer:  # pylint: disable=too-few-public-methods
+    """
+    `synthesize_piece(offset, count)` of the frame stream, batched by network ACROSS a window of pieces: the rank's
+    frames [offset, offset + window * frames_per_call) are synthesised network by network into one buffer the
+    first time a piece of the window is asked for, and the pieces are served from it. With several networks and an
+    RMS-driven index that switches every few frames a single piece splits into as many short engine calls as it has
+    networks; over a window the calls stay (nearly) full batches -- what the reference's sort-by-network does over
+    the whole video (network_visualization.py:653-674), bounded to `window` pieces of HBM.
+    """
+
+    def __init__(self, dlatents: torch.Tensor, indices: torch.Tensor, networks: MultiNetwork, side: int, frames_per_call: int, window: int) -> None:
+        self._dlatents, self._indices, self._networks, self._side = dlatents, indices, networks, side
+        self._frames_per_call, self._window = frames_per_call, max(1, window)
+        self._start, self._frames = 0, None
+
+    def __call__(self, offset: int, count: int) -> torch.Tensor:
+        if self._frames is None or not self._start <= offset < self._start + int(self._frames.shape[0]):
+            stop = min(int(self._dlatents.shape[0]), offset + self._window * self._frames_per_call)
+            self._start = offset
+            self._frames = synthesize_device_frames_network_major(
+                self._dlatents[offset:stop], self._indices[offset:stop], self._networks, self._side, self._frames_per_call
+            )
+        return self._frames[offset - self._start : offset - self._start + count]
+
+
+def decided_prefix(gated: List[bool], track_length: int, final: bool) -> int:
+    """
+    How many leading frames of a gate sequence seen SO FAR already have their final `track_length_filter` value
+    (vector_reduction.py:261-274: runs of True shorter than `track_length` become False): all of them, unless the
+    sequence ends in a run of True that is still shorter than `track_length` and may yet grow -- then everything
+    before that run. At the end of the stream (`final`) a short trailing run is judged by the length it has.
+    """
+    known = len(gated)
+    if final:
+        return known
+    run = 0
+    while run < known and gated[known - 1 - run]:
+        run += 1
+    return known if run >= track_length or run == 0 else known - run
+
+
+class _StreamingOverlay:
+    """
+    The overlay stage of gance/projection_file_blend.py:181-275 as a stage of the frame stream on rank 0: chunks of
+    synthesized frames go in (in HBM), chunks with the eye regions written come out, in order, as soon as every frame
+    of a chunk is DECIDED. The gate (landmarks, box distance, perceptual hashes) is evaluated per chunk as it arrives;
+    `track_length_filter` (vector_reduction.py:261-274) drops runs of gated frames shorter than `track_length`, so a
+    gated frame is undecided only while its run is still open and shorter than that: the stage holds back at most the
+    chunks such a run spans (track_length - 1 frames of look-ahead), never the video.
+    """
+
+    def __init__(  # pylint: disable=too-many-arguments
+        self, target_images: np.ndarray, frame_multiplier: int, parameters: OverlayParameters, skip_mask: List[bool], num_frames: int, side: int,
+        device: torch.device,
+    ) -> None:
+        self._targets, self._multiplier, self._parameters = target_images, frame_multiplier, parameters
+        self._skip_mask, self._num_frames, self._side, self._device = skip_mask, num_frames, side, device
+        self._gated: List[bool] = []  # per frame seen so far: not skipped and the gate passed
+        self._pending: List[Tuple[int, torch.Tensor, torch.Tensor, list]] = []  # (first, background, foreground, boxes per frame)
+        self.chunks_held_max = 0
+        self.overlays_written = 0
+        if -(-num_frames // frame_multiplier) > len(target_images):
+            raise ValueError("the projection file holds too few target images for the frames being written")
+
+    def _foreground(self, first: int, count: int) -> torch.Tensor:
+        """Target images of frames [first, first + count): each shown `frame_multiplier` times, scaled to the output side."""
+        lo, hi = first // self._multiplier, (first + count - 1) // self._multiplier + 1
+        targets = torch.from_numpy(np.ascontiguousarray(self._targets[lo:hi])).to(self._device)
+        if targets.shape[1] != self._side:
+            targets = torch.ops.gance.resize_bicubic(targets, self._side)
+        repeated = targets.repeat_interleave(self._multiplier, dim=0)
+        skip = first - lo * self._multiplier
+        return repeated[skip : skip + count].contiguous()
+
+    def _decided(self, final: bool) -> int:
+        return decided_prefix(self._gated, self._parameters.track_length, final)
+
+    def _release(self, final: bool) -> List[Tuple[int, torch.Tensor]]:
+        decided = self._decided(final)
+        # the filter is local to runs: on the frames known so far it already gives every decided frame its final value
+        keep = vector_reduction.track_length_filter(bool_tracks=self._gated, track_length=self._parameters.track_length)
+        out = []
+        while self._pending and self._pending[0][0] + int(self._pending[0][1].shape[0]) <= decided:
+            first, background, foreground, boxes_list = self._pending.pop(0)
+            written = [boxes if keep[first + i] else None for i, boxes in enumerate(boxes_list)]
+            self.overlays_written += sum(boxes is not None for boxes in written)
+            out.append((first, overlay_common.write_boxes_onto_frames_device(foreground, background, written)))
+        return out
+
+    def push(self, first: int, frames: torch.Tensor) -> List[Tuple[int, torch.Tensor]]:
+        """One gathered chunk in (a view that is only valid now: it is copied), the chunks that became ready out."""
+        count = int(frames.shape[0])
+        background = frames.clone()
+        foreground = self._foreground(first, count)
+        skips = self._skip_mask[first : first + count]
+        result = overlay_eye_tracking.compute_eye_tracking_overlay(
+            foreground_images=foreground, background_images=background, min_phash_distance=self._parameters.phash_distance,
+            min_bbox_distance=self._parameters.bbox_distance, skip_mask=skips, face_finder=self._parameters.face_finder,
+        )
+        boxes_list = list(result.bbox_lists)
+        self._gated.extend(not skip and boxes is not None for skip, boxes in zip(skips, boxes_list))
+        self._pending.append((first, background, foreground, boxes_list))
+        self.chunks_held_max = max(self.chunks_held_max, len(self._pending))
+        return self._release(final=False)
+
+    def flush(self) -> List[Tuple[int, torch.Tensor]]:
+        """End of the stream: a run still open is judged by the length it has."""
+        return self._release(final=True)
+
+
+def projection_file_blend_frame_chunks(  # pylint: disable=too-many-arguments,too-many-locals,too-many-statements
     wav: List[str],
     network_paths: List[Path],
     frames_to_visualize: Optional[int],
@@ -309,46 +438,111 @@ def projection_file_blend_frame_chunks(  # pylint: disable=too-many-arguments,to
     fft_amplitude_range: Tuple[int, int],
     projection_file_path: str,
     blend_depth: int,
-    frames_per_call: int = DEFAULT_MAX_BATCH,
+    frames_per_call: int = DEFAULT_STREAM_BATCH,
+    overlay: Optional[OverlayParameters] = None,
+    networks: Optional[MultiNetwork] = None,
+    timings: Optional[Dict[str, object]] = None,
 ) -> Iterator[Tuple[int, int, np.ndarray]]:
     """
     The frame stream of the reference's pipeline (gance/projection_file_blend.py:343 hands an iterator of frames to
     the video writer): a generator of (first_frame_index, total_frames, frames [n, S, S, 3] uint8) in frame order.
     Nothing holds all frames: per chunk, every rank synthesises `frames_per_call` frames, one gather lands the chunk
-    in order on rank 0 while the next chunk is already being synthesised, and rank 0 drains it to a pinned host
-    ring (`frames` is a view of a ring slot: consume or copy it before advancing the generator twice more).
-    Collective under `torch.distributed`: every rank must exhaust the generator; only rank 0 receives chunks.
+    in order on rank 0 while the next chunk is already being synthesised, rank 0 runs the eye-tracking overlay on it
+    if `overlay` is given (in HBM; see _StreamingOverlay) and drains it to a pinned host ring (`frames` is a view of
+    a ring slot: consume or copy it before advancing the generator twice more). With several networks the engine
+    calls are batched by network across a window of pieces (_WindowSynthesizer).
+    Collective under `torch.distributed`: every rank must exhaust the generator; only rank 0 receives chunks. If a rank
+    fails, every rank leaves the generator with an exception (frame_sharding.exchange_status).
+    :param networks: networks already resident (not unloaded at the end); default: load `network_paths`, unload after.
+    :param timings: if given, rank 0 records the wall-clock split of the call there (milliseconds).
     """
     rank = dist.get_rank() if dist.is_initialized() else 0
     world_size = dist.get_world_size() if dist.is_initialized() else 1
     device = torch.device("cuda", torch.cuda.current_device())
-    networks = MultiNetwork(network_paths=network_paths, load=True, max_batch=frames_per_call)
+    own_networks = networks is None
+    if own_networks:
+        networks = MultiNetwork(network_paths=network_paths, load=True, max_batch=frames_per_call)
     try:
         inputs = _BlendInputs(None, None, 0, None, None, 1)
+        failure = None
         if rank == 0:
-            inputs = _prepare_blend_inputs(
-                wav, networks, frames_to_visualize, output_fps, alpha, fft_roll_enabled, fft_amplitude_range,
-                projection_file_path, blend_depth, False, device,
-            )
+            try:
+                inputs = _prepare_blend_inputs(
+                    wav, networks, frames_to_visualize, output_fps, alpha, fft_roll_enabled, fft_amplitude_range,
+                    projection_file_path, blend_depth, overlay is not None, device, timings,
+                )
+            except Exception as error:  # pylint: disable=broad-except
+                failure = error
+        try:  # (a bad projection file or WAV on rank 0 must not leave the other ranks waiting in the broadcast below)
+            frame_sharding.exchange_status(failure is not None, "preparing the blend")
+        except frame_sharding.StreamRankError:
+            if failure is None:
+                raise
+        if failure is not None:
+            raise failure
         num_frames = inputs.num_frames
         if world_size > 1:
             count = [num_frames]
             dist.broadcast_object_list(count, src=0)
             num_frames = count[0]
+        clock = time.perf_counter()
         dlatents = frame_sharding.scatter_for_stream(inputs.dlatents, num_frames, frames_per_call, device)
         indices = frame_sharding.scatter_for_stream(inputs.indices, num_frames, frames_per_call, device)
         side = _common_output_side(networks, np.asarray(networks.network_indices), output_side_length)
-
-        def synthesize_piece(offset: int, count: int) -> torch.Tensor:
-            return synthesize_device_frames_network_major(
-                dlatents[offset : offset + count], indices[offset : offset + count], networks, side, frames_per_call
+        num_networks = len(set(networks.network_paths))
+        synthesize_piece = _WindowSynthesizer(dlatents, indices, networks, side, frames_per_call, 1 if num_networks == 1 else 2 * num_networks)
+        stage = None
+        if overlay is not None and rank == 0:
+            music_mask = overlay.complexity_change_rolling_sum_window is not None and overlay.complexity_change_threshold is not None
+            skip_mask = (
+                music_complexity_skip_mask(
+                    inputs.audio, networks.expected_vector_length, overlay.complexity_change_rolling_sum_window, overlay.complexity_change_threshold
+                )[:num_frames]
+                if music_mask
+                else [False] * num_frames
             )
-
-        for first, frames in frame_sharding.ordered_frame_stream(synthesize_piece, num_frames, frames_per_call, (side, side, 3), device):
-            yield first, num_frames, frames
+            stage = _StreamingOverlay(inputs.target_images, inputs.frame_multiplier, overlay, skip_mask, num_frames, side, device)
+        ring = None
+        bytes_to_host = 0
+        for first, frames, reader_stream in frame_sharding.ordered_device_chunks(synthesize_piece, num_frames, frames_per_call, (side, side, 3), device):
+            if ring is None:
+                ring = frame_sharding.HostRing(world_size * frames_per_call, (side, side, 3), device, slots=3)
+            if stage is None:
+                ready = [(first, frames)]
+            else:
+                with torch.cuda.stream(reader_stream):  # (the chunk view may only be read on the reader stream)
+                    ready = stage.push(first, frames)
+            for ready_first, ready_frames in ready:
+                done = ring.push(ready_first, ready_frames, reader_stream)
+                bytes_to_host += ready_frames.numel()
+                if done is not None:
+                    yield done[0], num_frames, done[1]
+        if stage is not None:
+            with torch.cuda.stream(reader_stream):
+                ready = stage.flush()
+            for ready_first, ready_frames in ready:
+                done = ring.push(ready_first, ready_frames, reader_stream)
+                bytes_to_host += ready_frames.numel()
+                if done is not None:
+                    yield done[0], num_frames, done[1]
+            LOGGER.info(f"Eye tracking overlay written on {stage.overlays_written} of {num_frames} frames")
+        if ring is not None:
+            last = ring.flush()
+            if last is not None:
+                yield last[0], num_frames, last[1]
         torch.cuda.synchronize(device)
+        if timings is not None and rank == 0:
+            elapsed = time.perf_counter() - clock
+            timings["synthesis_to_host_ms"] = elapsed * 1e3
+            timings["frames"] = num_frames
+            timings["bytes_to_host"] = bytes_to_host
+            timings["d2h_gb_per_s"] = bytes_to_host / elapsed / 1e9 if elapsed > 0 else None
+            if stage is not None:
+                timings["overlay_chunks_held_max"] = stage.chunks_held_max
+                timings["overlays_written"] = stage.overlays_written
     finally:
-        networks.unload()
+        if own_networks:
+            networks.unload()
 
 
 def projection_file_blend_frames(  # pylint: disable=too-many-arguments,too-many-locals
@@ -363,48 +557,30 @@ def projection_file_blend_frames(  # pylint: disable=too-many-arguments,too-many
     projection_file_path: str,
     blend_depth: int,
     overlay: Optional[OverlayParameters] = None,
+    frames_per_call: int = DEFAULT_STREAM_BATCH,
 ) -> Optional[np.ndarray]:
     """
     The pipeline of `projection_file_blend_api`, returning ALL frames [N][S][S][3] uint8 at once (on rank 0;
-    None on other ranks when running distributed): the stream of `projection_file_blend_frame_chunks` collected
-    into one array. With `overlay`, rank 0 runs the eye-tracking overlay on the gathered frames before they
-    leave HBM (the run-length filter of the overlay needs every frame's gate decision before the first write,
-    so that path keeps the frames resident instead of streaming them).
+    None on other ranks when running distributed): the stream of `projection_file_blend_frame_chunks` (overlay
+    included) collected into one host array.
     """
-    if overlay is None:
-        collected: Optional[np.ndarray] = None
-        for first, total, frames in projection_file_blend_frame_chunks(
-            wav, network_paths, frames_to_visualize, output_fps, output_side_length, alpha, fft_roll_enabled,
-            fft_amplitude_range, projection_file_path, blend_depth,
-        ):
-            if collected is None:
-                collected = np.empty((total, *frames.shape[1:]), dtype=np.uint8)
-            collected[first : first + len(frames)] = frames
-        rank = dist.get_rank() if dist.is_initialized() else 0
-        if rank == 0 and collected is None:
-            collected = np.empty((0, output_side_length, output_side_length, 3), dtype=np.uint8)
-        return collected
+    collected: Optional[np.ndarray] = None
+    for first, total, frames in projection_file_blend_frame_chunks(
+        wav, network_paths, frames_to_visualize, output_fps, output_side_length, alpha, fft_roll_enabled,
+        fft_amplitude_range, projection_file_path, blend_depth, frames_per_call=frames_per_call, overlay=overlay,
+    ):
+        if collected is None:
+            collected = np.empty((total, *frames.shape[1:]), dtype=np.uint8)
+        collected[first : first + len(frames)] = frames
     rank = dist.get_rank() if dist.is_initialized() else 0
-    device = torch.device("cuda", torch.cuda.current_device())
-    networks = MultiNetwork(network_paths=network_paths, load=True)
-    try:
-        inputs = _BlendInputs(None, None, 0, None, None, 1)
-        if rank == 0:
-            inputs = _prepare_blend_inputs(
-                wav, networks, frames_to_visualize, output_fps, alpha, fft_roll_enabled, fft_amplitude_range,
-                projection_file_path, blend_depth, True, device,
-            )
-        frames = shard_synthesize_gather(
-            inputs.dlatents, inputs.indices, inputs.num_frames, networks, output_side_length, device, keep_on_device=True
-        )
-        if frames is None:
-            return None
-        blended = apply_eye_tracking_overlay(
-            frames, inputs.target_images, inputs.frame_multiplier, overlay, inputs.audio, networks.expected_vector_length
-        )
-        return blended.cpu().numpy()
-    finally:
-        networks.unload()
+    if rank == 0 and collected is None:
+        collected = np.empty((0, output_side_length, output_side_length, 3), dtype=np.uint8)
+    return collected
+
+
+def _npy_path(output_path: str) -> str:
+    """`np.save` appends `.npy` when the suffix is missing: the streamed writer lands in the same file."""
+    return output_path if output_path.endswith(".npy") else output_path + ".npy"
 
 
 def projection_file_blend_api(  # pylint: disable=too-many-arguments,too-many-locals
@@ -451,24 +627,20 @@ def projection_file_blend_api(  # pylint: disable=too-many-arguments,too-many-lo
         if overlay_enabled
         else None
     )
-    if overlay is None:
-        # frame chunks go straight from the pinned ring into the (memory-mapped) output file: nothing holds the video
-        writer = None
-        for first, total, frames in projection_file_blend_frame_chunks(
-            wav, network_paths, frames_to_visualize, output_fps, output_side_length, alpha, fft_roll_enabled,
-            fft_amplitude_range, projection_file_path, blend_depth,
-        ):
-            if output_path is None:
-                continue
-            if writer is None:
-                writer = np.lib.format.open_memmap(output_path, mode="w+", dtype=np.uint8, shape=(total, *frames.shape[1:]))
-            writer[first : first + len(frames)] = frames
-        if writer is not None:
-            writer.flush()
-        return
-    frames = projection_file_blend_frames(
+    # frame chunks go straight from the pinned ring into the (memory-mapped) output file: nothing holds the video
+    writer = None
+    total_frames = 0
+    for first, total, frames in projection_file_blend_frame_chunks(
         wav, network_paths, frames_to_visualize, output_fps, output_side_length, alpha, fft_roll_enabled,
-        fft_amplitude_range, projection_file_path, blend_depth, overlay,
-    )
-    if frames is not None and output_path is not None:
-        np.save(output_path, frames)
+        fft_amplitude_range, projection_file_path, blend_depth, overlay=overlay,
+    ):
+        total_frames = total
+        if output_path is None:
+            continue
+        if writer is None:
+            writer = np.lib.format.open_memmap(_npy_path(output_path), mode="w+", dtype=np.uint8, shape=(total, *frames.shape[1:]))
+        writer[first : first + len(frames)] = frames
+    if writer is not None:
+        writer.flush()
+    elif output_path is not None and total_frames == 0 and (not dist.is_initialized() or dist.get_rank() == 0):
+        np.save(_npy_path(output_path), np.empty((0, output_side_length, output_side_length, 3), dtype=np.uint8))

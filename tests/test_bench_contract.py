@@ -19,6 +19,7 @@ def _bench_module():
 def test_step_names_map_to_kernels_and_executed_flops() -> None:
     bench = _bench_module()
     assert bench.kernel_of_step("convTF15_1024x1024_64->32") == "upfir_fused_kernel"
+    assert bench.kernel_of_step("convTFp15_1024x1024_64->32") == "upfir_fused_pre_kernel"
     assert bench.kernel_of_step("convW16+rgb_1024x1024_32->32") == "winograd64_c32_rgb_kernel"
     assert bench.kernel_of_step("convW8+rgb_64x64_512->512") == "winograd64_rgb_kernel"
     assert bench.kernel_of_step("convW14_512x512_64->64") == "winograd64_kernel"
@@ -33,12 +34,12 @@ def test_traffic_record_covers_the_dominant_launches_of_the_default_workload() -
     bench = _bench_module()
     record = json.loads((REPO_ROOT / "profiles" / "traffic_latest.json").read_text())
     workload = record["workload"]
-    for step in ("convW16+rgb_1024x1024_32->32", "convTF15_1024x1024_64->32"):
-        measured = bench.measured_traffic(step, workload["resolution"], workload["frames_per_step_per_gpu"])
-        assert measured is not None and measured > 0
+    for step in ("convW16+rgb_1024x1024_32->32", "convTF15_1024x1024_64->32", "convTFp15_1024x1024_64->32"):
+        measured, note = bench.measured_traffic(step, workload["resolution"], workload["frames_per_step_per_gpu"])
+        assert measured is not None and measured > 0 and "profiles/" in note
     for entry in record["launches"].values():
         # HBM traffic within a quarter of the algorithmic bytes (tensors read once, written once): the kernels re-read little
         assert 1.0 <= entry["hbm_bytes_per_launch"] / entry["algorithmic_bytes_per_launch"] < 1.25
         assert 0.3 < entry["mfma_busy_fraction"] < 1.0
     # another workload: no figure rather than a wrong one
-    assert bench.measured_traffic("convW16+rgb_1024x1024_32->32", 512, workload["frames_per_step_per_gpu"]) is None
+    assert bench.measured_traffic("convW16+rgb_1024x1024_32->32", 512, workload["frames_per_step_per_gpu"])[0] is None

@@ -184,6 +184,66 @@ def test_projection_file_blend_with_eye_tracking_overlay(tmp_path: Path) -> None
         )
 
 
+def test_streaming_overlay_with_three_networks_equals_the_one_shot_overlay(tmp_path: Path) -> None:
+    """
+    configs[4] in miniature through the STREAM: three resident networks switched by the RMS index, engine calls
+    batched by network across a window of pieces, the overlay gate evaluated chunk by chunk (4 frames per chunk, runs
+    of gated frames shorter than 5 dropped, so decisions span chunk borders). Frames must equal the one-shot form
+    (every frame resident, `apply_eye_tracking_overlay` on the lot), and the stage may never hold more than the chunks
+    an undecided run spans.
+    """
+    L, num_projection, fps_in, fps_out, side = 512, 30, 15.0, 30.0, 64
+    num_frames = int(num_projection * fps_out / fps_in)
+    audio = synthetic.synthetic_audio(num_frames, L, seed=81, frames_per_second=fps_out)
+    wav_path = tmp_path / "audio.wav"
+    wavfile.write(str(wav_path), int(L * fps_out), audio)
+    latents = synthetic.synthetic_final_latents(num_projection, L, seed=82)
+    rng = np.random.RandomState(83)
+    targets = (np.kron(rng.rand(num_projection, 8, 8, 3), np.ones((1, 8, 8, 1))) * 255).astype(np.uint8)  # 64 x 64
+    projection_path = tmp_path / "projection.npz"
+    pfr.write_projection_npz(
+        projection_path, latents.reshape(18, num_projection, L).transpose(1, 0, 2), projection_fps=fps_in, target_images=targets
+    )
+    network_paths = []
+    for seed in range(3):
+        network_paths.append(tmp_path / f"net_{seed}.pkl")
+        network_file.write_random_network(network_paths[-1], side, seed=20 + seed)
+
+    class FaceWhereThePictureIsBright:  # pylint: disable=too-few-public-methods
+        @staticmethod
+        def face_landmarks(face_image):
+            if int(face_image[0, 0].sum()) < 200:
+                return []
+            return [{"left_eye": ((12, 20), (24, 26)), "right_eye": ((36, 21), (50, 28))}]
+
+    common = dict(
+        wav=[str(wav_path)], network_paths=network_paths, frames_to_visualize=None, output_fps=fps_out,
+        output_side_length=side, alpha=0.25, fft_roll_enabled=True, fft_amplitude_range=(-5, 5),
+        projection_file_path=str(projection_path), blend_depth=12,
+    )
+    overlay = projection_file_blend.OverlayParameters(
+        phash_distance=64, bbox_distance=5.0, track_length=5, face_finder=FaceWhereThePictureIsBright()
+    )
+    background = projection_file_blend.projection_file_blend_frames(**common)  # one chunk, no overlay
+    want = projection_file_blend.apply_eye_tracking_overlay(
+        torch.from_numpy(background).cuda(), targets, int(fps_out / fps_in), overlay, audio, L
+    ).cpu().numpy()
+    assert (want != background).any(), "the test should exercise at least one written overlay"
+
+    timings: dict = {}
+    streamed = np.zeros_like(background)
+    firsts = []
+    for first, total, frames in projection_file_blend.projection_file_blend_frame_chunks(**common, frames_per_call=4, overlay=overlay, timings=timings):
+        assert total == num_frames
+        streamed[first : first + len(frames)] = frames
+        firsts.append(first)
+    assert firsts == list(range(0, num_frames, 4))
+    assert np.array_equal(streamed, want)
+    assert 1 <= timings["overlay_chunks_held_max"] <= 3 and timings["overlays_written"] > 0
+    # and the network-major windows (2 x 3 pieces) gave the frames of the piece-by-piece path
+    assert np.array_equal(projection_file_blend.projection_file_blend_frames(**common, frames_per_call=4), background)
+
+
 def test_blend_from_a_real_hdf5_projection_file(tmp_path: Path, golden_dir: Path) -> None:
     """The reference's own container end to end: an h5py-written projection file (12 projected frames, 15 fps) -> 24 frames at 30 fps."""
     L, fps_out, side = 512, 30.0, 64

@@ -126,3 +126,48 @@ def _stream_worker(rank: int, world_size: int, port: int, num_frames: int, per_r
 def test_ordered_frame_stream_gloo(world_size: int, num_frames: int, per_rank: int) -> None:
     """The product's multi-rank path: scatter of per-chunk latent pieces, chunked synthesis, ordered gather, host drain."""
     mp.spawn(_stream_worker, args=(world_size, _free_port(), num_frames, per_rank), nprocs=world_size, join=True)
+
+
+def _failing_stream_worker(rank: int, world_size: int, port: int, failing_rank: int, results) -> None:
+    import datetime  # pylint: disable=import-outside-toplevel
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world_size, timeout=datetime.timedelta(seconds=60))
+    try:
+        device = torch.device("cpu")
+        calls = []
+
+        def synthesize_piece(offset: int, count: int) -> torch.Tensor:
+            calls.append(offset)
+            if rank == failing_rank and len(calls) == 2:
+                raise ValueError("engine call refused")
+            return torch.zeros((count, 2, 2, 3), dtype=torch.uint8)
+
+        outcome = "finished"
+        try:
+            for _ in frame_sharding.ordered_frame_stream(synthesize_piece, 40, 4, (2, 2, 3), device):
+                pass
+        except frame_sharding.StreamRankError as error:
+            outcome = f"relayed: {error}"
+        except ValueError as error:
+            outcome = f"own: {error}"
+        results[rank] = (outcome, len(calls))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("failing_rank", [0, 1])
+def test_a_failing_rank_ends_the_stream_on_every_rank(failing_rank: int) -> None:
+    """
+    An exception inside one rank's synthesis must not leave the others blocked in the next gather: the per-chunk
+    status exchange makes every rank leave the generator in the same chunk -- the failing rank with its own
+    exception, the others with StreamRankError naming it.
+    """
+    world_size = 2
+    manager = mp.Manager()
+    results = manager.dict()
+    mp.spawn(_failing_stream_worker, args=(world_size, _free_port(), failing_rank, results), nprocs=world_size, join=True)
+    assert results[failing_rank] == ("own: engine call refused", 2)
+    other = 1 - failing_rank
+    assert results[other][0].startswith(f"relayed: rank {failing_rank} failed synthesising chunk 1") and results[other][1] == 2

@@ -98,3 +98,25 @@ def test_phash_oracle_is_a_perceptual_hash() -> None:
     brighter = np.clip(image.astype(int) + 10, 0, 255).astype(np.uint8)
     assert overlay_ref.phash_distance(base, overlay_ref.phash(brighter, box)) <= 6
     assert overlay_ref.phash_distance(base, overlay_ref.phash(other, box)) >= 16
+
+
+def test_streaming_gate_decisions_are_final_when_released() -> None:
+    """
+    The overlay stage of the frame stream releases frames as soon as `decided_prefix` says their run-length filter
+    value can no longer change: on every prefix of random gate sequences the released part of the filtered prefix
+    equals the filtered WHOLE sequence, and never more than track_length - 1 frames are held back.
+    """
+    from gance_amd.projection_file_blend import decided_prefix  # pylint: disable=import-outside-toplevel
+    from gance_amd.vector_sources.vector_reduction import track_length_filter  # pylint: disable=import-outside-toplevel
+
+    rng = np.random.RandomState(5)
+    for track_length in (1, 2, 3, 7):
+        for density in (0.3, 0.6, 0.9):
+            gated = [bool(v) for v in rng.rand(200) < density]
+            final = track_length_filter(gated, track_length)
+            for seen in range(len(gated) + 1):
+                prefix = gated[:seen]
+                decided = decided_prefix(prefix, track_length, final=False)
+                assert seen - decided <= max(0, track_length - 1)
+                assert track_length_filter(prefix, track_length)[:decided] == final[:decided]
+            assert decided_prefix(gated, track_length, final=True) == len(gated)
