@@ -241,6 +241,8 @@ struct gance_workspace {
     }
 };
 
+constexpr int kWino43DefaultMaxRes = 0;  // (off until measured faster: see DESIGN.md §3)
+
 struct GraphEntry {
     hipGraphExec_t exec = nullptr;
     bool warmed = false;
@@ -263,6 +265,7 @@ struct gance_engine {
     std::vector<size_t> conv_w, conv_bias, conv_noise;
     std::vector<size_t> wino_w;  // Winograd-domain weights of the stride-1 layers that support them (else SIZE_MAX)
     std::vector<size_t> wino64_w;  // the same for the 64-channel Winograd kernel (layers with >= 64 output channels)
+    std::vector<size_t> wino43_w;  // F(4x4, 3x3) weights (winograd43_conv.hip), SIZE_MAX where the layer does not take that form
     std::vector<size_t> upfir_w;  // fused transposed-conv + FIR kernel's weight image of the up layers that support it (else SIZE_MAX)
     int num_cus = 256;
     std::vector<float> conv_ns;
@@ -342,14 +345,27 @@ struct FusedRgb {
     uint8_t* u8;
 };
 
+// Largest resolution whose Conv1 runs in Winograd F(4x4, 3x3) form (winograd43_conv.hip) in an engine with these
+// flags: GANCE_FLAG_WINOGRAD43 = every resolution the kernel supports; otherwise the default limit, which
+// GANCE_TUNE_WINO43 (read once per process: 0 = off, else a resolution) overrides.
+static int wino43_max_res(int flags) {
+    static const int env_value = [] {
+        const char* v = std::getenv("GANCE_TUNE_WINO43");
+        return v ? std::atoi(v) : -1;
+    }();
+    if (flags & GANCE_FLAG_DIRECT_CONV) return 0;
+    if (flags & GANCE_FLAG_WINOGRAD43) return 1 << 20;
+    return env_value >= 0 ? env_value : kWino43DefaultMaxRes;
+}
+
 int run_conv(gance_engine* e, const ConvLayerHost& c, int li, const LayerPlan& p, const float* x,
              long long x_b_stride, int H, int W, float* out, int epilogue, int out_row_stride,
              int out_y_off, int out_x_off, long long out_b_stride, long long out_c_stride,
              long long slab_stride, long long cls_stride, int B, hipStream_t stream,
              const char* name, const FusedRgb* rgb = nullptr, bool winograd = false, bool wino64 = false,
-             const float* s_next = nullptr) {
+             const float* s_next = nullptr, bool wino43 = false) {
     gance::ConvArgs a{};
-    a.s_next = wino64 ? s_next : nullptr;  // (only the 16x16x4 Winograd kernels scale their stores)
+    a.s_next = (wino64 || wino43) ? s_next : nullptr;  // (only the 16x16x4 Winograd kernels scale their stores)
     if (epilogue == gance::kEpilogueFullRgbPart) {  // (rgb->y: the partial image; the coefficient table is the workspace's)
         a.rgb_y = rgb->y;
         a.rgb_coef = e->ws->rgb_coef;
@@ -414,6 +430,11 @@ int run_conv(gance_engine* e, const ConvLayerHost& c, int li, const LayerPlan& p
         bytes = 4.0 * ((double)B * c.cin * H * W + 9.0 * c.cin * c.cout + 0.75 * B * H * W) + 3.0 * B * H * W;
     }
     StepScope scope(e, stream, name, flops, bytes);
+    if (wino43) {  // F(4x4, 3x3); the input arrives multiplied by this layer's style (the caller arranged that)
+        a.w = e->pool + e->wino43_w[li];
+        GANCE_HIP_CHECK(gance::launch_winograd43_conv(a, stream));
+        return GANCE_OK;
+    }
     if (winograd) {
         // the kernel on 16x16x4 MFMAs (in its 32-channel geometry the input arrives multiplied by this layer's style: the
         // caller arranged that with the producing layer), else the round-1 32-channel kernel
@@ -481,7 +502,7 @@ int synthesize_from_dlat(gance_engine* e, const float* d_dlat, int B, uint8_t* d
     // Which form conv layer idx (a stride-1 conv) runs in for this batch. Decided in one place because the layer BEFORE
     // a conv on the 16x16x4 Winograd kernel has to know: that kernel takes its input multiplied by its own style.
     struct ConvForm {
-        bool fused_rgb, winograd, winograd_last, wino64;
+        bool fused_rgb, winograd, winograd_last, wino64, wino43;
     };
     auto conv_form_of = [&](int idx, bool have_y_then) -> ConvForm {
         const ConvLayerHost& c = e->convs[idx];
@@ -519,6 +540,11 @@ int synthesize_from_dlat(gance_engine* e, const float* d_dlat, int B, uint8_t* d
         // supports that follows an up layer (all of them do: Conv1 follows Conv0_up)
         static const bool wino64_on = [] { const char* v = std::getenv("GANCE_TUNE_WINO64"); return !(v && std::atoi(v) == 0); }();
         form.wino64 = !form.fused_rgb && form.winograd && wino64_on && e->wino64_w[idx] != SIZE_MAX && idx > 0 && e->convs[idx - 1].up;
+        // F(4x4, 3x3) where the layer has the weights for it (engine creation: resolution limit, geometry, an up layer in
+        // front) and the launch fills the chip; never the network's last layer while that one carries the fused ToRGB
+        const long long w43_tiles = (long long)(c.cout / 32) * (res / 16) * (res / 64) * B;
+        form.wino43 = !form.fused_rgb && form.winograd && e->wino43_w[idx] != SIZE_MAX && (w43_tiles >= e->num_cus || wino_mode == 2);
+        if (form.wino43) form.wino64 = false;
         return form;
     };
     // Whether up layer idx runs as the fused kernel (transposed conv + FIR in one launch): where it is supported and fills
@@ -577,6 +603,7 @@ int synthesize_from_dlat(gance_engine* e, const float* d_dlat, int B, uint8_t* d
                 static const bool w64_rgb_enabled = [] { const char* v = std::getenv("GANCE_TUNE_W64_RGB"); return !(v && std::atoi(v) == 0); }();
                 rgb_part = form.wino64 && w64_rgb_enabled && gance::winograd64_rgb_supported(c.cout);
                 if (winograd) std::snprintf(name, sizeof(name), rgb_part ? "convW%d+rgb_%dx%d_%d->%d" : "convW%d_%dx%d_%d->%d", c.layer_idx, res, res, c.cin, c.cout);
+                if (form.wino43) std::snprintf(name, sizeof(name), "convV%d_%dx%d_%d->%d", c.layer_idx, res, res, c.cin, c.cout);
                 // the next layer's style rides on this launch's stores when that layer is a fused up kernel — and only when this
                 // launch also does the ToRGB channel sum (from the plain values): torgb_kernel would otherwise read the scaled ones
                 const float* const s_next_up =
@@ -598,7 +625,7 @@ int synthesize_from_dlat(gance_engine* e, const float* d_dlat, int B, uint8_t* d
                 } else {
                     rc = run_conv(e, c, li, p, x_in, x_b_stride, res, res, x_out,
                                   gance::kEpilogueFull, res + 8, 1, 4, out_b, out_c, 0, 0, B, stream,
-                                  name, nullptr, winograd, form.wino64, s_next_up);
+                                  name, nullptr, winograd, form.wino64, s_next_up, form.wino43);
                 }
                 if (rc) return rc;
             } else {
@@ -618,7 +645,8 @@ int synthesize_from_dlat(gance_engine* e, const float* d_dlat, int B, uint8_t* d
             const int H = res / 2, W = res / 2;
             // the next layer's style rides on this layer's activation when that layer takes its input pre-scaled
             const float* const s_next =
-                (li + 1 < limit && !e->convs[li + 1].up && conv_form_of(li + 1, true).wino64 && gance::winograd64_input_prescaled(e->convs[li + 1].cout))
+                (li + 1 < limit && !e->convs[li + 1].up &&
+                 ((conv_form_of(li + 1, true).wino64 && gance::winograd64_input_prescaled(e->convs[li + 1].cout)) || conv_form_of(li + 1, true).wino43))
                     ? e->ws->styles + e->conv_s_off[li + 1]
                     : nullptr;
             const bool input_prescaled = x_prescaled;
@@ -970,6 +998,14 @@ int gance_engine_create(const gance_engine_config* config, const float* host_wei
             for (size_t j = 0; j < wn; ++j) scaled[j] = src[j] * coef;
             e->wino64_w[i] = reserve(gance::winograd64_weight_floats(c.cin, c.cout));
             gance::winograd64_transform_weights(scaled.data(), c.cin, c.cout, &pool[e->wino64_w[i]]);
+        }
+        e->wino43_w.push_back(SIZE_MAX);
+        if (!c.up && i > 0 && e->convs[i - 1].up && (1 << c.res_log2) >= 64 && (1 << c.res_log2) <= wino43_max_res(e->cfg.flags) &&
+            gance::winograd43_supported(c.cin, c.cout, 1 << c.res_log2, 1 << c.res_log2)) {
+            std::vector<float> scaled(wn);
+            for (size_t j = 0; j < wn; ++j) scaled[j] = src[j] * coef;
+            e->wino43_w[i] = reserve(gance::winograd43_weight_floats(c.cin, c.cout));
+            gance::winograd43_transform_weights(scaled.data(), c.cin, c.cout, &pool[e->wino43_w[i]]);
         }
         e->upfir_w.push_back(SIZE_MAX);
         if (c.up && gance::upfir_supported(c.cin, c.cout, (1 << c.res_log2) / 2, (1 << c.res_log2) / 2)) {

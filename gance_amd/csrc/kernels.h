@@ -152,6 +152,14 @@ bool winograd64_rgb_supported(int cout);
 int winograd64_rgb_partials(int cout);  // partial images the launch writes: [partials][B][3][OH][OW]
 hipError_t launch_winograd64_rgb_coef(const float* rgb_w, const float* rgb_s, int s_stride, int B, int cout, float* coef, hipStream_t stream);
 
+// Winograd F(4x4, 3x3) form (winograd43_conv.hip): 36 multiplies per 16 outputs instead of 16 per 4; 32 channels x
+// 16x64 pixels per block, two waves per SIMD; the input arrives multiplied by the layer's style (prescaled, like the
+// 32-channel geometry above); args.w points at [m tile of 32][chunk of 4][4864 floats]. kEpilogueFull only.
+bool winograd43_supported(int cin, int cout, int H, int W);
+size_t winograd43_weight_floats(int cin, int cout);
+void winograd43_transform_weights(const float* w_in /*[9][cin][cout]*/, int cin, int cout, float* w_out);
+hipError_t launch_winograd43_conv(const ConvArgs& args, hipStream_t stream);
+
 // Conv0_up as ONE kernel (upfir_fused.hip): transposed conv on the matrix cores + [1,3,3,1]^2 FIR + noise +
 // bias + leaky ReLU, for inputs >= 64 wide. Blocks sweep 64-column strips in steps of 8 position rows.
 struct UpFirArgs {

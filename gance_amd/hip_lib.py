@@ -31,6 +31,7 @@ GANCE_FLAG_FORCE_WINOGRAD = 4
 GANCE_FLAG_SPLIT_UPFIR = 8
 GANCE_FLAG_FORCE_FUSED_UPFIR = 16
 GANCE_FLAG_PRIVATE_WORKSPACE = 32
+GANCE_FLAG_WINOGRAD43 = 64
 
 STATUS_NAMES = {
     1: "GANCE_ERR_INVALID_ARGUMENT",
@@ -287,13 +288,18 @@ class Engine:
         passes; "fused" = the fused kernel whatever the batch.
         :param conv_form: "auto" = Winograd F(2x2,3x3) for the stride-1 convs of the >= 64x64 layers
         when a launch has at least one block per CU, else the direct form; "direct" = never Winograd;
-        "winograd" = Winograd on every layer that supports it, whatever the batch.
+        "winograd" = Winograd on every layer that supports it, whatever the batch; "winograd43" = the same with the
+        F(4x4,3x3) kernel on every Conv1 from 64x64 up that it supports (the default uses it up to the resolution where
+        it measured faster).
         """
         self._lib = load_library()
         self._handle = ctypes.c_void_p()
         spec = sg2_spec.make_spec(resolution)
         blob = sg2_spec.pack_variables(variables, spec)
-        form_flags = {"auto": 0, "direct": GANCE_FLAG_DIRECT_CONV, "winograd": GANCE_FLAG_FORCE_WINOGRAD}[conv_form]
+        form_flags = {
+            "auto": 0, "direct": GANCE_FLAG_DIRECT_CONV, "winograd": GANCE_FLAG_FORCE_WINOGRAD,
+            "winograd43": GANCE_FLAG_FORCE_WINOGRAD | GANCE_FLAG_WINOGRAD43,
+        }[conv_form]
         form_flags |= {"auto": 0, "split": GANCE_FLAG_SPLIT_UPFIR, "fused": GANCE_FLAG_FORCE_FUSED_UPFIR}[up_form]
         if private_workspace:
             form_flags |= GANCE_FLAG_PRIVATE_WORKSPACE

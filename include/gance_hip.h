@@ -64,6 +64,7 @@ typedef struct gance_engine_config {
  * Calls that share it are ordered by an event, on whatever streams they run. PRIVATE_WORKSPACE gives an engine
  * its own (calls of different engines may then overlap on different streams). */
 #define GANCE_FLAG_PRIVATE_WORKSPACE 32
+#define GANCE_FLAG_WINOGRAD43 64 /* Conv1 layers from 64x64 up in Winograd F(4x4,3x3) form wherever the kernel supports the layer */
 
 /*
  * Load a network. Replaces load_network_network + wrap_loaded_network

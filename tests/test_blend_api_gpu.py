@@ -45,8 +45,8 @@ def test_resize_keeps_flat_images_flat() -> None:
 def test_projection_file_blend_api_end_to_end(tmp_path: Path) -> None:
     L, num_projection, fps_in, fps_out, side, out_side = 512, 8, 15.0, 30.0, 64, 96
     num_frames = int(num_projection * fps_out / fps_in)
-    # inputs on disk: a float32 WAV at L * fps Hz (the stretch is then the identity), a projection
-    # file, two network files
+    # inputs on disk: a float32 WAV at L * fps Hz (stretch ratio 1: resampy then still low-pass filters it), a
+    # projection file, two network files
     audio = synthetic.synthetic_audio(num_frames, L, seed=51, frames_per_second=fps_out)
     wav_path = tmp_path / "audio.wav"
     wavfile.write(str(wav_path), int(L * fps_out), audio)
@@ -69,8 +69,9 @@ def test_projection_file_blend_api_end_to_end(tmp_path: Path) -> None:
     frames = np.load(out_path)
     assert frames.shape == (num_frames, out_side, out_side, 3) and frames.dtype == np.uint8
 
-    # the same pipeline through the oracles
-    want_blend = audio_ref.alpha_blend_projection_file(latents, 0.25, True, (-5, 5), 12, audio, L, [0, 1])
+    # the same pipeline through the oracles (the WAV stage: resampy at the ratio read_wavs_scale_for_video computes)
+    stretched = audio_ref.resample_audio(audio, int(L * fps_out), float(int(L * fps_out)) * (num_frames / (len(audio) / L)))
+    want_blend = audio_ref.alpha_blend_projection_file(latents, 0.25, True, (-5, 5), 12, stretched, L, [0, 1])
     dlatents = audio_ref.sub_vectors(want_blend.combined, L).astype(np.float32)
     rows = int(np.log2(side)) * 2 - 2
     for frame_index in (0, num_frames // 2, num_frames - 1):
@@ -114,7 +115,8 @@ def test_noise_blend_end_to_end(tmp_path: Path) -> None:
     frames = noise_blend.noise_blend_frames([str(wav_path)], network_paths, 20, fps, out_side, 0.25, True, (-5, 5))
     assert frames.shape == (20, out_side, out_side, 3) and frames.dtype == np.uint8
 
-    want = audio_ref.alpha_blend_vectors_max_rms_power_audio(0.25, True, (-5, 5), audio, L, [0, 1])
+    stretched = audio_ref.resample_audio(audio, int(L * fps), int(L * fps))  # FPS mode at L * fps Hz: ratio 1, still filtered
+    want = audio_ref.alpha_blend_vectors_max_rms_power_audio(0.25, True, (-5, 5), stretched, L, [0, 1])
     z = audio_ref.sub_vectors(want.combined, L).astype(np.float32)
     for frame_index in (0, 9, 19):
         variables = network_file.load_network(network_paths[int(want.network_indices[frame_index])]).variables
@@ -261,7 +263,8 @@ def test_blend_from_a_real_hdf5_projection_file(tmp_path: Path, golden_dir: Path
         blend_depth=12,
     )
     assert frames.shape == (num_frames, side, side, 3)
-    want_blend = audio_ref.alpha_blend_projection_file(latents, 0.25, True, (-5, 5), 12, audio, L, [0])
+    stretched = audio_ref.resample_audio(audio, int(L * fps_out), float(int(L * fps_out)) * (num_frames / (len(audio) / L)))
+    want_blend = audio_ref.alpha_blend_projection_file(latents, 0.25, True, (-5, 5), 12, stretched, L, [0])
     dlatents = audio_ref.sub_vectors(want_blend.combined, L).astype(np.float32)
     rows = int(np.log2(side)) * 2 - 2
     variables = network_file.load_network(network_path).variables

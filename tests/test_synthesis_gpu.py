@@ -47,12 +47,14 @@ def library():
 
 
 @pytest.mark.parametrize(
-    "resolution,batch,conv_form", [(8, 1, "auto"), (32, 3, "auto"), (32, 5, "winograd"), (64, 9, "direct"), (64, 9, "winograd"), (128, 3, "winograd")]
+    "resolution,batch,conv_form",
+    [(8, 1, "auto"), (32, 3, "auto"), (32, 5, "winograd"), (64, 9, "direct"), (64, 9, "winograd"), (128, 3, "winograd"), (64, 5, "winograd43"), (128, 3, "winograd43")],
 )
 def test_layerwise_activations_match_oracle(library, resolution: int, batch: int, conv_form: str) -> None:
     """
     Every conv layer's activation (all terms on: noise, biases) against the fp64 oracle, in the
-    direct form and with the Winograd F(2x2,3x3) kernel forced onto the >= 64x64 stride-1 layers.
+    direct form, with the Winograd F(2x2,3x3) kernel forced onto the >= 64x64 stride-1 layers, and with the
+    F(4x4,3x3) kernel ("winograd43") on the Conv1 layers from 64x64 up.
     """
     spec = sg2_spec.make_spec(resolution)
     variables = sg2_spec.make_random_variables(resolution, seed=3, perturb=True)
@@ -72,7 +74,7 @@ def test_layerwise_activations_match_oracle(library, resolution: int, batch: int
 
 @pytest.mark.parametrize(
     "resolution,batch,perturb,conv_form",
-    [(16, 2, True, "auto"), (128, 2, True, "direct"), (256, 3, False, "auto"), (256, 1, True, "direct"), (256, 2, True, "winograd")],
+    [(16, 2, True, "auto"), (128, 2, True, "direct"), (256, 3, False, "auto"), (256, 1, True, "direct"), (256, 2, True, "winograd"), (256, 2, True, "winograd43")],
 )
 def test_matrix_path_matches_oracle(library, resolution: int, batch: int, perturb: bool, conv_form: str) -> None:
     """create_image_matrix semantics (network_functions.py:160-169): dlatents -> frames."""
