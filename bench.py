@@ -64,6 +64,8 @@ def kernel_of_step(step_name: str) -> str:
         return "upfir_fused_pre_kernel"  # input pre-scaled by the Winograd launch before it
     if step_name.startswith("convTF"):
         return "upfir_fused_kernel"
+    if step_name.startswith("convV"):
+        return "winograd43_rgb_kernel" if "+rgb" in step_name else "winograd43_kernel"
     if step_name.startswith("convW"):
         narrow = step_name.endswith("->32")
         if "+rgb" in step_name:
@@ -73,7 +75,9 @@ def kernel_of_step(step_name: str) -> str:
 
 
 def executed_fraction(step_name: str) -> float:
-    """Matrix-core flops a launch EXECUTES per algorithmic (direct-form) flop: Winograd F(2x2,3x3) does 16 of 36."""
+    """Matrix-core flops a launch EXECUTES per algorithmic (direct-form) flop: Winograd F(2x2,3x3) does 16 of 36, F(4x4,3x3) 36 of 144."""
+    if step_name.startswith("convV"):
+        return 0.25
     return 4.0 / 9.0 if step_name.startswith("convW") else 1.0
 
 
@@ -455,8 +459,9 @@ def main() -> int:
     conv_flops = sum(s.flops for s in conv_steps)
     # Winograd F(2x2,3x3) launches ("convW..."): flops above are the ALGORITHMIC (direct-form) ones; the
     # matrix cores execute 4/9 of them
-    executed_flops = sum(s.flops * (4.0 / 9.0 if s.name.startswith("convW") else 1.0) for s in conv_steps)
-    winograd_launches = sum(1 for s in conv_steps if s.name.startswith("convW"))
+    executed_flops = sum(s.flops * executed_fraction(s.name) for s in conv_steps)
+    winograd_launches = sum(1 for s in conv_steps if s.name.startswith(("convW", "convV")))
+    winograd43_launches = sum(1 for s in conv_steps if s.name.startswith("convV"))
     total_ms = sum(s.ms for s in steps_info)
     if args.print_steps and rank == 0:
         for info in steps_info:
@@ -507,8 +512,8 @@ def main() -> int:
                     "algorithmic_direct_form": round(conv_flops / (conv_ms * 1e-3) / 1e12, 3),
                     "share_of_step_time": round(conv_ms / total_ms, 4),
                     "winograd_launches": winograd_launches,
-                    "note": "%d of the %d conv launches run in Winograd F(2x2,3x3) form and execute 4/9 of their direct-form flops; "
-                    "algorithmic_direct_form prices every launch as a direct convolution and may exceed the peak" % (winograd_launches, len(conv_steps)),
+                    "note": "%d of the %d conv launches run in Winograd form (%d of them F(4x4,3x3): 1/4 of their direct-form flops executed; the others F(2x2,3x3): 4/9); "
+                    "algorithmic_direct_form prices every launch as a direct convolution and may exceed the peak" % (winograd_launches, len(conv_steps), winograd43_launches),
                 },
                 # the whole step (mapping, styles, ToRGB, uint8 included) against the matrix peak: executed flops of a
                 # step over its wall time; and the same in direct-form flops, the work a direct implementation would do

@@ -601,13 +601,13 @@ int synthesize_from_dlat(gance_engine* e, const float* d_dlat, int B, uint8_t* d
                 // ToRGB pass below then only adds bias and skip image (and converts). The LAST layer's activation has no
                 // other reader and is not stored (unless a debug tap wants it). GANCE_TUNE_W64_RGB=0 turns this off.
                 static const bool w64_rgb_enabled = [] { const char* v = std::getenv("GANCE_TUNE_W64_RGB"); return !(v && std::atoi(v) == 0); }();
-                rgb_part = form.wino64 && w64_rgb_enabled && gance::winograd64_rgb_supported(c.cout);
+                rgb_part = w64_rgb_enabled && ((form.wino64 && gance::winograd64_rgb_supported(c.cout)) || (form.wino43 && gance::winograd43_rgb_supported(c.cout)));
                 if (winograd) std::snprintf(name, sizeof(name), rgb_part ? "convW%d+rgb_%dx%d_%d->%d" : "convW%d_%dx%d_%d->%d", c.layer_idx, res, res, c.cin, c.cout);
-                if (form.wino43) std::snprintf(name, sizeof(name), "convV%d_%dx%d_%d->%d", c.layer_idx, res, res, c.cin, c.cout);
+                if (form.wino43) std::snprintf(name, sizeof(name), rgb_part ? "convV%d+rgb_%dx%d_%d->%d" : "convV%d_%dx%d_%d->%d", c.layer_idx, res, res, c.cin, c.cout);
                 // the next layer's style rides on this launch's stores when that layer is a fused up kernel — and only when this
                 // launch also does the ToRGB channel sum (from the plain values): torgb_kernel would otherwise read the scaled ones
                 const float* const s_next_up =
-                    (rgb_part && form.wino64 && c.cout % 64 == 0 && prescale_up && li + 1 < limit && up_runs_fused(li + 1, nullptr))
+                    (rgb_part && (form.wino64 || form.wino43) && c.cout % 64 == 0 && prescale_up && li + 1 < limit && up_runs_fused(li + 1, nullptr))
                         ? e->ws->styles + e->conv_s_off[li + 1]
                         : nullptr;
                 x_prescaled = s_next_up != nullptr;
@@ -617,11 +617,11 @@ int synthesize_from_dlat(gance_engine* e, const float* d_dlat, int B, uint8_t* d
                     GANCE_HIP_CHECK(gance::launch_winograd64_rgb_coef(e->pool + e->rgb_w[ri], e->ws->styles + e->rgb_s_off[ri], e->ctot, B, c.cout,
                                                                       e->ws->rgb_coef, stream));
                     // (one partial image: straight into the skip buffer ToRGB finishes in place; several: the workspace's)
-                    rgb_partials = gance::winograd64_rgb_partials(c.cout);
+                    rgb_partials = form.wino43 ? gance::winograd43_rgb_partials(c.cout) : gance::winograd64_rgb_partials(c.cout);
                     FusedRgb part{nullptr, nullptr, nullptr, nullptr, rgb_partials == 1 ? e->ws->ybuf[have_y ? 1 - ycur : ycur] : e->ws->rgb_part, nullptr};
                     const bool last_unread = c.res_log2 == e->res_log2 && limit == num_convs && e->debug_stop_after <= 0;
                     rc = run_conv(e, c, li, p, x_in, x_b_stride, res, res, last_unread ? nullptr : x_out, gance::kEpilogueFullRgbPart,
-                                  res + 8, 1, 4, out_b, out_c, 0, 0, B, stream, name, &part, true, true, s_next_up);
+                                  res + 8, 1, 4, out_b, out_c, 0, 0, B, stream, name, &part, true, !form.wino43, s_next_up, form.wino43);
                 } else {
                     rc = run_conv(e, c, li, p, x_in, x_b_stride, res, res, x_out,
                                   gance::kEpilogueFull, res + 8, 1, 4, out_b, out_c, 0, 0, B, stream,
@@ -1092,6 +1092,9 @@ int gance_engine_create(const gance_engine_config* config, const float* host_wei
         const ConvLayerHost& c = e->convs[i];
         if (!c.up && c.cout > 64 && gance::winograd64_rgb_supported(c.cout))
             e->rgb_part_floats = std::max(e->rgb_part_floats, (size_t)gance::winograd64_rgb_partials(c.cout) * Bmax * 3 << (2 * c.res_log2));
+        // ... and of the F(4x4,3x3) launches: one partial image per 16-channel tile
+        if (e->wino43_w[i] != SIZE_MAX && gance::winograd43_rgb_supported(c.cout))
+            e->rgb_part_floats = std::max(e->rgb_part_floats, (size_t)gance::winograd43_rgb_partials(c.cout) * Bmax * 3 << (2 * c.res_log2));
     }
 
 #define GANCE_CREATE_CHECK(expr)                                                            \

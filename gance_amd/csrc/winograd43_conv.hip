@@ -43,7 +43,7 @@ namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2_lds __attribute__((ext_vector_type(2), aligned(4)));  // two window columns, any two dwords: ds_read2_b32
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
 constexpr int kKC = 4;                         // input channels per chunk = one k-step of the 16x16x4 MFMA
@@ -51,29 +51,30 @@ constexpr int kBM = 32;                        // output channels per block (2 c
 constexpr int kTW = 64, kTH = 16;              // pixels per block
 constexpr int kPW = kTW + 8, kPH = kTH + 2;    // haloed patch: 18 rows x 72 columns (16-byte aligned row segments)
 constexpr int kPlane = kPH * kPW;              // 1296 floats per input channel
-constexpr int kUnit = 16 * 36 + 2;             // a (channel tile, ci) unit of weights: [co % 16][36] + 2 floats of padding
-constexpr int kWPieces = 19;                   // 8 units = 4624 floats -> 19 pieces of 256 floats (zero padded in HBM)
-constexpr int kWFloats = kWPieces * 256;       // 4864
+constexpr int kUnit = 16 * 36;                 // a (channel tile, ci) unit of weights: [co % 16][36]: a lane's 36 weights are nine aligned float4
+constexpr int kWPieces = 18;                   // 8 units = 4608 floats = 18 pieces of 256 floats
+constexpr int kWFloats = kWPieces * 256;
 constexpr int kPatchF4 = kKC * kPlane / 4;     // 1296 float4
 constexpr int kPPieces = (kPatchF4 + 63) / 64; // 21 (the last one a quarter full)
-constexpr int kPieces = kWPieces + kPPieces;   // 40: five per wave
-constexpr int kPiecesPerWave = kPieces / 8;
-static_assert(kPieces == 40 && kPiecesPerWave == 5, "five LDS-DMA pieces per wave and chunk");
-constexpr int kSlot = kPieces * 256;           // 10240 floats = 40 KB
+constexpr int kPieces = kWPieces + kPPieces;   // 39 (+ one repeat of patch piece 0: every wave issues five, the waits count them)
+constexpr int kPiecesPerWave = 5;
+static_assert(kPieces <= 8 * kPiecesPerWave && kPieces > 7 * kPiecesPerWave, "five LDS-DMA pieces per wave and chunk");
+constexpr int kSlot = kPieces * 256;           // 9984 floats = 39 KB
 constexpr int kNBUF = 3;
 
-// B^T of F(4,3), points 0, +-1, +-2 (Lavin & Gray): 12 vector instructions
-__device__ __forceinline__ void input_transform6(float d0, float d1, float d2, float d3, float d4, float d5, float (&t)[6]) {
-    const float a = fmaf(-4.f, d2, d4);
-    const float b = fmaf(-4.f, d1, d3);
-    const float c = d4 - d2;
-    const float e = d3 - d1;
-    t[0] = fmaf(4.f, d0, fmaf(-5.f, d2, d4));
+// B^T of F(4,3), points 0, +-1, +-2 (Lavin & Gray): 12 vector instructions, on one window line or on two at once
+template <typename T>
+__device__ __forceinline__ void input_transform6(T d0, T d1, T d2, T d3, T d4, T d5, T (&t)[6]) {
+    const T a = d4 - 4.f * d2;
+    const T b = d3 - 4.f * d1;
+    const T c = d4 - d2;
+    const T e = d3 - d1;
+    t[0] = 4.f * d0 + (d4 - 5.f * d2);
     t[1] = a + b;
     t[2] = a - b;
-    t[3] = fmaf(2.f, e, c);
-    t[4] = fmaf(-2.f, e, c);
-    t[5] = fmaf(4.f, d1, fmaf(-5.f, d3, d5));
+    t[3] = c + 2.f * e;
+    t[4] = c - 2.f * e;
+    t[5] = 4.f * d1 + (d5 - 5.f * d3);
 }
 
 // A^T of F(4,3): 10 vector instructions
@@ -87,7 +88,8 @@ __device__ __forceinline__ void output_transform6(float m0, float m1, float m2, 
 
 }  // namespace
 
-__global__ __launch_bounds__(512, 1) void winograd43_kernel(const ConvArgs p) {
+template <bool RGB>
+__device__ __forceinline__ void winograd43_body(const ConvArgs& p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -112,14 +114,15 @@ __global__ __launch_bounds__(512, 1) void winograd43_kernel(const ConvArgs p) {
         b0 = id / p.tiles_y;
     }
 
-    // ---- LDS-DMA pieces of this wave: piece wave * 5 + r; < 19: weights (linear), else patch piece (per-lane source offset)
+    // ---- LDS-DMA pieces of this wave: piece wave * 5 + r; < 18: weights (linear), else patch piece (per-lane source offset)
     const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, 0x7fffffff, 0x00020000);
     const __amdgpu_buffer_rsrc_t x_rsrc =
         __builtin_amdgcn_make_buffer_rsrc((void*)(p.x + (size_t)b0 * p.x_b_stride), 0, 0x7fffffff, 0x00020000);
     int piece_voff[kPiecesPerWave];
 #pragma unroll
     for (int r = 0; r < kPiecesPerWave; ++r) {
-        const int piece = wave * kPiecesPerWave + r;
+        int piece = wave * kPiecesPerWave + r;
+        if (piece >= kPieces) piece = kWPieces;  // (the fortieth slot repeats patch piece 0: same bytes to the same place)
         if (piece < kWPieces) {
             piece_voff[r] = piece * 1024 + lane * 16;
         } else {
@@ -138,7 +141,8 @@ __global__ __launch_bounds__(512, 1) void winograd43_kernel(const ConvArgs p) {
         float* const base = smem + slot * kSlot;
 #pragma unroll
         for (int r = 0; r < kPiecesPerWave; ++r) {
-            const int piece = wave * kPiecesPerWave + r;  // (wave is scalar: the branch is uniform)
+            int piece = wave * kPiecesPerWave + r;  // (wave is scalar: the branches are uniform)
+            if (piece >= kPieces) piece = kWPieces;
             if (piece < kWPieces)
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, (lds_ptr_t)(base + piece * 256), 16, piece_voff[r], w_tile_base + chunk * (kWFloats * 4), 0, 0);
             else
@@ -155,47 +159,80 @@ __global__ __launch_bounds__(512, 1) void winograd43_kernel(const ConvArgs p) {
     const int win_off = kWFloats + g * kPlane + (4 * pg) * kPW + 4 * n16;  // window rows 4 pg .. + 5, columns 4 n + 3 .. + 8
     const int a_off = (cot * 4 + g) * kUnit + n16 * 36;
 
+    // L + T: this lane's weights of the chunk (position j * 6 + i) and V = B^T d B of its window, both into registers.
+    // Column pass first, two window columns per packed instruction (the pairs (4,5), (6,7) are aligned 8-byte reads,
+    // (3, 8) one ds_read2_b32), then the row pass line by line.
+    float V[36], A[36];
+    auto load_transform = [&](int slot) {
+        const float* const P = smem + slot * kSlot + win_off;
+        const float* const U = smem + slot * kSlot + a_off;
+        f32x2 c45[6], c67[6], c38[6];
+#pragma unroll
+        for (int y = 0; y < 6; ++y) {
+            c45[y] = *reinterpret_cast<const f32x2*>(P + y * kPW + 4);
+            c67[y] = *reinterpret_cast<const f32x2*>(P + y * kPW + 6);
+            c38[y][0] = P[y * kPW + 3];
+            c38[y][1] = P[y * kPW + 8];
+        }
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+            const f32x4 t = *reinterpret_cast<const f32x4*>(U + 4 * k);
+            A[4 * k + 0] = t[0];
+            A[4 * k + 1] = t[1];
+            A[4 * k + 2] = t[2];
+            A[4 * k + 3] = t[3];
+        }
+        f32x2 t45[6], t67[6], t38[6];
+        input_transform6<f32x2>(c45[0], c45[1], c45[2], c45[3], c45[4], c45[5], t45);
+        input_transform6<f32x2>(c67[0], c67[1], c67[2], c67[3], c67[4], c67[5], t67);
+        input_transform6<f32x2>(c38[0], c38[1], c38[2], c38[3], c38[4], c38[5], t38);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            // (kept opaque: where a packed result is only read by element, hipcc splits the packed operation again)
+            asm("" : "+v"(t45[i]), "+v"(t67[i]), "+v"(t38[i]));
+            float v[6];
+            input_transform6<float>(t38[i][0], t45[i][0], t45[i][1], t67[i][0], t67[i][1], t38[i][1], v);
+#pragma unroll
+            for (int j = 0; j < 6; ++j) V[j * 6 + i] = v[j];
+        }
+    };
+    auto multiply = [&]() {
+        if (p.debug_flags & 2) return;
+#pragma unroll
+        for (int pos = 0; pos < 36; ++pos) acc[pos] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[pos], V[pos], acc[pos], 0, 0, 0);
+    };
+
     issue_chunk(0, 0);
     if (n > 1) issue_chunk(1, 1);
 
+    // The two waves of a SIMD (wave w and w + 4: the two channel tiles of a tile row) run half a k-step apart: in the
+    // interval between two barriers the cot = 0 wave loads and transforms chunk q and then multiplies it, the cot = 1 wave
+    // first multiplies chunk q - 1 out of its registers and then loads and transforms chunk q. While one of them waits
+    // for LDS or issues vector instructions the other keeps the matrix pipe busy.
     int slot = 0;
     for (int q = 0; q < n; ++q) {
-        if (q + 1 < n)
+        if (q + 1 < n && !(p.debug_flags & 1))
             asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kPiecesPerWave) : "memory");
         else
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        if (q + 2 < n) issue_chunk(q + 2, slot == 0 ? 2 : slot - 1);  // (q + 2) % 3 == (slot + 2) % 3
-        const float* const P = smem + slot * kSlot + win_off;
-        const float* const U = smem + slot * kSlot + a_off;
-        // row pass: W = d B (along x), six rows of the window
-        float wt[6][6];
-#pragma unroll
-        for (int y = 0; y < 6; ++y) {
-            const f32x4 lo = *reinterpret_cast<const f32x4*>(P + y * kPW);
-            const f32x4 hi = *reinterpret_cast<const f32x4*>(P + y * kPW + 4);
-            const float last = P[y * kPW + 8];
-            input_transform6(lo[3], hi[0], hi[1], hi[2], hi[3], last, wt[y]);
-        }
-        // column pass + the six positions of a column: V[.][j] = B^T W[.][j]; position j * 6 + i
-#pragma unroll
-        for (int j = 0; j < 6; ++j) {
-            float v[6];
-            input_transform6(wt[0][j], wt[1][j], wt[2][j], wt[3][j], wt[4][j], wt[5][j], v);
-            const f32x2 a01 = *reinterpret_cast<const f32x2*>(U + j * 6);
-            const f32x2 a23 = *reinterpret_cast<const f32x2*>(U + j * 6 + 2);
-            const f32x2 a45 = *reinterpret_cast<const f32x2*>(U + j * 6 + 4);
-            const float a[6] = {a01[0], a01[1], a23[0], a23[1], a45[0], a45[1]};
-#pragma unroll
-            for (int i = 0; i < 6; ++i) acc[j * 6 + i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], v[i], acc[j * 6 + i], 0, 0, 0);
-        }
+        if (q + 2 < n && !((p.debug_flags & 1) && q > 0)) issue_chunk(q + 2, slot == 0 ? 2 : slot - 1);  // (q + 2) % 3 == (slot + 2) % 3
+        __builtin_amdgcn_sched_barrier(0);
+        if (cot == 0) load_transform(slot);
+        __builtin_amdgcn_sched_barrier(0);
+        if (cot == 0 || q > 0) multiply();
+        __builtin_amdgcn_sched_barrier(0);
+        if (cot != 0) load_transform(slot);
+        __builtin_amdgcn_sched_barrier(0);
         slot = slot == kNBUF - 1 ? 0 : slot + 1;
     }
+    if (cot != 0) multiply();
 
     // ---- epilogue: lane (n16, g) holds channels 4 g + r (r = 0 .. 3) of tile n16 for all 36 positions ----
     const int oy0 = y0 + 4 * pg, ox0 = x0 + 4 * n16;
-    const int co0 = m_tile * kBM + cot * 16 + 4 * g;
+    const int ct = m_tile * 2 + cot;  // 16-channel tile of the layer
+    const int co0 = ct * 16 + 4 * g;
     const f32x4 dm = *reinterpret_cast<const f32x4*>(p.d + (size_t)b0 * p.d_stride + co0);
     const f32x4 bm = *reinterpret_cast<const f32x4*>(p.bias + co0);
     f32x4 sn = f32x4{1.f, 1.f, 1.f, 1.f};
@@ -206,8 +243,22 @@ __global__ __launch_bounds__(512, 1) void winograd43_kernel(const ConvArgs p) {
         nz[oy] = f32x4{0.f, 0.f, 0.f, 0.f};
         if (p.noise != nullptr) nz[oy] = *reinterpret_cast<const f32x4*>(p.noise + (size_t)(oy0 + oy) * p.OW + ox0) * p.noise_strength;
     }
-    float* const out_base = p.out + (size_t)b0 * p.out_b_stride + (size_t)co0 * p.out_c_stride +
-                            (size_t)(oy0 + p.out_y_off) * p.out_row_stride + ox0 + p.out_x_off;
+    // (RGB) the layer's ToRGB channel sum over this wave's 16 channels rides on the matrix pipe: k-step r of the product
+    // takes B[k = g][n] = this lane's activation of channel 4 g + r and A[m][k] = style x weight of colour m < 3 (else 0)
+    // for channel 16 ct + 4 k + r, from the table launch_winograd64_rgb_coef prepares ([b][Cout / 4 steps][64 lanes]).
+    float a_rgb[4] = {0.f, 0.f, 0.f, 0.f};
+    f32x4 rgbacc[4][4];
+    if constexpr (RGB) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) a_rgb[r] = p.rgb_coef[((size_t)b0 * (p.Cout / 4) + 4 * ct + r) * 64 + lane];
+#pragma unroll
+        for (int oy = 0; oy < 4; ++oy)
+#pragma unroll
+            for (int ox = 0; ox < 4; ++ox) rgbacc[oy][ox] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    float* const out_base = p.out == nullptr ? nullptr
+                                             : p.out + (size_t)b0 * p.out_b_stride + (size_t)co0 * p.out_c_stride +
+                                                   (size_t)(oy0 + p.out_y_off) * p.out_row_stride + ox0 + p.out_x_off;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         float t[4][6];  // A^T M: [output row][position column]
@@ -225,11 +276,31 @@ __global__ __launch_bounds__(512, 1) void winograd43_kernel(const ConvArgs p) {
             f32x4 v = f32x4{yrow[0], yrow[1], yrow[2], yrow[3]} * dm[r] + nz[oy] + bm[r];
 #pragma unroll
             for (int k = 0; k < 4; ++k) v[k] = fmaxf(v[k], 0.2f * v[k]) * 1.4142135623730951f;
-            v *= sn[r];
-            *reinterpret_cast<f32x4*>(out_base + (size_t)r * p.out_c_stride + (size_t)oy * p.out_row_stride) = v;
+            if constexpr (RGB) {
+#pragma unroll
+                for (int ox = 0; ox < 4; ++ox) rgbacc[oy][ox] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_rgb[r], v[ox], rgbacc[oy][ox], 0, 0, 0);
+            }
+            // (the stored activation carries the next layer's style when that layer wants it so; the ToRGB product took the plain one)
+            if (out_base != nullptr) *reinterpret_cast<f32x4*>(out_base + (size_t)r * p.out_c_stride + (size_t)oy * p.out_row_stride) = v * sn[r];
+        }
+    }
+    if constexpr (RGB) {
+        // partial image of this 16-channel tile: [Cout / 16][B][3][OH][OW]; lanes 0 .. 15 hold (R, G, B, 0) of their tile's pixels
+        if (g == 0) {
+            float* const y_base = p.rgb_y + (((size_t)ct * p.B + b0) * 3) * p.OH * p.OW + (size_t)oy0 * p.OW + ox0;
+#pragma unroll
+            for (int c = 0; c < 3; ++c)
+#pragma unroll
+                for (int oy = 0; oy < 4; ++oy)
+                    *reinterpret_cast<f32x4*>(y_base + ((size_t)c * p.OH + oy) * p.OW) =
+                        f32x4{rgbacc[oy][0][c], rgbacc[oy][1][c], rgbacc[oy][2][c], rgbacc[oy][3][c]};
         }
     }
 }
+
+// (plain functions around the templated body: as a kernel TEMPLATE the host pass of hipcc drops the instantiation, see winograd64_conv.hip)
+__global__ __launch_bounds__(512, 1) void winograd43_kernel(const ConvArgs p) { winograd43_body<false>(p); }
+__global__ __launch_bounds__(512, 1) void winograd43_rgb_kernel(const ConvArgs p) { winograd43_body<true>(p); }
 
 bool winograd43_supported(int cin, int cout, int H, int W) {
     return cin % kKC == 0 && cin / kKC >= 2 && cout % kBM == 0 && H % kTH == 0 && W % kTW == 0;
@@ -237,8 +308,11 @@ bool winograd43_supported(int cin, int cout, int H, int W) {
 
 size_t winograd43_weight_floats(int cin, int cout) { return (size_t)(cout / kBM) * (cin / kKC) * kWFloats; }
 
-// w_in: the layer's runtime-scaled weights [tap = ky*3+kx][ci][co]; w_out: [m tile of 32][chunk of 4][channel tile][ci][co % 16][36]
-// (units of 578 floats, the chunk zero padded to 4864), position j * 6 + i = (G g G^T)[i][j], i along y
+bool winograd43_rgb_supported(int cout) { return winograd64_rgb_supported(cout) && cout % 64 == 0; }  // (shares launch_winograd64_rgb_coef's table)
+int winograd43_rgb_partials(int cout) { return cout / 16; }
+
+// w_in: the layer's runtime-scaled weights [tap = ky*3+kx][ci][co]; w_out: [m tile of 32][chunk of 4][channel tile][ci][co % 16][36],
+// position j * 6 + i = (G g G^T)[i][j], i along y
 void winograd43_transform_weights(const float* w_in, int cin, int cout, float* w_out) {
     const double G[6][3] = {{1. / 4, 0., 0.},          {-1. / 6, -1. / 6, -1. / 6}, {-1. / 6, 1. / 6, -1. / 6},
                             {1. / 24, 1. / 12, 1. / 6}, {1. / 24, -1. / 12, 1. / 6}, {0., 0., 1.}};
@@ -261,24 +335,30 @@ void winograd43_transform_weights(const float* w_in, int cin, int cout, float* w
 }
 
 hipError_t launch_winograd43_conv(const ConvArgs& args, hipStream_t stream) {
-    if (args.epilogue != kEpilogueFull || args.out == nullptr || !winograd43_supported(args.Cin, args.Cout, args.H, args.W)) return hipErrorInvalidValue;
-    static PerDeviceInt configured;
+    const bool rgb = args.epilogue == kEpilogueFullRgbPart;
+    if (!winograd43_supported(args.Cin, args.Cout, args.H, args.W)) return hipErrorInvalidValue;
+    if (rgb ? (!winograd43_rgb_supported(args.Cout) || args.rgb_coef == nullptr || args.rgb_y == nullptr) : (args.epilogue != kEpilogueFull || args.out == nullptr))
+        return hipErrorInvalidValue;
+    void (*const kernel)(const ConvArgs) = rgb ? winograd43_rgb_kernel : winograd43_kernel;
+    static PerDeviceInt configured[2];
     int unused = 0;
-    hipError_t e = configured.get(
+    hipError_t e = configured[rgb ? 1 : 0].get(
         [&](int, int* value) {
             *value = 1;
-            return hipFuncSetAttribute(reinterpret_cast<const void*>(winograd43_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       (int)(kNBUF * kSlot * sizeof(float)));
+            return hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kNBUF * kSlot * sizeof(float)));
         },
         &unused);
     if (e != hipSuccess) return e;
     ConvArgs a = args;
+    // timing ablations (results are wrong): GANCE_DEBUG_W43 = 1 no DMA after the second k-step, 2 no MFMAs
+    static const int env_debug = [] { const char* v = std::getenv("GANCE_DEBUG_W43"); return v ? std::atoi(v) : 0; }();
+    a.debug_flags = env_debug;
     a.tiles_x = a.W / kTW;
     a.tiles_y = a.H / kTH;
     a.m_tiles = a.Cout / kBM;
     a.total_chunks = a.Cin / kKC;
     a.total_tiles = a.m_tiles * a.tiles_x * a.tiles_y * a.B;
-    hipLaunchKernelGGL(winograd43_kernel, dim3(a.total_tiles), dim3(512), kNBUF * kSlot * sizeof(float), stream, a);
+    hipLaunchKernelGGL(kernel, dim3(a.total_tiles), dim3(512), kNBUF * kSlot * sizeof(float), stream, a);
     return hipGetLastError();
 }
 

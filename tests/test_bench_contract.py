@@ -27,6 +27,8 @@ def test_step_names_map_to_kernels_and_executed_flops() -> None:
     # Winograd F(2x2, 3x3): 16 multiplies per 2x2 tile and input channel instead of 36
     assert abs(bench.executed_fraction("convW8+rgb_64x64_512->512") - 16.0 / 36.0) < 1e-12
     assert bench.executed_fraction("convTF9_128x128_512->256") == 1.0
+    # Winograd F(4x4, 3x3): 36 multiplies per 4x4 tile and input channel instead of 144
+    assert bench.kernel_of_step("convV8+rgb_64x64_512->512") == "winograd43_rgb_kernel" and bench.executed_fraction("convV8+rgb_64x64_512->512") == 0.25
     assert bench.executed_fraction("conv4_16x16_512->512") == 1.0
 
 

@@ -240,10 +240,19 @@ def test_streaming_overlay_with_three_networks_equals_the_one_shot_overlay(tmp_p
         streamed[first : first + len(frames)] = frames
         firsts.append(first)
     assert firsts == list(range(0, num_frames, 4))
-    assert np.array_equal(streamed, want)
-    assert 1 <= timings["overlay_chunks_held_max"] <= 3 and timings["overlays_written"] > 0
+
+    def same_frames(a: np.ndarray, b: np.ndarray) -> bool:
+        # engine calls of 4 frames and of 20 pick different kernel forms for some layers: 1 LSB on a few pixels
+        diff = np.abs(a.astype(np.int16) - b.astype(np.int16))
+        return int(diff.max()) <= 1 and float((diff > 0).mean()) < 1e-3
+
+    assert same_frames(streamed, want)
+    # the overlay regions themselves are copies of the target pictures: wherever the one-shot form wrote one, so did the stream
+    written = (want != background).any(axis=(1, 2, 3))
+    assert written.any() and np.array_equal((np.abs(streamed.astype(np.int16) - background.astype(np.int16)) > 1).any(axis=(1, 2, 3)), written)
+    assert 1 <= timings["overlay_chunks_held_max"] <= 3 and timings["overlays_written"] == int(written.sum())
     # and the network-major windows (2 x 3 pieces) gave the frames of the piece-by-piece path
-    assert np.array_equal(projection_file_blend.projection_file_blend_frames(**common, frames_per_call=4), background)
+    assert same_frames(projection_file_blend.projection_file_blend_frames(**common, frames_per_call=4), background)
 
 
 def test_blend_from_a_real_hdf5_projection_file(tmp_path: Path, golden_dir: Path) -> None:

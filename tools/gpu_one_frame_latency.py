@@ -31,6 +31,17 @@ def main() -> None:
         result[name] = {"median": round(1e3 * float(np.median(times)), 4), "min": round(1e3 * min(times), 4), "p90": round(1e3 * float(np.percentile(times, 90)), 4)}
     engine.close()
     print(json.dumps(result))
+    # the per-launch table of ONE frame (every launch bracketed by HIP events: eager launches, no graph): where the
+    # 2.3 ms of a one-frame call go (the small layers run split-K 8 ... 128 ways at this batch)
+    profiled = hip_lib.Engine(sg2_spec.make_random_variables(resolution, seed=0), resolution, max_batch=1, profile=True)
+    for _ in range(3):
+        profiled.synthesize_w(rng.randn(1, profiled.num_layers, 512).astype(np.float32))
+    total = 0.0
+    for step in profiled.steps():
+        total += step.ms
+        print(f"  {step.name:34s} {step.ms * 1e3:9.1f} us", file=sys.stderr)
+    print(f"  sum of launches {total:.3f} ms", file=sys.stderr)
+    profiled.close()
 
 
 if __name__ == "__main__":

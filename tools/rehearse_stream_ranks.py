@@ -13,6 +13,7 @@ frames of the single-rank run.
 """
 
 import argparse
+import datetime
 import os
 import sys
 import time
@@ -22,7 +23,24 @@ import numpy as np
 
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
 
-L, NUM_PROJECTION, FPS_IN, FPS_OUT, SIDE, OUT_SIDE, NETWORKS, PER_CALL = 512, 45, 15.0, 30.0, 128, 200, 3, 8
+L, NUM_PROJECTION, FPS_IN, FPS_OUT, NETWORKS = 512, 45, 15.0, 30.0, 3
+# GANCE_REHEARSAL="side,out_side,frames_per_call,overlay": e.g. "1024,2160,8,0" (configs[3]'s shape) or "128,200,8,1"
+# (three networks + the streaming overlay gate: configs[4]'s shape); default 128 -> 200, 8 frames per call, no overlay
+SIDE, OUT_SIDE, PER_CALL, OVERLAY = (int(v) for v in os.environ.get("GANCE_REHEARSAL", "128,200,8,0").split(","))
+
+
+class BrightPicturesHaveAFace:  # pylint: disable=too-few-public-methods
+    """Stand-in landmark detector (the real one is external): a picture with a bright first pixel has one face."""
+
+    @staticmethod
+    def face_landmarks(face_image):
+        if int(face_image[0, 0].sum()) < 300:
+            return []
+        scale = face_image.shape[0] / 128.0
+        return [{
+            "left_eye": ((int(30 * scale), int(40 * scale)), (int(50 * scale), int(52 * scale))),
+            "right_eye": ((int(70 * scale), int(41 * scale)), (int(95 * scale), int(55 * scale))),
+        }]
 
 
 def job(directory: Path):
@@ -36,6 +54,9 @@ def job(directory: Path):
         frames_to_visualize=None, output_fps=FPS_OUT, output_side_length=OUT_SIDE, alpha=0.25, fft_roll_enabled=True,
         fft_amplitude_range=(-5, 5), projection_file_path=str(directory / "projection.npz"), blend_depth=12,
         frames_per_call=PER_CALL,
+        overlay=projection_file_blend.OverlayParameters(phash_distance=64, bbox_distance=5.0, track_length=4, face_finder=BrightPicturesHaveAFace())
+        if OVERLAY
+        else None,
     )
     collected, firsts = None, []
     for first, total, frames in chunks:
@@ -62,7 +83,10 @@ def main() -> int:
         num_frames = int(NUM_PROJECTION * FPS_OUT / FPS_IN)
         wavfile.write(str(directory / "audio.wav"), int(L * FPS_OUT), synthetic.synthetic_audio(num_frames, L, seed=61, frames_per_second=FPS_OUT))
         latents = synthetic.synthetic_final_latents(NUM_PROJECTION, L, seed=62)
-        pfr.write_projection_npz(directory / "projection.npz", latents.reshape(18, NUM_PROJECTION, L).transpose(1, 0, 2), projection_fps=FPS_IN)
+        targets = (np.kron(np.random.RandomState(63).rand(NUM_PROJECTION, 8, 8, 3), np.ones((1, 16, 16, 1))) * 255).astype(np.uint8)
+        pfr.write_projection_npz(
+            directory / "projection.npz", latents.reshape(18, NUM_PROJECTION, L).transpose(1, 0, 2), projection_fps=FPS_IN, target_images=targets
+        )
         for seed in range(NETWORKS):
             network_file.write_random_network(directory / f"net_{seed}.pkl", SIDE, seed=seed)
         frames, firsts = job(directory)
@@ -73,7 +97,7 @@ def main() -> int:
     import torch.distributed as dist  # pylint: disable=import-outside-toplevel
 
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    dist.init_process_group(backend="gloo")
+    dist.init_process_group(backend="gloo", timeout=datetime.timedelta(seconds=300))
     rank, world_size = dist.get_rank(), dist.get_world_size()
     start = time.perf_counter()
     frames, firsts = job(args.check)
@@ -84,7 +108,8 @@ def main() -> int:
         same = frames is not None and frames.shape == want.shape and np.array_equal(frames, want)
         ordered = firsts == sorted(firsts) and firsts[0] == 0
         print(
-            f"{world_size} ranks on one GPU over gloo: {0 if frames is None else frames.shape[0]} frames in {len(firsts)} ordered chunks "
+            f"{world_size} ranks on one GPU over gloo, {SIDE}^2 -> {OUT_SIDE}^2, {NETWORKS} networks, {PER_CALL} frames per call, overlay {bool(OVERLAY)}: "
+            f"{0 if frames is None else frames.shape[0]} frames in {len(firsts)} ordered chunks "
             f"({elapsed:.2f} s incl. network loading), identical to the single-rank run: {same}, chunk order ok: {ordered}"
         )
         status = 0 if same and ordered else 1
