@@ -241,7 +241,7 @@ struct gance_workspace {
     }
 };
 
-constexpr int kWino43DefaultMaxRes = 0;  // (off until measured faster: see DESIGN.md §3)
+constexpr int kWino43DefaultMaxRes = 1024;  // every Conv1 from 64x64 up (measured faster than the F(2x2,3x3) kernel on all five: DESIGN.md §3)
 
 struct GraphEntry {
     hipGraphExec_t exec = nullptr;

@@ -33,9 +33,16 @@
 
 #include <algorithm>
 #include <cstdint>
+#include <cstdio>
 #include <cstdlib>
 
 #include "kernels.h"
+
+// window reads of a k-step: 0 = two 8-byte reads + one ds_read2_b32 per row, 1 = three aligned 16-byte reads, 2 = one aligned
+// 16-byte read + two DPP row shifts
+#ifndef GANCE_W43_WINDOW
+#define GANCE_W43_WINDOW 0
+#endif
 
 namespace gance {
 
@@ -60,7 +67,10 @@ constexpr int kPieces = kWPieces + kPPieces;   // 39 (+ one repeat of patch piec
 constexpr int kPiecesPerWave = 5;
 static_assert(kPieces <= 8 * kPiecesPerWave && kPieces > 7 * kPiecesPerWave, "five LDS-DMA pieces per wave and chunk");
 constexpr int kSlot = kPieces * 256;           // 9984 floats = 39 KB
-constexpr int kNBUF = 3;
+#ifndef GANCE_W43_NBUF
+#define GANCE_W43_NBUF 3
+#endif
+constexpr int kNBUF = GANCE_W43_NBUF;          // ring slots: chunk q + kNBUF - 1 is issued in k-step q
 
 // B^T of F(4,3), points 0, +-1, +-2 (Lavin & Gray): 12 vector instructions, on one window line or on two at once
 template <typename T>
@@ -137,19 +147,31 @@ __device__ __forceinline__ void winograd43_body(const ConvArgs& p) {
     const int w_tile_base = m_tile * n * (kWFloats * 4);   // bytes: [m tile][chunk][kWFloats]
     const int x_tile_base = (y0 * Wp + x0) * 4;            // patch row 0 = image row y0 - 1 = buffer row y0; column x0 - 4 = buffer column x0
     const int x_chunk_step = kKC * Hp * Wp * 4;
-    auto issue_chunk = [&](int chunk, int slot) {
+    auto issue_piece = [&](int chunk, int slot, int r) {
         float* const base = smem + slot * kSlot;
-#pragma unroll
-        for (int r = 0; r < kPiecesPerWave; ++r) {
-            int piece = wave * kPiecesPerWave + r;  // (wave is scalar: the branches are uniform)
-            if (piece >= kPieces) piece = kWPieces;
-            if (piece < kWPieces)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, (lds_ptr_t)(base + piece * 256), 16, piece_voff[r], w_tile_base + chunk * (kWFloats * 4), 0, 0);
-            else
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(x_rsrc, (lds_ptr_t)(base + kWFloats + (piece - kWPieces) * 256), 16, piece_voff[r],
-                                                         x_tile_base + chunk * x_chunk_step, 0, 0);
-        }
+        int piece = wave * kPiecesPerWave + r;  // (wave is scalar: the branches are uniform)
+        if (piece >= kPieces) piece = kWPieces;
+        if (piece < kWPieces)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, (lds_ptr_t)(base + piece * 256), 16, piece_voff[r], w_tile_base + chunk * (kWFloats * 4), 0, 0);
+        else
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(x_rsrc, (lds_ptr_t)(base + kWFloats + (piece - kWPieces) * 256), 16, piece_voff[r],
+                                                     x_tile_base + chunk * x_chunk_step, 0, 0);
     };
+    auto issue_chunk = [&](int chunk, int slot) {
+#pragma unroll
+        for (int r = 0; r < kPiecesPerWave; ++r) issue_piece(chunk, slot, r);
+    };
+
+    // Which half of the pipeline this wave runs (see the k-loop): the two waves that share a SIMD must differ, and which
+    // waves share one is the dispatcher's choice, so the wave asks the hardware (HW_ID.simd_id) and takes a ticket per SIMD.
+    __shared__ int simd_tickets[4];
+    if (tid < 4) simd_tickets[tid] = 0;
+    __syncthreads();
+    int role = 0;
+    if (lane == 0) role = atomicAdd(&simd_tickets[__builtin_amdgcn_s_getreg((1 << 11) | (4 << 6) | 4) & 3], 1) & 1;  // hwreg(HW_REG_HW_ID, 4, 2)
+    role = __builtin_amdgcn_readfirstlane(role);
+    if (p.debug_flags & 16) role = 0;  // (timing experiment: no skew)
+    if (p.debug_flags & 64) role = cot;  // (timing experiment: roles by channel tile)
 
     f32x4 acc[36];
 #pragma unroll
@@ -167,12 +189,39 @@ __device__ __forceinline__ void winograd43_body(const ConvArgs& p) {
         const float* const P = smem + slot * kSlot + win_off;
         const float* const U = smem + slot * kSlot + a_off;
         f32x2 c45[6], c67[6], c38[6];
+#if GANCE_W43_WINDOW == 2
+        float halo[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (n16 == 0 || n16 == 15) {  // column 3 (x0 - 1) for the row's first tile, column 68 (x0 + 64) for its last
+#pragma unroll
+            for (int y = 0; y < 6; ++y) halo[y] = P[y * kPW + (n16 == 0 ? 3 : 8)];
+        }
+#endif
 #pragma unroll
         for (int y = 0; y < 6; ++y) {
+#if GANCE_W43_WINDOW == 1
+            // three aligned 16-byte reads per window row (columns 4 n .. 4 n + 11): bank-conflict free, twice the bytes
+            const f32x4 q0 = *reinterpret_cast<const f32x4*>(P + y * kPW);
+            const f32x4 q1 = *reinterpret_cast<const f32x4*>(P + y * kPW + 4);
+            const f32x4 q2 = *reinterpret_cast<const f32x4*>(P + y * kPW + 8);
+            c45[y] = f32x2{q1[0], q1[1]};
+            c67[y] = f32x2{q1[2], q1[3]};
+            c38[y] = f32x2{q0[3], q2[0]};
+#elif GANCE_W43_WINDOW == 2
+            // ONE aligned 16-byte read per row (columns 4 n + 4 .. + 7): column 4 n + 3 is the left neighbour's column 7 and
+            // 4 n + 8 the right neighbour's column 4, fetched by DPP row shifts; the row's end lanes keep the halo value read
+            // below (bound_ctrl off: a lane without a source keeps `old`)
+            const f32x4 q1 = *reinterpret_cast<const f32x4*>(P + y * kPW + 4);
+            c45[y] = f32x2{q1[0], q1[1]};
+            c67[y] = f32x2{q1[2], q1[3]};
+            c38[y][0] = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(halo[y]), __float_as_int(q1[3]), 0x111, 0xf, 0xf, false));  // row_shr:1
+            c38[y][1] = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(halo[y]), __float_as_int(q1[0]), 0x101, 0xf, 0xf, false));  // row_shl:1
+#else
+            // two 8-byte reads + one ds_read2_b32 per row: fewest bytes, 2- and 4-way bank conflicts
             c45[y] = *reinterpret_cast<const f32x2*>(P + y * kPW + 4);
             c67[y] = *reinterpret_cast<const f32x2*>(P + y * kPW + 6);
             c38[y][0] = P[y * kPW + 3];
             c38[y][1] = P[y * kPW + 8];
+#endif
         }
 #pragma unroll
         for (int k = 0; k < 9; ++k) {
@@ -183,6 +232,13 @@ __device__ __forceinline__ void winograd43_body(const ConvArgs& p) {
             A[4 * k + 3] = t[3];
         }
         f32x2 t45[6], t67[6], t38[6];
+        if (p.debug_flags & 32) {  // (timing experiment: no transform arithmetic)
+#pragma unroll
+            for (int i = 0; i < 6; ++i) {
+                V[i] = c45[i][0]; V[6 + i] = c45[i][1]; V[12 + i] = c67[i][0]; V[18 + i] = c67[i][1]; V[24 + i] = c38[i][0]; V[30 + i] = c38[i][1];
+            }
+            return;
+        }
         input_transform6<f32x2>(c45[0], c45[1], c45[2], c45[3], c45[4], c45[5], t45);
         input_transform6<f32x2>(c67[0], c67[1], c67[2], c67[3], c67[4], c67[5], t67);
         input_transform6<f32x2>(c38[0], c38[1], c38[2], c38[3], c38[4], c38[5], t38);
@@ -196,38 +252,71 @@ __device__ __forceinline__ void winograd43_body(const ConvArgs& p) {
             for (int j = 0; j < 6; ++j) V[j * 6 + i] = v[j];
         }
     };
-    auto multiply = [&]() {
-        if (p.debug_flags & 2) return;
+    // The 36 MFMAs of a k-step, and woven between them (one per seven MFMAs: an LDS-DMA instruction takes the wave about
+    // 120 cycles to issue, which the matrix pipe hides) the five DMA pieces of chunk `stage_chunk` if there is one.
+    auto multiply = [&](int stage_chunk, int stage_slot) {
+        if (p.debug_flags & 2) {
+            if (stage_chunk >= 0) issue_chunk(stage_chunk, stage_slot);
+            return;
+        }
 #pragma unroll
-        for (int pos = 0; pos < 36; ++pos) acc[pos] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[pos], V[pos], acc[pos], 0, 0, 0);
+        for (int pos = 0; pos < 36; ++pos) {
+            acc[pos] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[pos], V[pos], acc[pos], 0, 0, 0);
+            if (pos % 7 == 3 && stage_chunk >= 0) issue_piece(stage_chunk, stage_slot, pos / 7);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);  // 4 MFMAs, then 4 x (one LDS-DMA issue, 7 MFMAs), one issue, 4 MFMAs
+        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 7, 0);
+            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
     };
 
-    issue_chunk(0, 0);
-    if (n > 1) issue_chunk(1, 1);
+#pragma unroll
+    for (int c = 0; c < kNBUF - 1; ++c)
+        if (c < n) issue_chunk(c, c);
 
-    // The two waves of a SIMD (wave w and w + 4: the two channel tiles of a tile row) run half a k-step apart: in the
-    // interval between two barriers the cot = 0 wave loads and transforms chunk q and then multiplies it, the cot = 1 wave
-    // first multiplies chunk q - 1 out of its registers and then loads and transforms chunk q. While one of them waits
-    // for LDS or issues vector instructions the other keeps the matrix pipe busy.
+    // The two waves of a SIMD run half a k-step apart: in the interval between two barriers the role-0 wave loads and
+    // transforms chunk q and then multiplies it, the role-1 wave first multiplies chunk q - 1 out of its registers and then
+    // loads and transforms chunk q. While one of them waits for LDS or issues vector instructions the other keeps the
+    // matrix pipe busy. (ONE loop with role tests: split into a straight-line loop per role, hipcc's code ran 12 % slower.)
     int slot = 0;
     for (int q = 0; q < n; ++q) {
-        if (q + 1 < n && !(p.debug_flags & 1))
+        // chunk q must have landed; the kNBUF - 2 younger ones may stay in flight (fewer near the end of the tile)
+        if (q + kNBUF - 2 < n && !(p.debug_flags & 1))
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"((kNBUF - 2) * kPiecesPerWave) : "memory");
+        else if (kNBUF > 3 && q + 1 < n && !(p.debug_flags & 1))
             asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kPiecesPerWave) : "memory");
         else
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        if (q + 2 < n && !((p.debug_flags & 1) && q > 0)) issue_chunk(q + 2, slot == 0 ? 2 : slot - 1);  // (q + 2) % 3 == (slot + 2) % 3
         __builtin_amdgcn_sched_barrier(0);
-        if (cot == 0) load_transform(slot);
+        const bool stamp = (p.debug_flags & 128) && blockIdx.x == 256 && q >= 8 && q < 16 && lane == 0;
+        unsigned long long* const stamps = p.debug_stamps + ((size_t)wave * 8 + (q & 7)) * 4;
+        if (stamp) stamps[0] = __builtin_readcyclecounter();
+        if (role == 0) load_transform(slot);
         __builtin_amdgcn_sched_barrier(0);
-        if (cot == 0 || q > 0) multiply();
+        if (stamp) stamps[1] = __builtin_readcyclecounter();
+        // chunk q + kNBUF - 1 goes into the slot k-step q - 1 read (every wave is past the barrier: nobody reads it any more);
+        // its DMA pieces ride in the shadow of this interval's MFMAs (right behind the barrier they sat on the critical path
+        // of every wave: five issues cost about 600 cycles)
+        const int stage_chunk = (q + kNBUF - 1 < n && !((p.debug_flags & 1) && q > 0)) ? q + kNBUF - 1 : -1;
+        const int stage_slot = slot == 0 ? kNBUF - 1 : slot - 1;
+        if (role == 0 || q > 0)
+            multiply(stage_chunk, stage_slot);
+        else if (stage_chunk >= 0)
+            issue_chunk(stage_chunk, stage_slot);
         __builtin_amdgcn_sched_barrier(0);
-        if (cot != 0) load_transform(slot);
+        if (stamp) stamps[2] = __builtin_readcyclecounter();
+        if (role != 0) load_transform(slot);
         __builtin_amdgcn_sched_barrier(0);
+        if (stamp) stamps[3] = __builtin_readcyclecounter() | ((unsigned long long)role << 63);
         slot = slot == kNBUF - 1 ? 0 : slot + 1;
     }
-    if (cot != 0) multiply();
+    if (role != 0) multiply(-1, 0);
 
     // ---- epilogue: lane (n16, g) holds channels 4 g + r (r = 0 .. 3) of tile n16 for all 36 positions ----
     const int oy0 = y0 + 4 * pg, ox0 = x0 + 4 * n16;
@@ -308,7 +397,7 @@ bool winograd43_supported(int cin, int cout, int H, int W) {
 
 size_t winograd43_weight_floats(int cin, int cout) { return (size_t)(cout / kBM) * (cin / kKC) * kWFloats; }
 
-bool winograd43_rgb_supported(int cout) { return winograd64_rgb_supported(cout) && cout % 64 == 0; }  // (shares launch_winograd64_rgb_coef's table)
+bool winograd43_rgb_supported(int cout) { return winograd64_rgb_supported(cout); }  // (shares launch_winograd64_rgb_coef's table: Cout = 32 or a multiple of 64)
 int winograd43_rgb_partials(int cout) { return cout / 16; }
 
 // w_in: the layer's runtime-scaled weights [tap = ky*3+kx][ci][co]; w_out: [m tile of 32][chunk of 4][channel tile][ci][co % 16][36],
@@ -358,7 +447,29 @@ hipError_t launch_winograd43_conv(const ConvArgs& args, hipStream_t stream) {
     a.m_tiles = a.Cout / kBM;
     a.total_chunks = a.Cin / kKC;
     a.total_tiles = a.m_tiles * a.tiles_x * a.tiles_y * a.B;
+    static unsigned long long* stamps = nullptr;
+    if (env_debug & 128) {  // per-wave cycle stamps of k-steps 8 .. 15 of block 256, printed after the launch
+        if (stamps == nullptr && hipMalloc((void**)&stamps, 8 * 8 * 4 * sizeof(unsigned long long)) != hipSuccess) return hipErrorOutOfMemory;
+        (void)hipMemsetAsync(stamps, 0, 8 * 8 * 4 * sizeof(unsigned long long), stream);
+        a.debug_stamps = stamps;
+    }
     hipLaunchKernelGGL(kernel, dim3(a.total_tiles), dim3(512), kNBUF * kSlot * sizeof(float), stream, a);
+    if ((env_debug & 128) && a.total_tiles > 256) {
+        (void)hipStreamSynchronize(stream);
+        unsigned long long h[8 * 8 * 4];
+        (void)hipMemcpy(h, stamps, sizeof(h), hipMemcpyDeviceToHost);
+        unsigned long long t0 = ~0ull;
+        for (int w = 0; w < 8; ++w) t0 = std::min(t0, h[(w * 8) * 4] & ~(1ull << 63));
+        std::fprintf(stderr, "W43 STAMPS (cycles from the first stamp; per wave: role, then per k-step start / after first L+T / after multiply / end)\n");
+        for (int w = 0; w < 8; ++w) {
+            std::fprintf(stderr, "  wave %d role %d:", w, (int)(h[(w * 8) * 4 + 3] >> 63));
+            for (int q = 0; q < 8; ++q) {
+                const unsigned long long* e = h + (w * 8 + q) * 4;
+                std::fprintf(stderr, " | %llu %llu %llu %llu", e[0] - t0, e[1] - t0, e[2] - t0, (e[3] & ~(1ull << 63)) - t0);
+            }
+            std::fprintf(stderr, "\n");
+        }
+    }
     return hipGetLastError();
 }
 
