@@ -38,19 +38,12 @@
 
 #include "kernels.h"
 
-// window reads of a k-step: 0 = two 8-byte reads + one ds_read2_b32 per row, 1 = three aligned 16-byte reads, 2 = one aligned
-// 16-byte read + two DPP row shifts
-#ifndef GANCE_W43_WINDOW
-#define GANCE_W43_WINDOW 0
-#endif
-
 namespace gance {
 
 namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
-typedef float f32x2_lds __attribute__((ext_vector_type(2), aligned(4)));  // two window columns, any two dwords: ds_read2_b32
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
 constexpr int kKC = 4;                         // input channels per chunk = one k-step of the 16x16x4 MFMA
@@ -67,10 +60,12 @@ constexpr int kPieces = kWPieces + kPPieces;   // 39 (+ one repeat of patch piec
 constexpr int kPiecesPerWave = 5;
 static_assert(kPieces <= 8 * kPiecesPerWave && kPieces > 7 * kPiecesPerWave, "five LDS-DMA pieces per wave and chunk");
 constexpr int kSlot = kPieces * 256;           // 9984 floats = 39 KB
-#ifndef GANCE_W43_NBUF
-#define GANCE_W43_NBUF 3
-#endif
-constexpr int kNBUF = GANCE_W43_NBUF;          // ring slots: chunk q + kNBUF - 1 is issued in k-step q
+constexpr int kNBUF = 3;                       // ring slots: chunk G + 2 is issued during k-step G (a fourth slot measured no faster)
+// constants of a tile, fetched by LDS-DMA with its first chunk (a global load in the epilogue costs its whole latency once
+// per tile, and the wait behind it would drain the ring): demod | bias | next layer's style (32 each, padded to 64) |
+// noise [16][64] | (RGB) A operands of the ToRGB product [2 channel tiles][4 steps][64 lanes]
+constexpr int kConstD = 0, kConstB = 64, kConstS = 128, kConstNoise = 192, kConstRgb = kConstNoise + kTH * kTW, kConstFloats = kConstRgb + 512;
+constexpr int kStoresPerEpilogue = 16, kRgbStores = 12;
 
 // B^T of F(4,3), points 0, +-1, +-2 (Lavin & Gray): 12 vector instructions, on one window line or on two at once
 template <typename T>
@@ -96,132 +91,171 @@ __device__ __forceinline__ void output_transform6(float m0, float m1, float m2, 
     y[3] = fmaf(8.f, d2, d1) + m5;
 }
 
+struct Tile43 {
+    int m_tile, y0, x0, b0;
+};
+
+// The lane id, computed where it is used: per-lane values derived once at kernel entry would be live across the epilogue,
+// where every register is taken; hipcc spills them, and a scratch reload inside the k-steps is a vector-memory load whose
+// wait drains the LDS-DMA ring. Everything per-lane is therefore re-derived from this after every epilogue.
+__device__ __forceinline__ int fresh_lane() {
+    int l;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+    return l;
+}
+
 }  // namespace
 
 template <bool RGB>
 __device__ __forceinline__ void winograd43_body(const ConvArgs& p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* const const0 = smem + kNBUF * kSlot;  // two sets of tile constants (tile parity)
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int lane = tid & 63;
-    const int n16 = lane & 15, g = lane >> 4;
     const int cot = wave >> 2, pg = wave & 3;  // channel tile and tile row of this wave
     const int Hp = p.H + 2, Wp = p.W + 8;
-    const int n = p.total_chunks;
+    const int n = p.total_chunks;               // chunks per tile
+    const int my_tiles = (p.total_tiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int total = my_tiles * n;             // chunks of this block's stream
 
-    // virtual block id -> tile, XCD-aware (consecutive ids run on one XCD: the channel tiles of a pixel tile share its L2)
-    int b0, m_tile, y0, x0;
-    {
-        const int v = (int)blockIdx.x;
+    // tile i of this block -> tile, XCD-aware (a persistent block strides by a multiple of 8; consecutive ids run on one XCD:
+    // the channel tiles of a pixel tile share its L2)
+    auto decode = [&](int i) {
+        const int v = (int)blockIdx.x + i * (int)gridDim.x;
         const int nwg = p.total_tiles;
         const int q = nwg >> 3, r = nwg & 7, xcd = v & 7;
         int id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (v >> 3);
-        m_tile = id % p.m_tiles;
+        Tile43 t;
+        t.m_tile = id % p.m_tiles;
         id /= p.m_tiles;
-        x0 = (id % p.tiles_x) * kTW;
+        t.x0 = (id % p.tiles_x) * kTW;
         id /= p.tiles_x;
-        y0 = (id % p.tiles_y) * kTH;
-        b0 = id / p.tiles_y;
-    }
+        t.y0 = (id % p.tiles_y) * kTH;
+        t.b0 = id / p.tiles_y;
+        return t;
+    };
 
-    // ---- LDS-DMA pieces of this wave: piece wave * 5 + r; < 18: weights (linear), else patch piece (per-lane source offset)
+    // ---- per-lane values of the k-steps (re-derived after every epilogue: see fresh_lane) ----
+    // LDS-DMA pieces of this wave: piece wave * 5 + r; < 18: weights (linear), else patch piece (per-lane source offset);
+    // operand offsets of the lane inside a slot (floats): its window (rows 4 pg .. + 5, columns 4 n + 3 .. + 8) and its weights
     const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, 0x7fffffff, 0x00020000);
-    const __amdgpu_buffer_rsrc_t x_rsrc =
-        __builtin_amdgcn_make_buffer_rsrc((void*)(p.x + (size_t)b0 * p.x_b_stride), 0, 0x7fffffff, 0x00020000);
     int piece_voff[kPiecesPerWave];
+    int win_off, a_off;
+    auto lane_setup = [&]() {
+        const int lane = fresh_lane();
+        const int n16 = lane & 15, g = lane >> 4;
 #pragma unroll
-    for (int r = 0; r < kPiecesPerWave; ++r) {
-        int piece = wave * kPiecesPerWave + r;
-        if (piece >= kPieces) piece = kWPieces;  // (the fortieth slot repeats patch piece 0: same bytes to the same place)
-        if (piece < kWPieces) {
-            piece_voff[r] = piece * 1024 + lane * 16;
-        } else {
-            int f = (piece - kWPieces) * 64 + lane;
-            if (f >= kPatchF4) f = (piece - kWPieces) * 64;  // (the last piece is a quarter full: the rest re-copy its first float4 into padding)
-            const int q4 = f % (kPW / 4);
-            const int row = (f / (kPW / 4)) % kPH;
-            const int c = f / (kPW / 4 * kPH);
-            piece_voff[r] = ((c * Hp + row) * Wp + 4 * q4) * 4;
+        for (int r = 0; r < kPiecesPerWave; ++r) {
+            int piece = wave * kPiecesPerWave + r;
+            if (piece >= kPieces) piece = kWPieces;  // (the fortieth slot repeats patch piece 0: same bytes to the same place)
+            if (piece < kWPieces) {
+                piece_voff[r] = piece * 1024 + lane * 16;
+            } else {
+                int f = (piece - kWPieces) * 64 + lane;
+                if (f >= kPatchF4) f = (piece - kWPieces) * 64;  // (the last piece is a quarter full: the rest re-copy its first float4 into padding)
+                const int q4 = f % (kPW / 4);
+                const int row = (f / (kPW / 4)) % kPH;
+                const int c = f / (kPW / 4 * kPH);
+                piece_voff[r] = ((c * Hp + row) * Wp + 4 * q4) * 4;
+            }
         }
-    }
-    const int w_tile_base = m_tile * n * (kWFloats * 4);   // bytes: [m tile][chunk][kWFloats]
-    const int x_tile_base = (y0 * Wp + x0) * 4;            // patch row 0 = image row y0 - 1 = buffer row y0; column x0 - 4 = buffer column x0
+        win_off = kWFloats + g * kPlane + (4 * pg) * kPW + 4 * n16;
+        a_off = (cot * 4 + g) * kUnit + n16 * 36;
+    };
+    lane_setup();
+    // Staging side of the stream (all scalar): the next chunk to fetch = chunk st_q of this block's tile st_tile, into ring
+    // slot st_slot; byte offsets of its weights and its patch; the patch's buffer resource (one per sample).
+    int st_tile = 0, st_q = 0, st_slot = 0, st_w = 0, st_x = 0, st_count = 0;
+    __amdgpu_buffer_rsrc_t st_x_rsrc = w_rsrc;
     const int x_chunk_step = kKC * Hp * Wp * 4;
-    auto issue_piece = [&](int chunk, int slot, int r) {
-        float* const base = smem + slot * kSlot;
+    int cur_slot = 0, cur_w = 0, cur_x = 0;  // of the chunk being staged
+    bool cur_valid = false;
+    // Opens the next chunk of the stream (runs once per k-step, outside the MFMA weave: it branches). A chunk that opens a
+    // tile also brings the tile's constants: up to two extra DMA instructions per wave, issued here, i.e. BEFORE the
+    // chunk's five pieces (the counted waits allow the five youngest operations to be in flight).
+    auto stage_begin = [&]() {
+        cur_valid = st_count < total;
+        if (!cur_valid) return;
+        if (st_q == 0) {
+            const Tile43 t = decode(st_tile);
+            const int lane = fresh_lane();
+            st_x_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(p.x + (size_t)t.b0 * p.x_b_stride), 0, 0x7fffffff, 0x00020000);
+            st_w = t.m_tile * n * (kWFloats * 4);  // bytes: [m tile][chunk][kWFloats]
+            st_x = (t.y0 * Wp + t.x0) * 4;         // patch row 0 = image row y0 - 1 = buffer row y0; column x0 - 4 = buffer column x0
+            float* const set = const0 + (st_tile & 1) * kConstFloats;
+            const int co = t.m_tile * kBM;
+            if (wave < 3) {  // demod / bias / next style of the block's 32 channels: one dword piece each (the resource's bound clips the other lanes)
+                const float* src = wave == 0 ? p.d + (size_t)t.b0 * p.d_stride + co
+                                             : (wave == 1 ? p.bias + co : (p.s_next != nullptr ? p.s_next + (size_t)t.b0 * p.s_stride + co : nullptr));
+                if (src != nullptr) {
+                    const __amdgpu_buffer_rsrc_t c_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)src, 0, kBM * 4, 0x00020000);
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(c_rsrc, (lds_ptr_t)(set + wave * 64), 4, lane * 4, 0, 0, 0);
+                }
+            } else if (wave < 7) {  // noise rows 4 (wave - 3) .. + 3 of the tile: 4 x 64 floats, one 16-byte piece
+                if (p.noise != nullptr) {
+                    const __amdgpu_buffer_rsrc_t nz_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.noise, 0, 0x7fffffff, 0x00020000);
+                    const int row = 4 * (wave - 3) + (lane >> 4);
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(nz_rsrc, (lds_ptr_t)(set + kConstNoise + (wave - 3) * 256), 16,
+                                                             ((t.y0 + row) * p.OW + t.x0 + 4 * (lane & 15)) * 4, 0, 0, 0);
+                }
+            } else if (RGB) {  // the A operands of the ToRGB product: [b][Cout / 4 steps][64 lanes], steps 8 m_tile .. + 7: two 16-byte pieces
+                const __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+                    (void*)(p.rgb_coef + ((size_t)t.b0 * (p.Cout / 4) + 8 * t.m_tile) * 64), 0, 512 * 4, 0x00020000);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rsrc, (lds_ptr_t)(set + kConstRgb), 16, lane * 16, 0, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rsrc, (lds_ptr_t)(set + kConstRgb + 256), 16, lane * 16, 1024, 0, 0);
+            }
+        }
+        cur_slot = st_slot;
+        cur_w = st_w;
+        cur_x = st_x;
+        st_w += kWFloats * 4;
+        st_x += x_chunk_step;
+        st_slot = st_slot == kNBUF - 1 ? 0 : st_slot + 1;
+        ++st_count;
+        if (++st_q == n) {
+            st_q = 0;
+            ++st_tile;
+        }
+    };
+    // piece r of the chunk stage_begin() opened: one instruction, no control flow beyond the wave-uniform choice of its kind
+    auto stage_piece = [&](int r) {
+        float* const base = smem + cur_slot * kSlot;
         int piece = wave * kPiecesPerWave + r;  // (wave is scalar: the branches are uniform)
         if (piece >= kPieces) piece = kWPieces;
         if (piece < kWPieces)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, (lds_ptr_t)(base + piece * 256), 16, piece_voff[r], w_tile_base + chunk * (kWFloats * 4), 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, (lds_ptr_t)(base + piece * 256), 16, piece_voff[r], cur_w, 0, 0);
         else
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(x_rsrc, (lds_ptr_t)(base + kWFloats + (piece - kWPieces) * 256), 16, piece_voff[r],
-                                                     x_tile_base + chunk * x_chunk_step, 0, 0);
-    };
-    auto issue_chunk = [&](int chunk, int slot) {
-#pragma unroll
-        for (int r = 0; r < kPiecesPerWave; ++r) issue_piece(chunk, slot, r);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(st_x_rsrc, (lds_ptr_t)(base + kWFloats + (piece - kWPieces) * 256), 16, piece_voff[r], cur_x, 0, 0);
     };
 
-    // Which half of the pipeline this wave runs (see the k-loop): the two waves that share a SIMD must differ, and which
+    // Which half of the pipeline this wave runs (see the stream loop): the two waves that share a SIMD must differ, and which
     // waves share one is the dispatcher's choice, so the wave asks the hardware (HW_ID.simd_id) and takes a ticket per SIMD.
     __shared__ int simd_tickets[4];
     if (tid < 4) simd_tickets[tid] = 0;
     __syncthreads();
     int role = 0;
-    if (lane == 0) role = atomicAdd(&simd_tickets[__builtin_amdgcn_s_getreg((1 << 11) | (4 << 6) | 4) & 3], 1) & 1;  // hwreg(HW_REG_HW_ID, 4, 2)
+    if ((tid & 63) == 0) role = atomicAdd(&simd_tickets[__builtin_amdgcn_s_getreg((1 << 11) | (4 << 6) | 4) & 3], 1) & 1;  // hwreg(HW_REG_HW_ID, 4, 2)
     role = __builtin_amdgcn_readfirstlane(role);
-    if (p.debug_flags & 16) role = 0;  // (timing experiment: no skew)
-    if (p.debug_flags & 64) role = cot;  // (timing experiment: roles by channel tile)
 
     f32x4 acc[36];
 #pragma unroll
     for (int i = 0; i < 36; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    // operand offsets of this lane inside a slot (floats)
-    const int win_off = kWFloats + g * kPlane + (4 * pg) * kPW + 4 * n16;  // window rows 4 pg .. + 5, columns 4 n + 3 .. + 8
-    const int a_off = (cot * 4 + g) * kUnit + n16 * 36;
-
     // L + T: this lane's weights of the chunk (position j * 6 + i) and V = B^T d B of its window, both into registers.
     // Column pass first, two window columns per packed instruction (the pairs (4,5), (6,7) are aligned 8-byte reads,
-    // (3, 8) one ds_read2_b32), then the row pass line by line.
+    // (3, 8) one ds_read2_b32: fewest bytes; three aligned 16-byte reads per row -- no bank conflicts, twice the bytes -- and
+    // one 16-byte read + two DPP row shifts both measured slower), then the row pass line by line.
     float V[36], A[36];
     auto load_transform = [&](int slot) {
         const float* const P = smem + slot * kSlot + win_off;
         const float* const U = smem + slot * kSlot + a_off;
         f32x2 c45[6], c67[6], c38[6];
-#if GANCE_W43_WINDOW == 2
-        float halo[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        if (n16 == 0 || n16 == 15) {  // column 3 (x0 - 1) for the row's first tile, column 68 (x0 + 64) for its last
-#pragma unroll
-            for (int y = 0; y < 6; ++y) halo[y] = P[y * kPW + (n16 == 0 ? 3 : 8)];
-        }
-#endif
 #pragma unroll
         for (int y = 0; y < 6; ++y) {
-#if GANCE_W43_WINDOW == 1
-            // three aligned 16-byte reads per window row (columns 4 n .. 4 n + 11): bank-conflict free, twice the bytes
-            const f32x4 q0 = *reinterpret_cast<const f32x4*>(P + y * kPW);
-            const f32x4 q1 = *reinterpret_cast<const f32x4*>(P + y * kPW + 4);
-            const f32x4 q2 = *reinterpret_cast<const f32x4*>(P + y * kPW + 8);
-            c45[y] = f32x2{q1[0], q1[1]};
-            c67[y] = f32x2{q1[2], q1[3]};
-            c38[y] = f32x2{q0[3], q2[0]};
-#elif GANCE_W43_WINDOW == 2
-            // ONE aligned 16-byte read per row (columns 4 n + 4 .. + 7): column 4 n + 3 is the left neighbour's column 7 and
-            // 4 n + 8 the right neighbour's column 4, fetched by DPP row shifts; the row's end lanes keep the halo value read
-            // below (bound_ctrl off: a lane without a source keeps `old`)
-            const f32x4 q1 = *reinterpret_cast<const f32x4*>(P + y * kPW + 4);
-            c45[y] = f32x2{q1[0], q1[1]};
-            c67[y] = f32x2{q1[2], q1[3]};
-            c38[y][0] = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(halo[y]), __float_as_int(q1[3]), 0x111, 0xf, 0xf, false));  // row_shr:1
-            c38[y][1] = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(halo[y]), __float_as_int(q1[0]), 0x101, 0xf, 0xf, false));  // row_shl:1
-#else
-            // two 8-byte reads + one ds_read2_b32 per row: fewest bytes, 2- and 4-way bank conflicts
             c45[y] = *reinterpret_cast<const f32x2*>(P + y * kPW + 4);
             c67[y] = *reinterpret_cast<const f32x2*>(P + y * kPW + 6);
             c38[y][0] = P[y * kPW + 3];
             c38[y][1] = P[y * kPW + 8];
-#endif
         }
 #pragma unroll
         for (int k = 0; k < 9; ++k) {
@@ -232,13 +266,6 @@ __device__ __forceinline__ void winograd43_body(const ConvArgs& p) {
             A[4 * k + 3] = t[3];
         }
         f32x2 t45[6], t67[6], t38[6];
-        if (p.debug_flags & 32) {  // (timing experiment: no transform arithmetic)
-#pragma unroll
-            for (int i = 0; i < 6; ++i) {
-                V[i] = c45[i][0]; V[6 + i] = c45[i][1]; V[12 + i] = c67[i][0]; V[18 + i] = c67[i][1]; V[24 + i] = c38[i][0]; V[30 + i] = c38[i][1];
-            }
-            return;
-        }
         input_transform6<f32x2>(c45[0], c45[1], c45[2], c45[3], c45[4], c45[5], t45);
         input_transform6<f32x2>(c67[0], c67[1], c67[2], c67[3], c67[4], c67[5], t67);
         input_transform6<f32x2>(c38[0], c38[1], c38[2], c38[3], c38[4], c38[5], t38);
@@ -253,16 +280,13 @@ __device__ __forceinline__ void winograd43_body(const ConvArgs& p) {
         }
     };
     // The 36 MFMAs of a k-step, and woven between them (one per seven MFMAs: an LDS-DMA instruction takes the wave about
-    // 120 cycles to issue, which the matrix pipe hides) the five DMA pieces of chunk `stage_chunk` if there is one.
-    auto multiply = [&](int stage_chunk, int stage_slot) {
-        if (p.debug_flags & 2) {
-            if (stage_chunk >= 0) issue_chunk(stage_chunk, stage_slot);
-            return;
-        }
+    // 120 cycles to issue, behind the barrier that sat on every wave's critical path) the five DMA pieces of the chunk
+    // stage_begin() opened, if there is one.
+    auto multiply = [&]() {
 #pragma unroll
         for (int pos = 0; pos < 36; ++pos) {
             acc[pos] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[pos], V[pos], acc[pos], 0, 0, 0);
-            if (pos % 7 == 3 && stage_chunk >= 0) issue_piece(stage_chunk, stage_slot, pos / 7);
+            if (pos % 7 == 3 && cur_valid) stage_piece(pos / 7);
         }
         __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);  // 4 MFMAs, then 4 x (one LDS-DMA issue, 7 MFMAs), one issue, 4 MFMAs
         __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
@@ -274,117 +298,168 @@ __device__ __forceinline__ void winograd43_body(const ConvArgs& p) {
         __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
     };
 
+    // ---- epilogue of this block's tile i: lane (n16, g) holds channels 4 g + r (r = 0 .. 3) of tile n16 for all 36
+    // positions. Output transform, demodulation, noise, bias, leaky ReLU, (RGB) ToRGB product, stores; clears acc. ----
+    auto epilogue = [&](int i) {
+        const Tile43 t = decode(i);
+        const float* const set = const0 + (i & 1) * kConstFloats;
+        const int lane = fresh_lane();
+        const int n16 = lane & 15, g = lane >> 4;
+        const int oy0 = t.y0 + 4 * pg, ox0 = t.x0 + 4 * n16;
+        const int ct = t.m_tile * 2 + cot;  // 16-channel tile of the layer
+        const int co0 = ct * 16 + 4 * g;
+        const f32x4 dm = *reinterpret_cast<const f32x4*>(set + kConstD + cot * 16 + 4 * g);
+        const f32x4 bm = *reinterpret_cast<const f32x4*>(set + kConstB + cot * 16 + 4 * g);
+        f32x4 sn = f32x4{1.f, 1.f, 1.f, 1.f};
+        if (p.s_next != nullptr) sn = *reinterpret_cast<const f32x4*>(set + kConstS + cot * 16 + 4 * g);
+        // (RGB) the layer's ToRGB channel sum over this wave's 16 channels rides on the matrix pipe: k-step r of the product
+        // takes B[k = g][n] = this lane's activation of channel 4 g + r and A[m][k] = style x weight of colour m < 3 (else
+        // 0) for channel 16 ct + 4 k + r, from the table launch_winograd64_rgb_coef prepares
+        f32x4 rgbacc[4][4];
+        if constexpr (RGB) {
 #pragma unroll
-    for (int c = 0; c < kNBUF - 1; ++c)
-        if (c < n) issue_chunk(c, c);
+            for (int oy = 0; oy < 4; ++oy)
+#pragma unroll
+                for (int ox = 0; ox < 4; ++ox) rgbacc[oy][ox] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        float* const out_base = p.out == nullptr ? nullptr
+                                                 : p.out + (size_t)t.b0 * p.out_b_stride + (size_t)co0 * p.out_c_stride +
+                                                       (size_t)(oy0 + p.out_y_off) * p.out_row_stride + ox0 + p.out_x_off;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            __builtin_amdgcn_sched_barrier(0);  // one channel's 36 accumulators at a time (unfenced, hipcc hoists all four and spills)
+            float a_rgb = 0.f;
+            if constexpr (RGB) a_rgb = set[kConstRgb + (cot * 4 + r) * 64 + lane];
+            float tr[4][6];  // A^T M: [output row][position column]
+#pragma unroll
+            for (int j = 0; j < 6; ++j) {
+                float col[4];
+                output_transform6(acc[j * 6 + 0][r], acc[j * 6 + 1][r], acc[j * 6 + 2][r], acc[j * 6 + 3][r], acc[j * 6 + 4][r], acc[j * 6 + 5][r], col);
+#pragma unroll
+                for (int oy = 0; oy < 4; ++oy) tr[oy][j] = col[oy];
+            }
+#pragma unroll
+            for (int oy = 0; oy < 4; ++oy) {
+                float yrow[4];
+                output_transform6(tr[oy][0], tr[oy][1], tr[oy][2], tr[oy][3], tr[oy][4], tr[oy][5], yrow);
+                f32x4 nz = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (p.noise != nullptr) nz = *reinterpret_cast<const f32x4*>(set + kConstNoise + (4 * pg + oy) * kTW + 4 * n16) * p.noise_strength;
+                f32x4 v = f32x4{yrow[0], yrow[1], yrow[2], yrow[3]} * dm[r] + nz + bm[r];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) v[k] = fmaxf(v[k], 0.2f * v[k]) * 1.4142135623730951f;
+                if constexpr (RGB) {
+#pragma unroll
+                    for (int ox = 0; ox < 4; ++ox) rgbacc[oy][ox] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_rgb, v[ox], rgbacc[oy][ox], 0, 0, 0);
+                }
+                // (the stored activation carries the next layer's style when that layer wants it so; the ToRGB product took the plain one)
+                if (out_base != nullptr) *reinterpret_cast<f32x4*>(out_base + (size_t)r * p.out_c_stride + (size_t)oy * p.out_row_stride) = v * sn[r];
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (RGB) {
+            // partial image of this 16-channel tile: [Cout / 16][B][3][OH][OW]; lanes 0 .. 15 hold (R, G, B, 0) of their tile's pixels
+            if (g == 0) {
+                float* const y_base = p.rgb_y + (((size_t)ct * p.B + t.b0) * 3) * p.OH * p.OW + (size_t)oy0 * p.OW + ox0;
+#pragma unroll
+                for (int c = 0; c < 3; ++c)
+#pragma unroll
+                    for (int oy = 0; oy < 4; ++oy)
+                        *reinterpret_cast<f32x4*>(y_base + ((size_t)c * p.OH + oy) * p.OW) =
+                            f32x4{rgbacc[oy][0][c], rgbacc[oy][1][c], rgbacc[oy][2][c], rgbacc[oy][3][c]};
+            }
+        }
+#pragma unroll
+        for (int i2 = 0; i2 < 36; ++i2) acc[i2] = f32x4{0.f, 0.f, 0.f, 0.f};
+        lane_setup();
+    };
 
+    // ---- ring prologue: the first two chunks of the stream, all pieces at once ----
+    for (int c = 0; c < kNBUF - 1; ++c) {
+        stage_begin();
+        if (cur_valid) {
+#pragma unroll
+            for (int r = 0; r < kPiecesPerWave; ++r) stage_piece(r);
+        }
+    }
+
+    // ---- the stream: k-step G of the block multiplies chunk G (chunk G % n of tile G / n), ring slot G % 3 ----
     // The two waves of a SIMD run half a k-step apart: in the interval between two barriers the role-0 wave loads and
-    // transforms chunk q and then multiplies it, the role-1 wave first multiplies chunk q - 1 out of its registers and then
-    // loads and transforms chunk q. While one of them waits for LDS or issues vector instructions the other keeps the
-    // matrix pipe busy. (ONE loop with role tests: split into a straight-line loop per role, hipcc's code ran 12 % slower.)
-    int slot = 0;
-    for (int q = 0; q < n; ++q) {
-        // chunk q must have landed; the kNBUF - 2 younger ones may stay in flight (fewer near the end of the tile)
-        if (q + kNBUF - 2 < n && !(p.debug_flags & 1))
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"((kNBUF - 2) * kPiecesPerWave) : "memory");
-        else if (kNBUF > 3 && q + 1 < n && !(p.debug_flags & 1))
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kPiecesPerWave) : "memory");
-        else
+    // transforms chunk G and then multiplies it, the role-1 wave first multiplies chunk G - 1 out of its registers and then
+    // loads and transforms chunk G. While one of them waits for LDS or issues vector instructions the other keeps the
+    // matrix pipe busy. A tile's epilogue runs right behind its last multiply -- for a role-1 wave that is in the first
+    // interval of the NEXT tile -- while the ring keeps fetching: the stream never drains between tiles.
+    // Shape of the loops: tiles outside, their chunks inside, the epilogue UNCONDITIONALLY behind the inner loop, one nest per
+    // role: accumulators that flow through a conditional (an epilogue under `if` inside one loop) cost 244 spilled
+    // registers here; do-while because the guard path of a `for` (all accumulators zero) meets the real path in front of the
+    // epilogue and costs accumulator copies.
+    int slot = 0, G = 0;
+    // opens interval G: chunk G must have landed; chunk G + 1 (five pieces) may stay in flight, and so may the stores of an
+    // epilogue this wave ran in the previous interval (vmcnt counts in issue order: they are younger than chunk G's pieces)
+    auto open_interval = [&](bool stores_behind) {
+        if (G + 1 >= total)
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else if (stores_behind)
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kPiecesPerWave + kStoresPerEpilogue + (RGB ? kRgbStores : 0)) : "memory");
+        else
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kPiecesPerWave) : "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
+        stage_begin();  // chunk G + 2 -> the slot k-step G - 1 read (every wave is past the barrier: nobody reads it any more)
         __builtin_amdgcn_sched_barrier(0);
-        const bool stamp = (p.debug_flags & 128) && blockIdx.x == 256 && q >= 8 && q < 16 && lane == 0;
-        unsigned long long* const stamps = p.debug_stamps + ((size_t)wave * 8 + (q & 7)) * 4;
-        if (stamp) stamps[0] = __builtin_readcyclecounter();
-        if (role == 0) load_transform(slot);
+    };
+    auto close_interval = [&]() {
         __builtin_amdgcn_sched_barrier(0);
-        if (stamp) stamps[1] = __builtin_readcyclecounter();
-        // chunk q + kNBUF - 1 goes into the slot k-step q - 1 read (every wave is past the barrier: nobody reads it any more);
-        // its DMA pieces ride in the shadow of this interval's MFMAs (right behind the barrier they sat on the critical path
-        // of every wave: five issues cost about 600 cycles)
-        const int stage_chunk = (q + kNBUF - 1 < n && !((p.debug_flags & 1) && q > 0)) ? q + kNBUF - 1 : -1;
-        const int stage_slot = slot == 0 ? kNBUF - 1 : slot - 1;
-        if (role == 0 || q > 0)
-            multiply(stage_chunk, stage_slot);
-        else if (stage_chunk >= 0)
-            issue_chunk(stage_chunk, stage_slot);
-        __builtin_amdgcn_sched_barrier(0);
-        if (stamp) stamps[2] = __builtin_readcyclecounter();
-        if (role != 0) load_transform(slot);
-        __builtin_amdgcn_sched_barrier(0);
-        if (stamp) stamps[3] = __builtin_readcyclecounter() | ((unsigned long long)role << 63);
         slot = slot == kNBUF - 1 ? 0 : slot + 1;
-    }
-    if (role != 0) multiply(-1, 0);
-
-    // ---- epilogue: lane (n16, g) holds channels 4 g + r (r = 0 .. 3) of tile n16 for all 36 positions ----
-    const int oy0 = y0 + 4 * pg, ox0 = x0 + 4 * n16;
-    const int ct = m_tile * 2 + cot;  // 16-channel tile of the layer
-    const int co0 = ct * 16 + 4 * g;
-    const f32x4 dm = *reinterpret_cast<const f32x4*>(p.d + (size_t)b0 * p.d_stride + co0);
-    const f32x4 bm = *reinterpret_cast<const f32x4*>(p.bias + co0);
-    f32x4 sn = f32x4{1.f, 1.f, 1.f, 1.f};
-    if (p.s_next != nullptr) sn = *reinterpret_cast<const f32x4*>(p.s_next + (size_t)b0 * p.s_stride + co0);
-    f32x4 nz[4];
+        ++G;
+    };
+    if (role == 0) {
+        int tile = 0;
+        do {
+            int q = 0;
+            do {
+                open_interval(q == 0 && tile > 0);
+                load_transform(slot);
+                __builtin_amdgcn_sched_barrier(0);
+                multiply();
+                close_interval();
+            } while (++q < n);
+            epilogue(tile);
+        } while (++tile < my_tiles);
+    } else {
+        open_interval(false);  // interval 0: nothing to multiply yet; this interval's DMA pieces go out in one burst
+        if (cur_valid) {
 #pragma unroll
-    for (int oy = 0; oy < 4; ++oy) {
-        nz[oy] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (p.noise != nullptr) nz[oy] = *reinterpret_cast<const f32x4*>(p.noise + (size_t)(oy0 + oy) * p.OW + ox0) * p.noise_strength;
-    }
-    // (RGB) the layer's ToRGB channel sum over this wave's 16 channels rides on the matrix pipe: k-step r of the product
-    // takes B[k = g][n] = this lane's activation of channel 4 g + r and A[m][k] = style x weight of colour m < 3 (else 0)
-    // for channel 16 ct + 4 k + r, from the table launch_winograd64_rgb_coef prepares ([b][Cout / 4 steps][64 lanes]).
-    float a_rgb[4] = {0.f, 0.f, 0.f, 0.f};
-    f32x4 rgbacc[4][4];
-    if constexpr (RGB) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) a_rgb[r] = p.rgb_coef[((size_t)b0 * (p.Cout / 4) + 4 * ct + r) * 64 + lane];
-#pragma unroll
-        for (int oy = 0; oy < 4; ++oy)
-#pragma unroll
-            for (int ox = 0; ox < 4; ++ox) rgbacc[oy][ox] = f32x4{0.f, 0.f, 0.f, 0.f};
-    }
-    float* const out_base = p.out == nullptr ? nullptr
-                                             : p.out + (size_t)b0 * p.out_b_stride + (size_t)co0 * p.out_c_stride +
-                                                   (size_t)(oy0 + p.out_y_off) * p.out_row_stride + ox0 + p.out_x_off;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        float t[4][6];  // A^T M: [output row][position column]
-#pragma unroll
-        for (int j = 0; j < 6; ++j) {
-            float col[4];
-            output_transform6(acc[j * 6 + 0][r], acc[j * 6 + 1][r], acc[j * 6 + 2][r], acc[j * 6 + 3][r], acc[j * 6 + 4][r], acc[j * 6 + 5][r], col);
-#pragma unroll
-            for (int oy = 0; oy < 4; ++oy) t[oy][j] = col[oy];
+            for (int r = 0; r < kPiecesPerWave; ++r) stage_piece(r);
         }
-#pragma unroll
-        for (int oy = 0; oy < 4; ++oy) {
-            float yrow[4];
-            output_transform6(t[oy][0], t[oy][1], t[oy][2], t[oy][3], t[oy][4], t[oy][5], yrow);
-            f32x4 v = f32x4{yrow[0], yrow[1], yrow[2], yrow[3]} * dm[r] + nz[oy] + bm[r];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) v[k] = fmaxf(v[k], 0.2f * v[k]) * 1.4142135623730951f;
-            if constexpr (RGB) {
-#pragma unroll
-                for (int ox = 0; ox < 4; ++ox) rgbacc[oy][ox] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_rgb[r], v[ox], rgbacc[oy][ox], 0, 0, 0);
+        load_transform(slot);
+        close_interval();
+        int tile = 0;
+        do {
+            int q = 1;
+            do {
+                open_interval(q == 1 && tile > 0);
+                multiply();
+                __builtin_amdgcn_sched_barrier(0);
+                load_transform(slot);
+                close_interval();
+            } while (++q < n);
+            // the tile's last chunk: multiplied in the first interval of the next tile (if there is one), then the epilogue,
+            // then that interval's own load + transform
+            const bool more = tile + 1 < my_tiles;
+            if (more)
+                open_interval(false);
+            else
+                cur_valid = false;
+            multiply();
+            __builtin_amdgcn_sched_barrier(0);
+            epilogue(tile);
+            if (more) {
+                load_transform(slot);
+                close_interval();
             }
-            // (the stored activation carries the next layer's style when that layer wants it so; the ToRGB product took the plain one)
-            if (out_base != nullptr) *reinterpret_cast<f32x4*>(out_base + (size_t)r * p.out_c_stride + (size_t)oy * p.out_row_stride) = v * sn[r];
-        }
+        } while (++tile < my_tiles);
     }
-    if constexpr (RGB) {
-        // partial image of this 16-channel tile: [Cout / 16][B][3][OH][OW]; lanes 0 .. 15 hold (R, G, B, 0) of their tile's pixels
-        if (g == 0) {
-            float* const y_base = p.rgb_y + (((size_t)ct * p.B + b0) * 3) * p.OH * p.OW + (size_t)oy0 * p.OW + ox0;
-#pragma unroll
-            for (int c = 0; c < 3; ++c)
-#pragma unroll
-                for (int oy = 0; oy < 4; ++oy)
-                    *reinterpret_cast<f32x4*>(y_base + ((size_t)c * p.OH + oy) * p.OW) =
-                        f32x4{rgbacc[oy][0][c], rgbacc[oy][1][c], rgbacc[oy][2][c], rgbacc[oy][3][c]};
-        }
-    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // nothing of the ring may still be landing when the block's LDS is given back
 }
 
 // (plain functions around the templated body: as a kernel TEMPLATE the host pass of hipcc drops the instantiation, see winograd64_conv.hip)
@@ -392,7 +467,7 @@ __global__ __launch_bounds__(512, 1) void winograd43_kernel(const ConvArgs p) { 
 __global__ __launch_bounds__(512, 1) void winograd43_rgb_kernel(const ConvArgs p) { winograd43_body<true>(p); }
 
 bool winograd43_supported(int cin, int cout, int H, int W) {
-    return cin % kKC == 0 && cin / kKC >= 2 && cout % kBM == 0 && H % kTH == 0 && W % kTW == 0;
+    return cin % kKC == 0 && cin / kKC >= 4 && cout % kBM == 0 && H % kTH == 0 && W % kTW == 0;  // (>= 4 chunks per tile: two constant sets)
 }
 
 size_t winograd43_weight_floats(int cin, int cout) { return (size_t)(cout / kBM) * (cin / kKC) * kWFloats; }
@@ -429,47 +504,27 @@ hipError_t launch_winograd43_conv(const ConvArgs& args, hipStream_t stream) {
     if (rgb ? (!winograd43_rgb_supported(args.Cout) || args.rgb_coef == nullptr || args.rgb_y == nullptr) : (args.epilogue != kEpilogueFull || args.out == nullptr))
         return hipErrorInvalidValue;
     void (*const kernel)(const ConvArgs) = rgb ? winograd43_rgb_kernel : winograd43_kernel;
-    static PerDeviceInt configured[2];
-    int unused = 0;
-    hipError_t e = configured[rgb ? 1 : 0].get(
-        [&](int, int* value) {
-            *value = 1;
-            return hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kNBUF * kSlot * sizeof(float)));
+    constexpr size_t kLdsBytes = sizeof(float) * ((size_t)kNBUF * kSlot + 2 * kConstFloats);
+    static PerDeviceInt resident[2];  // per device: the dynamic-LDS opt-in and the launch size = one block per CU, a multiple of 8 (XCDs)
+    int resident_blocks = 0;
+    hipError_t e = resident[rgb ? 1 : 0].get(
+        [&](int device, int* value) {
+            hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes);
+            if (err != hipSuccess) return err;
+            int cus = 0;
+            if ((err = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device)) != hipSuccess) return err;
+            *value = std::max(8, cus / 8 * 8);
+            return hipSuccess;
         },
-        &unused);
+        &resident_blocks);
     if (e != hipSuccess) return e;
     ConvArgs a = args;
-    // timing ablations (results are wrong): GANCE_DEBUG_W43 = 1 no DMA after the second k-step, 2 no MFMAs
-    static const int env_debug = [] { const char* v = std::getenv("GANCE_DEBUG_W43"); return v ? std::atoi(v) : 0; }();
-    a.debug_flags = env_debug;
     a.tiles_x = a.W / kTW;
     a.tiles_y = a.H / kTH;
     a.m_tiles = a.Cout / kBM;
     a.total_chunks = a.Cin / kKC;
     a.total_tiles = a.m_tiles * a.tiles_x * a.tiles_y * a.B;
-    static unsigned long long* stamps = nullptr;
-    if (env_debug & 128) {  // per-wave cycle stamps of k-steps 8 .. 15 of block 256, printed after the launch
-        if (stamps == nullptr && hipMalloc((void**)&stamps, 8 * 8 * 4 * sizeof(unsigned long long)) != hipSuccess) return hipErrorOutOfMemory;
-        (void)hipMemsetAsync(stamps, 0, 8 * 8 * 4 * sizeof(unsigned long long), stream);
-        a.debug_stamps = stamps;
-    }
-    hipLaunchKernelGGL(kernel, dim3(a.total_tiles), dim3(512), kNBUF * kSlot * sizeof(float), stream, a);
-    if ((env_debug & 128) && a.total_tiles > 256) {
-        (void)hipStreamSynchronize(stream);
-        unsigned long long h[8 * 8 * 4];
-        (void)hipMemcpy(h, stamps, sizeof(h), hipMemcpyDeviceToHost);
-        unsigned long long t0 = ~0ull;
-        for (int w = 0; w < 8; ++w) t0 = std::min(t0, h[(w * 8) * 4] & ~(1ull << 63));
-        std::fprintf(stderr, "W43 STAMPS (cycles from the first stamp; per wave: role, then per k-step start / after first L+T / after multiply / end)\n");
-        for (int w = 0; w < 8; ++w) {
-            std::fprintf(stderr, "  wave %d role %d:", w, (int)(h[(w * 8) * 4 + 3] >> 63));
-            for (int q = 0; q < 8; ++q) {
-                const unsigned long long* e = h + (w * 8 + q) * 4;
-                std::fprintf(stderr, " | %llu %llu %llu %llu", e[0] - t0, e[1] - t0, e[2] - t0, (e[3] & ~(1ull << 63)) - t0);
-            }
-            std::fprintf(stderr, "\n");
-        }
-    }
+    hipLaunchKernelGGL(kernel, dim3(std::min(a.total_tiles, resident_blocks)), dim3(512), kLdsBytes, stream, a);
     return hipGetLastError();
 }
 
