@@ -38,6 +38,10 @@
 
 #include "kernels.h"
 
+#ifndef GANCE_W43_WINDOW
+#define GANCE_W43_WINDOW 0
+#endif
+
 namespace gance {
 
 namespace {
@@ -250,10 +254,20 @@ __device__ __forceinline__ void winograd43_body(const ConvArgs& p) {
         f32x2 c45[6], c67[6], c38[6];
 #pragma unroll
         for (int y = 0; y < 6; ++y) {
+#if GANCE_W43_WINDOW == 1
+            // (variant: three aligned 16-byte reads per window row, columns 4 n .. 4 n + 11: bank-conflict free, twice the bytes)
+            const f32x4 q0 = *reinterpret_cast<const f32x4*>(P + y * kPW);
+            const f32x4 q1 = *reinterpret_cast<const f32x4*>(P + y * kPW + 4);
+            const f32x4 q2 = *reinterpret_cast<const f32x4*>(P + y * kPW + 8);
+            c45[y] = f32x2{q1[0], q1[1]};
+            c67[y] = f32x2{q1[2], q1[3]};
+            c38[y] = f32x2{q0[3], q2[0]};
+#else
             c45[y] = *reinterpret_cast<const f32x2*>(P + y * kPW + 4);
             c67[y] = *reinterpret_cast<const f32x2*>(P + y * kPW + 6);
             c38[y][0] = P[y * kPW + 3];
             c38[y][1] = P[y * kPW + 8];
+#endif
         }
 #pragma unroll
         for (int k = 0; k < 9; ++k) {
