@@ -57,7 +57,7 @@ def main() -> int:
             "hbm_bytes_per_launch": int((2.0 * fetch_kb + write_kb) * 1024),
             "algorithmic_bytes_per_launch": int(gbs * 1e9 * micros * 1e-6),
             "mfma_busy_fraction": round(busy, 3),
-            "effective_clock_ghz": round(float(write[row_name]["GRBM_GUI_ACTIVE"]) / 8.0 / (float(write[row_name]["dur_us"]) * 1e3), 3)  # (the counter sums the 8 XCDs),
+            "effective_clock_ghz": round(float(write[row_name]["GRBM_GUI_ACTIVE"]) / 8.0 / (float(write[row_name]["dur_us"]) * 1e3), 3),  # (the counter sums the 8 XCDs)
             "duration_us": float(write[row_name]["dur_us"]),
         }
     record = {

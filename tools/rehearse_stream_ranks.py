@@ -105,12 +105,21 @@ def main() -> int:
     status = 0
     if rank == 0:
         want = np.load(args.check / "single_rank.npy")
-        same = frames is not None and frames.shape == want.shape and np.array_equal(frames, want)
+        # (the ranks' engine calls group the frames differently -- other batch sizes pick other split-K factors / kernel
+        # forms on the small layers --, so frames may differ by fp32 rounding: at most 1 LSB on a few pixels; with an
+        # overlay the written regions are copies of the target pictures and must sit on the same frames)
+        same = frames is not None and frames.shape == want.shape
+        differing, worst = 0.0, 0
+        if same:
+            diff = np.abs(frames.astype(np.int16) - want.astype(np.int16))
+            differing, worst = float((diff > 0).mean()), int(diff.max())
+            same = worst <= (2 if OUT_SIDE != SIDE else 1) and differing < 1e-3  # (the bicubic resize can double a 1-LSB difference)
         ordered = firsts == sorted(firsts) and firsts[0] == 0
         print(
             f"{world_size} ranks on one GPU over gloo, {SIDE}^2 -> {OUT_SIDE}^2, {NETWORKS} networks, {PER_CALL} frames per call, overlay {bool(OVERLAY)}: "
             f"{0 if frames is None else frames.shape[0]} frames in {len(firsts)} ordered chunks "
-            f"({elapsed:.2f} s incl. network loading), identical to the single-rank run: {same}, chunk order ok: {ordered}"
+            f"({elapsed:.2f} s incl. network loading), same frames as the single-rank run: {same} (max |diff| {worst} LSB on "
+            f"{100.0 * differing:.4f} % of the values), chunk order ok: {ordered}"
         )
         status = 0 if same and ordered else 1
     else:
