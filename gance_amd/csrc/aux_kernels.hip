@@ -661,6 +661,35 @@ __global__ __launch_bounds__(256) void resize_bicubic_u8_kernel(const uint8_t* _
     }
 }
 
+// Fresh standard-normal noise (the upstream generator's randomize_noise=True draws tf.random_normal per call): counter-based,
+// value i of a buffer = Box-Muller of two uniforms hashed from (seed, stream id, i / 2) by splitmix64. Not TF's stream
+// (nothing could reproduce that), only its distribution.
+__device__ __forceinline__ unsigned long long splitmix64(unsigned long long x) {
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+__global__ void normal_noise_kernel(float* __restrict__ out, size_t count, unsigned long long seed, unsigned long long stream_id) {
+    const size_t pair = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (2 * pair >= count) return;
+    const unsigned long long bits = splitmix64(splitmix64(seed ^ (stream_id * 0xD1B54A32D192ED03ull)) + pair);
+    const float u1 = ((float)(unsigned)(bits >> 40) + 1.0f) * (1.0f / 16777216.0f);  // (0, 1]
+    const float u2 = (float)(unsigned)((bits >> 8) & 0xFFFFFFu) * (1.0f / 16777216.0f);  // [0, 1)
+    const float radius = sqrtf(-2.0f * logf(u1));
+    float sn, cs;
+    sincosf(6.283185307179586f * u2, &sn, &cs);
+    out[2 * pair] = radius * cs;
+    if (2 * pair + 1 < count) out[2 * pair + 1] = radius * sn;
+}
+
+hipError_t launch_normal_noise(float* out, size_t count, unsigned long long seed, unsigned long long stream_id, hipStream_t stream) {
+    if (count == 0) return hipSuccess;
+    const size_t pairs = (count + 1) / 2;
+    hipLaunchKernelGGL(normal_noise_kernel, dim3((unsigned)((pairs + 255) / 256)), dim3(256), 0, stream, out, count, seed, stream_id);
+    return hipGetLastError();
+}
+
 hipError_t launch_resize_bicubic_u8(const uint8_t* in, int batch, int src, uint8_t* out, int dst,
                                     hipStream_t stream) {
     const int tiles_x = (dst + kResizeTW - 1) / kResizeTW, tiles_y = (dst + kResizeTH - 1) / kResizeTH;

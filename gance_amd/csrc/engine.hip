@@ -265,6 +265,8 @@ struct gance_engine {
     std::vector<size_t> conv_w, conv_bias, conv_noise;
     std::vector<size_t> wino_w;  // Winograd-domain weights of the stride-1 layers that support them (else SIZE_MAX)
     std::vector<size_t> wino64_w;  // the same for the 64-channel Winograd kernel (layers with >= 64 output channels)
+    float* noise_backup = nullptr;  // the stored noise buffers, saved by the first gance_engine_randomize_noise (layer by layer, packed)
+    bool noise_randomized = false;
     std::vector<size_t> wino43_w;  // F(4x4, 3x3) weights (winograd43_conv.hip), SIZE_MAX where the layer does not take that form
     std::vector<size_t> upfir_w;  // fused transposed-conv + FIR kernel's weight image of the up layers that support it (else SIZE_MAX)
     int num_cus = 256;
@@ -303,6 +305,7 @@ void free_engine(gance_engine* e) {
         hipEventDestroy(s.stop);
     }
     hipFree(e->pool);
+    hipFree(e->noise_backup);
     hipFree(e->blk_row);
     hipFree(e->demod_layers);
     if (e->ws && e->ws->used) hipEventSynchronize(e->ws->last_use);  // nothing of this engine still runs on the shared scratch
@@ -1297,6 +1300,60 @@ int gance_engine_step_info(gance_engine* engine, int32_t index, char* name64, fl
     if (ms) *ms = elapsed;
     if (flops) *flops = r.flops;
     if (bytes) *bytes = r.bytes;
+    return GANCE_OK;
+}
+
+int gance_engine_randomize_noise(gance_engine* e, uint64_t seed, void* stream_) {
+    if (e == nullptr) return fail(GANCE_ERR_INVALID_ARGUMENT, "engine is NULL");
+    gance::DeviceGuard guard(e->cfg.device);
+    GANCE_HIP_CHECK(guard.status());
+    hipStream_t stream = (hipStream_t)stream_;
+    const int nconv = (int)e->convs.size();
+    size_t total = 0;
+    for (int i = 0; i < nconv; ++i) total += (size_t)1 << (2 * e->convs[i].res_log2);
+    if (e->noise_backup == nullptr) {  // keep the stored buffers: gance_engine_restore_noise puts them back
+        GANCE_HIP_CHECK(hipMalloc((void**)&e->noise_backup, total * sizeof(float)));
+        size_t at = 0;
+        for (int i = 0; i < nconv; ++i) {
+            const size_t n = (size_t)1 << (2 * e->convs[i].res_log2);
+            GANCE_HIP_CHECK(hipMemcpyAsync(e->noise_backup + at, e->pool + e->conv_noise[i], n * sizeof(float), hipMemcpyDeviceToDevice, stream));
+            at += n;
+        }
+    }
+    for (int i = 0; i < nconv; ++i) {
+        if (e->conv_ns[i] == 0.0f) continue;  // (a layer whose strength is zero never reads its noise)
+        GANCE_HIP_CHECK(gance::launch_normal_noise(e->pool + e->conv_noise[i], (size_t)1 << (2 * e->convs[i].res_log2), seed, (unsigned long long)i, stream));
+    }
+    e->noise_randomized = true;
+    if (stream == nullptr) GANCE_HIP_CHECK(hipStreamSynchronize(nullptr));  // (the host-buffer entries run on a private stream)
+    return GANCE_OK;
+}
+
+int gance_engine_restore_noise(gance_engine* e, void* stream_) {
+    if (e == nullptr) return fail(GANCE_ERR_INVALID_ARGUMENT, "engine is NULL");
+    if (!e->noise_randomized || e->noise_backup == nullptr) return GANCE_OK;
+    gance::DeviceGuard guard(e->cfg.device);
+    GANCE_HIP_CHECK(guard.status());
+    size_t at = 0;
+    for (size_t i = 0; i < e->convs.size(); ++i) {
+        const size_t n = (size_t)1 << (2 * e->convs[i].res_log2);
+        GANCE_HIP_CHECK(hipMemcpyAsync(e->pool + e->conv_noise[i], e->noise_backup + at, n * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream_));
+        at += n;
+    }
+    e->noise_randomized = false;
+    if (stream_ == nullptr) GANCE_HIP_CHECK(hipStreamSynchronize(nullptr));
+    return GANCE_OK;
+}
+
+int gance_engine_debug_read_noise(gance_engine* e, int32_t conv_layer, float* h_out, uint64_t count) {
+    if (e == nullptr || h_out == nullptr || conv_layer < 0 || conv_layer >= (int)e->convs.size())
+        return fail(GANCE_ERR_INVALID_ARGUMENT, "bad argument to gance_engine_debug_read_noise");
+    const uint64_t n = (uint64_t)1 << (2 * e->convs[conv_layer].res_log2);
+    if (count != n) return fail(GANCE_ERR_INVALID_ARGUMENT, "the layer's noise buffer holds " + std::to_string(n) + " floats");
+    gance::DeviceGuard guard(e->cfg.device);
+    GANCE_HIP_CHECK(guard.status());
+    GANCE_HIP_CHECK(hipDeviceSynchronize());
+    GANCE_HIP_CHECK(hipMemcpy(h_out, e->pool + e->conv_noise[conv_layer], n * sizeof(float), hipMemcpyDeviceToHost));
     return GANCE_OK;
 }
 

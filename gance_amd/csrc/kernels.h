@@ -260,6 +260,9 @@ struct ToRgbArgs {
 };
 hipError_t launch_torgb(const ToRgbArgs& args, hipStream_t stream);
 
+// out[0 .. count) = standard-normal draws, a function of (seed, stream_id, index) only (randomize_noise of the vector path)
+hipError_t launch_normal_noise(float* out, size_t count, unsigned long long seed, unsigned long long stream_id, hipStream_t stream);
+
 // Bicubic (a = -0.75) resize of uint8 NHWC RGB frames [batch][src][src][3] -> [batch][dst][dst][3].
 hipError_t launch_resize_bicubic_u8(const uint8_t* in, int batch, int src, uint8_t* out, int dst,
                                     hipStream_t stream);

@@ -80,17 +80,26 @@ class LoadedNetwork:
         """`network.input_shape[1]` (network_functions.py:191)."""
         return self.engine.vector_length
 
-    def create_images_vector(self, data: np.ndarray) -> np.ndarray:
-        """z (B, L) -> uint8 (B, H, W, 3): mapping, truncation psi = 1.2, synthesis (network_functions.py:144-158)."""
+    def create_images_vector(self, data: np.ndarray, randomize_noise: bool = True, noise_seed: Optional[int] = None) -> np.ndarray:
+        """
+        z (B, L) -> uint8 (B, H, W, 3): mapping, truncation psi = 1.2, synthesis (network_functions.py:144-158).
+        The reference does not pass `randomize_noise` on this path, so the upstream default True applies: fresh noise per
+        call (one draw per engine call here, shared by its frames; `noise_seed` makes it repeatable). A network whose noise
+        strengths are all zero -- every random-init network -- gives the same image either way.
+        """
         data = np.asarray(data)
-        out = [
-            self.engine.synthesize_z(data[start : start + self.max_batch], truncation_psi=TRUNCATION_PSI)
-            for start in range(0, len(data), self.max_batch)
-        ]
+        out = []
+        for index, start in enumerate(range(0, len(data), self.max_batch)):
+            if randomize_noise:
+                self.engine.randomize_noise(None if noise_seed is None else noise_seed + index)
+            else:
+                self.engine.restore_noise()
+            out.append(self.engine.synthesize_z(data[start : start + self.max_batch], truncation_psi=TRUNCATION_PSI))
         return np.concatenate(out) if len(out) > 1 else out[0]
 
     def create_images_matrix(self, data: np.ndarray) -> np.ndarray:
-        """dlatents (B, W, L) -> uint8 (B, H, W, 3): synthesis only, stored noise (network_functions.py:160-169)."""
+        """dlatents (B, W, L) -> uint8 (B, H, W, 3): synthesis only, stored noise (network_functions.py:160-169: randomize_noise=False)."""
+        self.engine.restore_noise()
         data = np.asarray(data)
         out = [self.engine.synthesize_w(data[start : start + self.max_batch]) for start in range(0, len(data), self.max_batch)]
         return np.concatenate(out) if len(out) > 1 else out[0]

@@ -79,9 +79,12 @@ def synthesize_device_frames(  # pylint: disable=too-many-locals
         for network_index in np.unique(chunk):
             engine = networks._network_at(int(network_index)).engine  # pylint: disable=protected-access
             members = torch.from_numpy(np.nonzero(chunk == network_index)[0] + start).to(dlatents.device)
+            stream = torch.cuda.current_stream(dlatents.device).cuda_stream
             if dlatents.dim() == 2:
+                engine.randomize_noise(stream=stream)  # the reference's vector path draws fresh noise per call (upstream default)
                 images = torch.ops.gance.synthesize_z(dlatents.index_select(0, members), engine.op_handle, TRUNCATION_PSI)
             else:
+                engine.restore_noise(stream=stream)  # its matrix path passes randomize_noise=False: the stored buffers
                 images = torch.ops.gance.synthesize_w(dlatents.index_select(0, members)[:, : engine.num_layers, :], engine.op_handle)
             if engine.resolution != out_side:
                 images = torch.ops.gance.resize_bicubic(images, out_side)
@@ -122,10 +125,13 @@ def synthesize_device_frames_network_major(  # pylint: disable=too-many-locals
             native = out[first : first + count] if in_place and out_side == side else torch.empty(
                 (count, side, side, 3), dtype=torch.uint8, device=device
             )
+            stream = torch.cuda.current_stream(device).cuda_stream
             if dlatents.dim() == 2:
+                engine.randomize_noise(stream=stream)  # the reference's vector path draws fresh noise per call (upstream default)
                 selected = dlatents[first : first + count] if in_place else dlatents.index_select(0, members)
                 torch.ops.gance.synthesize_z_out(selected, engine.op_handle, TRUNCATION_PSI, native)
             else:
+                engine.restore_noise(stream=stream)  # its matrix path passes randomize_noise=False: the stored buffers
                 selected = (dlatents[first : first + count] if in_place else dlatents.index_select(0, members))[:, : engine.num_layers, :]
                 torch.ops.gance.synthesize_w_out(selected, engine.op_handle, native)
             if out_side != side:

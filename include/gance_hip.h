@@ -138,6 +138,22 @@ int32_t gance_engine_step_count(const gance_engine* engine);
 int gance_engine_step_info(gance_engine* engine, int32_t index, char* name64, float* ms,
                            double* flops, double* bytes);
 /*
+ * randomize_noise of the generator. The reference's vector path (create_image_vector, network_functions.py:152-157)
+ * leaves `randomize_noise` at the upstream default True: every call draws fresh N(0, 1) noise per layer instead of the
+ * stored noise buffers; its matrix path passes randomize_noise=False (:121-125). gance_engine_randomize_noise overwrites
+ * the engine's noise buffers in HBM with standard-normal draws that are a function of `seed` only (layers whose
+ * noise_strength is zero -- every layer of a random-init network -- are skipped: they never read theirs), asynchronously
+ * on `stream` (with a NULL stream both functions return after completion: the host-buffer entries run on a stream of
+ * their own); the draws stay until the next call of either function. gance_engine_restore_noise puts the stored buffers
+ * back. One noise plane per layer serves the whole batch of a call (upstream draws per sample; at one frame per call,
+ * the reference's call pattern, that is the same thing).
+ */
+int gance_engine_randomize_noise(gance_engine* engine, uint64_t seed, void* stream);
+int gance_engine_restore_noise(gance_engine* engine, void* stream);
+/* Debug: the noise buffer conv layer `conv_layer` currently reads ([res][res] floats, count = res * res), to host memory. */
+int gance_engine_debug_read_noise(gance_engine* engine, int32_t conv_layer, float* h_out, uint64_t count);
+
+/*
  * Debug: run only the first `num_steps` conv layers of the next synthesize_w calls (<=0 = all)
  * and copy the current activation tensor [batch][C][res][res] to the host.
  */

@@ -281,6 +281,47 @@ def test_host_entry_graph_replay_equals_the_eager_device_entry(library) -> None:
         engine.close()
 
 
+def test_randomize_noise_draws_fresh_standard_normal_noise_and_restores(library) -> None:
+    """
+    The reference's vector path leaves randomize_noise at the upstream default True (network_functions.py:152-157):
+    gance_engine_randomize_noise replaces the stored noise buffers by N(0, 1) draws (a function of the seed), frames
+    change with the seed and repeat with it, gance_engine_restore_noise brings the stored-noise frame back exactly; a
+    random-init network (all strengths zero) is unaffected.
+    """
+    resolution = 64
+    variables = sg2_spec.make_random_variables(resolution, seed=4, perturb=True)
+    z = np.random.RandomState(3).randn(2, 512).astype(np.float32)
+    engine = hip_lib.Engine(variables, resolution, max_batch=2)
+    try:
+        stored = engine.synthesize_z(z, truncation_psi=1.2)
+        stored_noise = engine.debug_noise(5)
+        engine.randomize_noise(seed=11)
+        noise = np.concatenate([engine.debug_noise(layer).reshape(-1) for layer in (6, 7, 8, 9)])  # 32^2 + 32^2 + 64^2 + 64^2 draws
+        assert abs(float(noise.mean())) < 0.05 and abs(float(noise.std()) - 1.0) < 0.03
+        assert abs(float((noise ** 4).mean()) - 3.0) < 0.3 and float(np.abs(noise).max()) < 6.0  # kurtosis of a normal, no wild tails
+        assert abs(float(np.corrcoef(noise[:-1], noise[1:])[0, 1])) < 0.03  # neighbours (the two halves of a Box-Muller pair) uncorrelated
+        first = engine.synthesize_z(z, truncation_psi=1.2)
+        engine.randomize_noise(seed=11)
+        assert np.array_equal(engine.synthesize_z(z, truncation_psi=1.2), first)
+        engine.randomize_noise(seed=12)
+        other = engine.synthesize_z(z, truncation_psi=1.2)
+        assert (other != first).mean() > 0.5 and (first != stored).mean() > 0.5
+        engine.randomize_noise()  # a fresh seed from the OS
+        assert (engine.synthesize_z(z, truncation_psi=1.2) != other).mean() > 0.5
+        engine.restore_noise()
+        assert np.array_equal(engine.debug_noise(5), stored_noise)
+        assert np.array_equal(engine.synthesize_z(z, truncation_psi=1.2), stored)
+    finally:
+        engine.close()
+    plain = hip_lib.Engine(sg2_spec.make_random_variables(resolution, seed=4), resolution, max_batch=2)
+    try:
+        before = plain.synthesize_z(z, truncation_psi=1.2)
+        plain.randomize_noise(seed=1)
+        assert np.array_equal(plain.synthesize_z(z, truncation_psi=1.2), before)
+    finally:
+        plain.close()
+
+
 def test_calls_are_validated(library) -> None:
     variables = sg2_spec.make_random_variables(8, seed=0)
     engine = hip_lib.Engine(variables, 8, max_batch=2)
