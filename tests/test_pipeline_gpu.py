@@ -198,8 +198,11 @@ def test_legacy_tf_pickle_loads_into_a_network_and_renders(tmp_path: Path) -> No
         rng = np.random.RandomState(12)
         z = rng.randn(2, 512).astype(np.float32)
         dlatents = rng.randn(1, network.engine.num_layers, 512).astype(np.float32)
-        from_z = network.create_images_vector(z)
-        from_w = network.create_image_matrix(dlatents[0].astype(np.float64))  # callers pass float64
+        from_z = network.create_images_vector(z, randomize_noise=False)  # the stored buffers: what the oracle computes
+        fresh = network.create_images_vector(z)  # the reference's vector path: upstream default randomize_noise=True
+        assert (fresh != from_z).mean() > 0.2 and (network.create_images_vector(z) != fresh).mean() > 0.2  # (saturated pixels stay equal)
+        assert np.array_equal(network.create_images_vector(z, noise_seed=7), network.create_images_vector(z, noise_seed=7))
+        from_w = network.create_image_matrix(dlatents[0].astype(np.float64))  # callers pass float64; stored noise again
     finally:
         network.stop()
     want_z = stylegan2_ref.convert_images_to_uint8(stylegan2_ref.synthesize_z(z, variables, resolution, truncation_psi=1.2))

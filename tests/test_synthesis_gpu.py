@@ -294,9 +294,9 @@ def test_randomize_noise_draws_fresh_standard_normal_noise_and_restores(library)
     engine = hip_lib.Engine(variables, resolution, max_batch=2)
     try:
         stored = engine.synthesize_z(z, truncation_psi=1.2)
-        stored_noise = engine.debug_noise(5)
+        stored_noise = engine.debug_noise(8)
         engine.randomize_noise(seed=11)
-        noise = np.concatenate([engine.debug_noise(layer).reshape(-1) for layer in (6, 7, 8, 9)])  # 32^2 + 32^2 + 64^2 + 64^2 draws
+        noise = np.concatenate([engine.debug_noise(layer).reshape(-1) for layer in (5, 6, 7, 8)])  # 32^2 + 32^2 + 64^2 + 64^2 draws
         assert abs(float(noise.mean())) < 0.05 and abs(float(noise.std()) - 1.0) < 0.03
         assert abs(float((noise ** 4).mean()) - 3.0) < 0.3 and float(np.abs(noise).max()) < 6.0  # kurtosis of a normal, no wild tails
         assert abs(float(np.corrcoef(noise[:-1], noise[1:])[0, 1])) < 0.03  # neighbours (the two halves of a Box-Muller pair) uncorrelated
@@ -305,11 +305,11 @@ def test_randomize_noise_draws_fresh_standard_normal_noise_and_restores(library)
         assert np.array_equal(engine.synthesize_z(z, truncation_psi=1.2), first)
         engine.randomize_noise(seed=12)
         other = engine.synthesize_z(z, truncation_psi=1.2)
-        assert (other != first).mean() > 0.5 and (first != stored).mean() > 0.5
+        assert (other != first).mean() > 0.2 and (first != stored).mean() > 0.2  # (saturated pixels stay equal)
         engine.randomize_noise()  # a fresh seed from the OS
-        assert (engine.synthesize_z(z, truncation_psi=1.2) != other).mean() > 0.5
+        assert (engine.synthesize_z(z, truncation_psi=1.2) != other).mean() > 0.2
         engine.restore_noise()
-        assert np.array_equal(engine.debug_noise(5), stored_noise)
+        assert np.array_equal(engine.debug_noise(8), stored_noise)
         assert np.array_equal(engine.synthesize_z(z, truncation_psi=1.2), stored)
     finally:
         engine.close()
