@@ -65,7 +65,8 @@ def kernel_of_step(step_name: str) -> str:
     if step_name.startswith("convTF"):
         return "upfir_fused_kernel"
     if step_name.startswith("convV"):
-        return "winograd43_rgb_kernel" if "+rgb" in step_name else "winograd43_kernel"
+        narrow = "_32x32_" in step_name  # the 32 x 32 pixel geometry
+        return ("winograd43_w32" if narrow else "winograd43") + ("_rgb_kernel" if "+rgb" in step_name else "_kernel")
     if step_name.startswith("convW"):
         narrow = step_name.endswith("->32")
         if "+rgb" in step_name:

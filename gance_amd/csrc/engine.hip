@@ -241,7 +241,7 @@ struct gance_workspace {
     }
 };
 
-constexpr int kWino43DefaultMaxRes = 1024;  // every Conv1 from 64x64 up (measured faster than the F(2x2,3x3) kernel on all five: DESIGN.md §3)
+constexpr int kWino43DefaultMaxRes = 1024;  // every Conv1 from 32x32 up (measured faster than the F(2x2,3x3) kernels on all six: DESIGN.md §3)
 
 struct GraphEntry {
     hipGraphExec_t exec = nullptr;
@@ -545,7 +545,7 @@ int synthesize_from_dlat(gance_engine* e, const float* d_dlat, int B, uint8_t* d
         form.wino64 = !form.fused_rgb && form.winograd && wino64_on && e->wino64_w[idx] != SIZE_MAX && idx > 0 && e->convs[idx - 1].up;
         // F(4x4, 3x3) where the layer has the weights for it (engine creation: resolution limit, geometry, an up layer in
         // front) and the launch fills the chip; never the network's last layer while that one carries the fused ToRGB
-        const long long w43_tiles = (long long)(c.cout / 32) * (res / 16) * (res / 64) * B;
+        const long long w43_tiles = (long long)(c.cout / 32) * (res >= 64 ? (res / 16) * (res / 64) : 1) * B;  // (32 x 32 pixels per tile on the 32-wide layer)
         form.wino43 = !form.fused_rgb && form.winograd && e->wino43_w[idx] != SIZE_MAX && (w43_tiles >= e->num_cus || wino_mode == 2);
         if (form.wino43) form.wino64 = false;
         return form;
@@ -1003,7 +1003,7 @@ int gance_engine_create(const gance_engine_config* config, const float* host_wei
             gance::winograd64_transform_weights(scaled.data(), c.cin, c.cout, &pool[e->wino64_w[i]]);
         }
         e->wino43_w.push_back(SIZE_MAX);
-        if (!c.up && i > 0 && e->convs[i - 1].up && (1 << c.res_log2) >= 64 && (1 << c.res_log2) <= wino43_max_res(e->cfg.flags) &&
+        if (!c.up && i > 0 && e->convs[i - 1].up && (1 << c.res_log2) >= 32 && (1 << c.res_log2) <= wino43_max_res(e->cfg.flags) &&
             gance::winograd43_supported(c.cin, c.cout, 1 << c.res_log2, 1 << c.res_log2)) {
             std::vector<float> scaled(wn);
             for (size_t j = 0; j < wn; ++j) scaled[j] = src[j] * coef;

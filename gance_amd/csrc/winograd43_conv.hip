@@ -52,23 +52,31 @@ typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
 constexpr int kKC = 4;                         // input channels per chunk = one k-step of the 16x16x4 MFMA
 constexpr int kBM = 32;                        // output channels per block (2 channel tiles of 16)
-constexpr int kTW = 64, kTH = 16;              // pixels per block
-constexpr int kPW = kTW + 8, kPH = kTH + 2;    // haloed patch: 18 rows x 72 columns (16-byte aligned row segments)
-constexpr int kPlane = kPH * kPW;              // 1296 floats per input channel
 constexpr int kUnit = 16 * 36;                 // a (channel tile, ci) unit of weights: [co % 16][36]: a lane's 36 weights are nine aligned float4
 constexpr int kWPieces = 18;                   // 8 units = 4608 floats = 18 pieces of 256 floats
 constexpr int kWFloats = kWPieces * 256;
-constexpr int kPatchF4 = kKC * kPlane / 4;     // 1296 float4
-constexpr int kPPieces = (kPatchF4 + 63) / 64; // 21 (the last one a quarter full)
-constexpr int kPieces = kWPieces + kPPieces;   // 39 (+ one repeat of patch piece 0: every wave issues five, the waits count them)
 constexpr int kPiecesPerWave = 5;
-static_assert(kPieces <= 8 * kPiecesPerWave && kPieces > 7 * kPiecesPerWave, "five LDS-DMA pieces per wave and chunk");
-constexpr int kSlot = kPieces * 256;           // 9984 floats = 39 KB
+// Pixel geometry of a block: TW x (1024 / TW) pixels = 64 tiles of 4x4; a wave's sixteen tiles are TW / 4 tile columns x
+// 16 / (TW / 4) tile rows. <64>: 16 x 64 pixels, a wave = one row of 16 tiles (layers >= 64 wide); <32>: 32 x 32 pixels,
+// a wave = two rows of 8 tiles (the 32x32 layer).
+template <int TW>
+struct Geo43 {
+    static constexpr int kTW = TW, kTH = 1024 / TW;
+    static constexpr int kTC = TW / 4, kTR = 16 / kTC;           // tile columns / tile rows of a wave
+    static constexpr int kPW = kTW + 8, kPH = kTH + 2;            // haloed patch (16-byte aligned row segments): 18 x 72 / 34 x 40
+    static constexpr int kPlane = kPH * kPW;                      // 1296 / 1360 floats per input channel
+    static constexpr int kPatchF4 = kKC * kPlane / 4;
+    static constexpr int kPPieces = (kPatchF4 + 63) / 64;         // 21 / 22 (the last one a quarter full)
+    static constexpr int kPieces = kWPieces + kPPieces;           // 39 (+ one repeat of patch piece 0: every wave issues five) / 40
+    static_assert(kPieces <= 8 * kPiecesPerWave && kPieces > 7 * kPiecesPerWave, "five LDS-DMA pieces per wave and chunk");
+    static constexpr int kSlot = kPieces * 256;                   // 39 / 40 KB
+    static constexpr int kNoiseRowsPerPiece = 256 / kTW;          // noise rows one 1 KB piece covers: 4 / 8
+};
 constexpr int kNBUF = 3;                       // ring slots: chunk G + 2 is issued during k-step G (a fourth slot measured no faster)
 // constants of a tile, fetched by LDS-DMA with its first chunk (a global load in the epilogue costs its whole latency once
 // per tile, and the wait behind it would drain the ring): demod | bias | next layer's style (32 each, padded to 64) |
 // noise [16][64] | (RGB) A operands of the ToRGB product [2 channel tiles][4 steps][64 lanes]
-constexpr int kConstD = 0, kConstB = 64, kConstS = 128, kConstNoise = 192, kConstRgb = kConstNoise + kTH * kTW, kConstFloats = kConstRgb + 512;
+constexpr int kConstD = 0, kConstB = 64, kConstS = 128, kConstNoise = 192, kConstRgb = kConstNoise + 1024, kConstFloats = kConstRgb + 512;
 constexpr int kStoresPerEpilogue = 16, kRgbStores = 12;
 
 // B^T of F(4,3), points 0, +-1, +-2 (Lavin & Gray): 12 vector instructions, on one window line or on two at once
@@ -110,8 +118,11 @@ __device__ __forceinline__ int fresh_lane() {
 
 }  // namespace
 
-template <bool RGB>
+template <bool RGB, int TW>
 __device__ __forceinline__ void winograd43_body(const ConvArgs& p) {
+    using Geo = Geo43<TW>;
+    constexpr int kTW = Geo::kTW, kTH = Geo::kTH, kPW = Geo::kPW, kPH = Geo::kPH, kPlane = Geo::kPlane, kPatchF4 = Geo::kPatchF4;
+    constexpr int kPieces = Geo::kPieces, kSlot = Geo::kSlot, kTC = Geo::kTC, kTR = Geo::kTR;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* const const0 = smem + kNBUF * kSlot;  // two sets of tile constants (tile parity)
     const int tid = threadIdx.x;
@@ -163,7 +174,7 @@ __device__ __forceinline__ void winograd43_body(const ConvArgs& p) {
                 piece_voff[r] = ((c * Hp + row) * Wp + 4 * q4) * 4;
             }
         }
-        win_off = kWFloats + g * kPlane + (4 * pg) * kPW + 4 * n16;
+        win_off = kWFloats + g * kPlane + 4 * (pg * kTR + n16 / kTC) * kPW + 4 * (n16 % kTC);
         a_off = (cot * 4 + g) * kUnit + n16 * 36;
     };
     lane_setup();
@@ -195,12 +206,12 @@ __device__ __forceinline__ void winograd43_body(const ConvArgs& p) {
                     const __amdgpu_buffer_rsrc_t c_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)src, 0, kBM * 4, 0x00020000);
                     __builtin_amdgcn_raw_ptr_buffer_load_lds(c_rsrc, (lds_ptr_t)(set + wave * 64), 4, lane * 4, 0, 0, 0);
                 }
-            } else if (wave < 7) {  // noise rows 4 (wave - 3) .. + 3 of the tile: 4 x 64 floats, one 16-byte piece
+            } else if (wave < 7) {  // a quarter of the tile's noise (256 floats = 4 rows of 64 / 8 rows of 32): one 16-byte piece
                 if (p.noise != nullptr) {
                     const __amdgpu_buffer_rsrc_t nz_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.noise, 0, 0x7fffffff, 0x00020000);
-                    const int row = 4 * (wave - 3) + (lane >> 4);
+                    const int row = Geo::kNoiseRowsPerPiece * (wave - 3) + lane / kTC;
                     __builtin_amdgcn_raw_ptr_buffer_load_lds(nz_rsrc, (lds_ptr_t)(set + kConstNoise + (wave - 3) * 256), 16,
-                                                             ((t.y0 + row) * p.OW + t.x0 + 4 * (lane & 15)) * 4, 0, 0, 0);
+                                                             ((t.y0 + row) * p.OW + t.x0 + 4 * (lane % kTC)) * 4, 0, 0, 0);
                 }
             } else if (RGB) {  // the A operands of the ToRGB product: [b][Cout / 4 steps][64 lanes], steps 8 m_tile .. + 7: two 16-byte pieces
                 const __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc(
@@ -319,7 +330,8 @@ __device__ __forceinline__ void winograd43_body(const ConvArgs& p) {
         const float* const set = const0 + (i & 1) * kConstFloats;
         const int lane = fresh_lane();
         const int n16 = lane & 15, g = lane >> 4;
-        const int oy0 = t.y0 + 4 * pg, ox0 = t.x0 + 4 * n16;
+        const int ty4 = 4 * (pg * kTR + n16 / kTC), tx4 = 4 * (n16 % kTC);  // the lane's tile inside the block's pixel tile
+        const int oy0 = t.y0 + ty4, ox0 = t.x0 + tx4;
         const int ct = t.m_tile * 2 + cot;  // 16-channel tile of the layer
         const int co0 = ct * 16 + 4 * g;
         const f32x4 dm = *reinterpret_cast<const f32x4*>(set + kConstD + cot * 16 + 4 * g);
@@ -358,7 +370,7 @@ __device__ __forceinline__ void winograd43_body(const ConvArgs& p) {
                 float yrow[4];
                 output_transform6(tr[oy][0], tr[oy][1], tr[oy][2], tr[oy][3], tr[oy][4], tr[oy][5], yrow);
                 f32x4 nz = f32x4{0.f, 0.f, 0.f, 0.f};
-                if (p.noise != nullptr) nz = *reinterpret_cast<const f32x4*>(set + kConstNoise + (4 * pg + oy) * kTW + 4 * n16) * p.noise_strength;
+                if (p.noise != nullptr) nz = *reinterpret_cast<const f32x4*>(set + kConstNoise + (ty4 + oy) * kTW + tx4) * p.noise_strength;
                 f32x4 v = f32x4{yrow[0], yrow[1], yrow[2], yrow[3]} * dm[r] + nz + bm[r];
 #pragma unroll
                 for (int k = 0; k < 4; ++k) v[k] = fmaxf(v[k], 0.2f * v[k]);  // (x sqrt(2): in a_rgb and s2)
@@ -486,11 +498,14 @@ __device__ __forceinline__ void winograd43_body(const ConvArgs& p) {
 }
 
 // (plain functions around the templated body: as a kernel TEMPLATE the host pass of hipcc drops the instantiation, see winograd64_conv.hip)
-__global__ __launch_bounds__(512, 1) void winograd43_kernel(const ConvArgs p) { winograd43_body<false>(p); }
-__global__ __launch_bounds__(512, 1) void winograd43_rgb_kernel(const ConvArgs p) { winograd43_body<true>(p); }
+__global__ __launch_bounds__(512, 1) void winograd43_kernel(const ConvArgs p) { winograd43_body<false, 64>(p); }
+__global__ __launch_bounds__(512, 1) void winograd43_rgb_kernel(const ConvArgs p) { winograd43_body<true, 64>(p); }
+__global__ __launch_bounds__(512, 1) void winograd43_w32_kernel(const ConvArgs p) { winograd43_body<false, 32>(p); }
+__global__ __launch_bounds__(512, 1) void winograd43_w32_rgb_kernel(const ConvArgs p) { winograd43_body<true, 32>(p); }
 
 bool winograd43_supported(int cin, int cout, int H, int W) {
-    return cin % kKC == 0 && cin / kKC >= 4 && cout % kBM == 0 && H % kTH == 0 && W % kTW == 0;  // (>= 4 chunks per tile: two constant sets)
+    // (>= 4 chunks per tile: two constant sets). Pixel tiles of 16 x 64, or 32 x 32 on the 32-pixel-wide layer.
+    return cin % kKC == 0 && cin / kKC >= 4 && cout % kBM == 0 && ((W % 64 == 0 && H % 16 == 0) || (W == 32 && H % 32 == 0));
 }
 
 size_t winograd43_weight_floats(int cin, int cout) { return (size_t)(cout / kBM) * (cin / kKC) * kWFloats; }
@@ -526,13 +541,15 @@ hipError_t launch_winograd43_conv(const ConvArgs& args, hipStream_t stream) {
     if (!winograd43_supported(args.Cin, args.Cout, args.H, args.W)) return hipErrorInvalidValue;
     if (rgb ? (!winograd43_rgb_supported(args.Cout) || args.rgb_coef == nullptr || args.rgb_y == nullptr) : (args.epilogue != kEpilogueFull || args.out == nullptr))
         return hipErrorInvalidValue;
-    void (*const kernel)(const ConvArgs) = rgb ? winograd43_rgb_kernel : winograd43_kernel;
-    constexpr size_t kLdsBytes = sizeof(float) * ((size_t)kNBUF * kSlot + 2 * kConstFloats);
-    static PerDeviceInt resident[2];  // per device: the dynamic-LDS opt-in and the launch size = one block per CU, a multiple of 8 (XCDs)
+    const bool narrow = args.W % 64 != 0;  // the 32 x 32 pixel geometry
+    void (*const kernel)(const ConvArgs) = narrow ? (rgb ? winograd43_w32_rgb_kernel : winograd43_w32_kernel) : (rgb ? winograd43_rgb_kernel : winograd43_kernel);
+    const int tw = narrow ? 32 : 64, th = 1024 / tw;
+    const size_t lds_bytes = sizeof(float) * ((size_t)kNBUF * (narrow ? Geo43<32>::kSlot : Geo43<64>::kSlot) + 2 * kConstFloats);
+    static PerDeviceInt resident[4];  // per device: the dynamic-LDS opt-in and the launch size = one block per CU, a multiple of 8 (XCDs)
     int resident_blocks = 0;
-    hipError_t e = resident[rgb ? 1 : 0].get(
+    hipError_t e = resident[(narrow ? 2 : 0) + (rgb ? 1 : 0)].get(
         [&](int device, int* value) {
-            hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes);
+            hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
             if (err != hipSuccess) return err;
             int cus = 0;
             if ((err = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device)) != hipSuccess) return err;
@@ -542,12 +559,12 @@ hipError_t launch_winograd43_conv(const ConvArgs& args, hipStream_t stream) {
         &resident_blocks);
     if (e != hipSuccess) return e;
     ConvArgs a = args;
-    a.tiles_x = a.W / kTW;
-    a.tiles_y = a.H / kTH;
+    a.tiles_x = a.W / tw;
+    a.tiles_y = a.H / th;
     a.m_tiles = a.Cout / kBM;
     a.total_chunks = a.Cin / kKC;
     a.total_tiles = a.m_tiles * a.tiles_x * a.tiles_y * a.B;
-    hipLaunchKernelGGL(kernel, dim3(std::min(a.total_tiles, resident_blocks)), dim3(512), kLdsBytes, stream, a);
+    hipLaunchKernelGGL(kernel, dim3(std::min(a.total_tiles, resident_blocks)), dim3(512), lds_bytes, stream, a);
     return hipGetLastError();
 }
 

@@ -163,11 +163,13 @@ def g_synthesis(
     resolution: int,
     noise_override: Optional[Dict[int, torch.Tensor]] = None,
     stop_after: Optional[int] = None,
+    collect: Optional[list] = None,
 ) -> torch.Tensor:
     """
     `G_synthesis_stylegan2`, architecture 'skip', randomize_noise=False (stored noise buffers).
     dlatents [B, W, 512] -> images [B, 3, R, R] (float).
-    `stop_after=n` (debug) returns the activation x after the n-th conv layer instead.
+    `stop_after=n` (debug) returns the activation x after the n-th conv layer instead; `collect` (a list) receives the
+    activation after every conv layer, in order (the layer-wise parity tests: one pass instead of one per layer).
     """
     dtype = dlatents.dtype
     res_log2 = int(np.log2(resolution))
@@ -190,15 +192,21 @@ def g_synthesis(
 
     x = _t(variables, "G_synthesis/4x4/Const/const", dtype).repeat(batch, 1, 1, 1)
     x = layer(x, 0, "G_synthesis/4x4/Conv", up=False)
+    if collect is not None:
+        collect.append(x)
     if stop_after == 1:
         return x
     y = torgb(x, None, 2)
     for res in range(3, res_log2 + 1):
         side = 2 ** res
         x = layer(x, res * 2 - 5, f"G_synthesis/{side}x{side}/Conv0_up", up=True)
+        if collect is not None:
+            collect.append(x)
         if stop_after == res * 2 - 4:
             return x
         x = layer(x, res * 2 - 4, f"G_synthesis/{side}x{side}/Conv1", up=False)
+        if collect is not None:
+            collect.append(x)
         if stop_after == res * 2 - 3:
             return x
         y = upsample_2d(y)

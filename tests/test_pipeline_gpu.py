@@ -168,9 +168,9 @@ def test_config_0_verbatim_256_random_z_through_the_network_interface(tmp_path: 
     assert frames.shape == (64, resolution, resolution, 3) and frames.dtype == np.uint8
     assert np.array_equal(generic, frames[5])
     variables = sg2_spec.make_random_variables(resolution, seed=0)
-    for start in (0, 56):  # the oracle (fp64 on the host cores) on the first and last eight; all 64 went through the GPU path
-        want = stylegan2_ref.convert_images_to_uint8(stylegan2_ref.synthesize_z(vectors[start : start + 8], variables, resolution, truncation_psi=1.2))
-        diff = np.abs(frames[start : start + 8].astype(np.int16) - want.astype(np.int16))
+    for start in (0, 60):  # the oracle (fp64 on the host cores) on the first and last four; all 64 went through the GPU path
+        want = stylegan2_ref.convert_images_to_uint8(stylegan2_ref.synthesize_z(vectors[start : start + 4], variables, resolution, truncation_psi=1.2))
+        diff = np.abs(frames[start : start + 4].astype(np.int16) - want.astype(np.int16))
         assert int(diff.max()) <= 1 and float((diff > 0).mean()) < 1e-3
     assert len({frame.tobytes() for frame in frames}) == 64  # 64 different z vectors, 64 different frames
     assert frames.sum() > 0  # the reference's own assertion at this boundary (test_network_functions.py:100-118)

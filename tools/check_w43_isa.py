@@ -10,7 +10,7 @@ with tempfile.NamedTemporaryFile(suffix=".s") as out:
                    check=True, cwd=src.parent, stderr=subprocess.DEVNULL)
     text = Path(out.name).read_text()
 bad = False
-for name in ("winograd43_kernel", "winograd43_rgb_kernel"):
+for name in ("winograd43_kernel", "winograd43_rgb_kernel", "winograd43_w32_kernel", "winograd43_w32_rgb_kernel"):
     start = text.index(f"_ZN5gance{len(name)}{name}ENS_8ConvArgsE:")
     end = text.index(".Lfunc_end", start)
     body = text[start:end].split("\n")
