@@ -41,6 +41,10 @@
 #ifndef GANCE_W43_WINDOW
 #define GANCE_W43_WINDOW 0
 #endif
+#ifndef GANCE_W43_ABLATE
+#define GANCE_W43_ABLATE 0  // timing ablations (wrong results; Makefile w43ab%): 1 no DMA inside the stream, 2 no input transform,
+                            // 4 no weight reads, 8 no window reads (nor transform), 16 no barrier per k-step
+#endif
 
 namespace gance {
 
@@ -92,6 +96,24 @@ __device__ __forceinline__ void input_transform6(T d0, T d1, T d2, T d3, T d4, T
     t[3] = c + 2.f * e;
     t[4] = c - 2.f * e;
     t[5] = 4.f * d1 + (d5 - 5.f * d3);
+}
+
+// The same B^T along a window ROW whose six values lie in three register pairs (d0, d5), (d1, d2), (d3, d4) -- which is how
+// the packed column pass leaves them: eight vector instructions instead of twelve. (b, a), (e, c) are one packed operation
+// each; t1 = a + b | t2 = a - b and t3 = c + 2 e | t4 = c - 2 e are one each with both result halves reading BOTH halves of
+// the same source pair (op_sel), which hipcc does not form by itself; t0 and t5 mix three pairs and stay scalar.
+__device__ __forceinline__ void input_transform6_row(f32x2 r05, f32x2 r12, f32x2 r34, float (&t)[6]) {
+    const f32x2 ba = r34 - 4.f * r12;
+    const f32x2 ec = r34 - r12;
+    f32x2 t12, t34;
+    asm("v_pk_add_f32 %0, %1, %1 op_sel:[1,0] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(t12) : "v"(ba));
+    asm("v_pk_fma_f32 %0, %1, 2.0, %1 op_sel:[0,0,1] op_sel_hi:[0,0,1] neg_hi:[1,0,0]" : "=v"(t34) : "v"(ec));
+    t[0] = 4.f * r05[0] + (r34[1] - 5.f * r12[1]);
+    t[1] = t12[0];
+    t[2] = t12[1];
+    t[3] = t34[0];
+    t[4] = t34[1];
+    t[5] = 4.f * r12[0] + (r05[1] - 5.f * r34[0]);
 }
 
 // A^T of F(4,3): 10 vector instructions
@@ -259,9 +281,27 @@ __device__ __forceinline__ void winograd43_body(const ConvArgs& p) {
     // (3, 8) one ds_read2_b32: fewest bytes; three aligned 16-byte reads per row -- no bank conflicts, twice the bytes -- and
     // one 16-byte read + two DPP row shifts both measured slower), then the row pass line by line.
     float V[36], A[36];
+#if GANCE_W43_ABLATE & 12
+    for (int k = 0; k < 36; ++k) V[k] = A[k] = 0.f;
+#endif
     auto load_transform = [&](int slot) {
         const float* const P = smem + slot * kSlot + win_off;
         const float* const U = smem + slot * kSlot + a_off;
+#if GANCE_W43_ABLATE & 8
+#pragma unroll
+        for (int k = 0; k < 36; ++k) asm volatile("" : "+v"(V[k]));
+#if GANCE_W43_ABLATE & 4
+#pragma unroll
+        for (int k = 0; k < 36; ++k) asm volatile("" : "+v"(A[k]));
+#else
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+            const f32x4 t = *reinterpret_cast<const f32x4*>(U + 4 * k);
+            A[4 * k + 0] = t[0], A[4 * k + 1] = t[1], A[4 * k + 2] = t[2], A[4 * k + 3] = t[3];
+        }
+#endif
+        return;
+#endif
         f32x2 c45[6], c67[6], c38[6];
 #pragma unroll
         for (int y = 0; y < 6; ++y) {
@@ -280,6 +320,10 @@ __device__ __forceinline__ void winograd43_body(const ConvArgs& p) {
             c38[y][1] = P[y * kPW + 8];
 #endif
         }
+#if GANCE_W43_ABLATE & 4
+#pragma unroll
+        for (int k = 0; k < 36; ++k) asm volatile("" : "+v"(A[k]));
+#else
 #pragma unroll
         for (int k = 0; k < 9; ++k) {
             const f32x4 t = *reinterpret_cast<const f32x4*>(U + 4 * k);
@@ -288,6 +332,15 @@ __device__ __forceinline__ void winograd43_body(const ConvArgs& p) {
             A[4 * k + 2] = t[2];
             A[4 * k + 3] = t[3];
         }
+#endif
+#if GANCE_W43_ABLATE & 2
+#pragma unroll
+        for (int y = 0; y < 6; ++y) {
+            V[y * 6 + 0] = c38[y][0], V[y * 6 + 1] = c45[y][0], V[y * 6 + 2] = c45[y][1];
+            V[y * 6 + 3] = c67[y][0], V[y * 6 + 4] = c67[y][1], V[y * 6 + 5] = c38[y][1];
+        }
+        return;
+#endif
         f32x2 t45[6], t67[6], t38[6];
         input_transform6<f32x2>(c45[0], c45[1], c45[2], c45[3], c45[4], c45[5], t45);
         input_transform6<f32x2>(c67[0], c67[1], c67[2], c67[3], c67[4], c67[5], t67);
@@ -297,7 +350,7 @@ __device__ __forceinline__ void winograd43_body(const ConvArgs& p) {
             // (kept opaque: where a packed result is only read by element, hipcc splits the packed operation again)
             asm("" : "+v"(t45[i]), "+v"(t67[i]), "+v"(t38[i]));
             float v[6];
-            input_transform6<float>(t38[i][0], t45[i][0], t45[i][1], t67[i][0], t67[i][1], t38[i][1], v);
+            input_transform6_row(t38[i], t45[i], t67[i], v);
 #pragma unroll
             for (int j = 0; j < 6; ++j) V[j * 6 + i] = v[j];
         }
@@ -311,7 +364,7 @@ __device__ __forceinline__ void winograd43_body(const ConvArgs& p) {
 #pragma unroll
         for (int pos = 0; pos < 36; ++pos) {
             acc[pos] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[pos], V[pos], kFirst ? f32x4{0.f, 0.f, 0.f, 0.f} : acc[pos], 0, 0, 0);
-            if (pos % 7 == 3 && cur_valid) stage_piece(pos / 7);
+            if (pos % 7 == 3 && cur_valid && !(GANCE_W43_ABLATE & 1)) stage_piece(pos / 7);
         }
         __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);  // 4 MFMAs, then 4 x (one LDS-DMA issue, 7 MFMAs), one issue, 4 MFMAs
         __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
@@ -427,7 +480,7 @@ __device__ __forceinline__ void winograd43_body(const ConvArgs& p) {
             asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kPiecesPerWave + kStoresPerEpilogue + (RGB ? kRgbStores : 0)) : "memory");
         else
             asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kPiecesPerWave) : "memory");
-        __builtin_amdgcn_s_barrier();
+        if (!(GANCE_W43_ABLATE & 16)) __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         stage_begin();  // chunk G + 2 -> the slot k-step G - 1 read (every wave is past the barrier: nobody reads it any more)
         __builtin_amdgcn_sched_barrier(0);
