@@ -39,7 +39,8 @@
 
 #include "kernels.h"
 
-// Timing ablations (GANCE_DEBUG_UPFIR: 1 no stores, 2 no epilogue, 4 no MFMA, 8 no DMA after the first chunk)
+// Timing ablations (GANCE_DEBUG_UPFIR: 1 no stores, 2 no epilogue, 4 no MFMA, 8 no DMA after the first chunk, 16 no
+// accumulator dump into the T window, 32 no FIR rows; Makefile target upfirdbg)
 // exist only in a -DGANCE_UPFIR_DEBUG=1 build: their uniform branches cost scalar registers the product kernel
 // does not have (it already spills some to VGPR lanes).
 #ifndef GANCE_UPFIR_DEBUG
@@ -463,6 +464,7 @@ __device__ __forceinline__ void upfir_fused_body(const UpFirArgs& p) {
         for (int g = 0; g < 4; ++g) {
             // -- dump: accumulator registers 4g .. 4g+3 = channels 8g + rr + 4 lh (g is unrolled: the
             // register indices are static and a pass's accumulators die with its dump) --
+            if (!(UPFIR_DBG & 16))
 #pragma unroll
             for (int jj = 0; jj < 4; ++jj)
 #pragma unroll
@@ -488,18 +490,19 @@ __device__ __forceinline__ void upfir_fused_body(const UpFirArgs& p) {
             const int o_soff_base = (int)((8 * g * oplane + (long long)(oy0 + 1) * OWp + 2 * X0 + 4) * 4);
             f32x4 keep_a[3], keep_b[3];  // raw T rows 16..18 of the own columns: the next step's carry
             f32x4 h0, h1, h2, h3;        // ring of horizontally filtered rows
-            // one window row: two aligned 16-byte LDS reads, 4 horizontal outputs (mul + 3 fma each), and when a
-            // whole 4-row window ends here the vertical taps (4 fma), leaky ReLU as 0.6 v + 0.4 |v| (2 ops, no
-            // NaN canonicalisation as fmaxf would add) and one 16-byte store. Scalar on purpose: packed-f32 forms
-            // need even-aligned register pairs and cost more moves than they save here.
-            auto window_row = [&](const float* rowp, f32x4& hnew, const f32x4& ha, const f32x4& hb, const f32x4& hc, int r,
-                                  f32x4* keep_ta, f32x4* keep_tb) {
-                const f32x4 ta = *reinterpret_cast<const f32x4*>(rowp);
-                const f32x4 tb = *reinterpret_cast<const f32x4*>(rowp + 4);
-                if (keep_ta != nullptr) {
-                    *keep_ta = ta;
-                    *keep_tb = tb;
-                }
+            // one window row: two aligned 16-byte LDS reads (+ one of the noise tile), 4 horizontal outputs (mul + 3 fma
+            // each), and when a whole 4-row window ends here the vertical taps (4 fma), leaky ReLU as 0.6 v + 0.4 |v| (2
+            // ops, no NaN canonicalisation as fmaxf would add) and one 16-byte store. Scalar on purpose: packed-f32 forms
+            // need even-aligned register pairs and cost more moves than they save here. The reads of a trip's four rows
+            // are issued together in front of its arithmetic: read where they are used, behind the row's own branch, each
+            // row exposed its LDS latency to the only wave of the SIMD (19 times per pass).
+            // (the noise read is unconditional: a branch around it would split the block the reads are gathered in)
+            auto read_row = [&](const float* rowp, int r, f32x4& ta, f32x4& tb, f32x4& nz) {
+                ta = *reinterpret_cast<const f32x4*>(rowp);
+                tb = *reinterpret_cast<const f32x4*>(rowp + 4);
+                nz = *reinterpret_cast<const f32x4*>(nz_lds + r * (2 * kSW) + 4 * cg);  // (r < 0: inside the constants in front of the tile, unused)
+            };
+            auto window_row = [&](const f32x4& ta, const f32x4& tb, const f32x4& nz, f32x4& hnew, const f32x4& ha, const f32x4& hb, const f32x4& hc, int r) {
                 if (!emit) return;
                 const float t[7] = {ta[0], ta[1], ta[2], ta[3], tb[0], tb[1], tb[2]};
 #pragma unroll
@@ -508,7 +511,7 @@ __device__ __forceinline__ void upfir_fused_body(const UpFirArgs& p) {
                     f32x4 v;
 #pragma unroll
                     for (int o = 0; o < 4; ++o) v[o] = fmaf(0.25f, hnew[o], fmaf(0.75f, hc[o], fmaf(0.75f, hb[o], fmaf(0.25f, ha[o], bias2))));
-                    if (has_noise) v += ns2 * *reinterpret_cast<const f32x4*>(nz_lds + r * (2 * kSW) + 4 * cg);
+                    if (has_noise) v += ns2 * nz;
 #pragma unroll
                     for (int o = 0; o < 4; ++o) v[o] = fmaf(lr6, v[o], lr4 * __builtin_fabsf(v[o]));
                     if (!(UPFIR_DBG & 1) || v[0] == 12345.f)
@@ -518,17 +521,28 @@ __device__ __forceinline__ void upfir_fused_body(const UpFirArgs& p) {
             // rows 0..15 in four trips of four (rolled: the compiler must not hoist all 38 LDS reads into registers),
             // rows 16..18 peeled (they are also the carry). Window row i closes output row r = i - 3.
 #pragma unroll 1
-            for (int i4 = 0; i4 < 4; ++i4) {
+            for (int i4 = (UPFIR_DBG & 32) ? 4 : 0; i4 < 4; ++i4) {
                 const float* const st = stage_c + (4 * i4 - 3) * kTW;
                 const float* const r0 = i4 == 0 ? carry_c : st;
-                window_row(r0, h0, h1, h2, h3, 4 * i4 - 3, nullptr, nullptr);
-                window_row(r0 + kTW, h1, h2, h3, h0, 4 * i4 - 2, nullptr, nullptr);
-                window_row(r0 + 2 * kTW, h2, h3, h0, h1, 4 * i4 - 1, nullptr, nullptr);
-                window_row(st + 3 * kTW, h3, h0, h1, h2, 4 * i4, nullptr, nullptr);
+                f32x4 ta0, tb0, nz0, ta1, tb1, nz1, ta2, tb2, nz2, ta3, tb3, nz3;
+                read_row(r0, 4 * i4 - 3, ta0, tb0, nz0);
+                read_row(r0 + kTW, 4 * i4 - 2, ta1, tb1, nz1);
+                read_row(r0 + 2 * kTW, 4 * i4 - 1, ta2, tb2, nz2);
+                read_row(st + 3 * kTW, 4 * i4, ta3, tb3, nz3);
+                window_row(ta0, tb0, nz0, h0, h1, h2, h3, 4 * i4 - 3);
+                window_row(ta1, tb1, nz1, h1, h2, h3, h0, 4 * i4 - 2);
+                window_row(ta2, tb2, nz2, h2, h3, h0, h1, 4 * i4 - 1);
+                window_row(ta3, tb3, nz3, h3, h0, h1, h2, 4 * i4);
             }
-            window_row(stage_c + 13 * kTW, h0, h1, h2, h3, 13, &keep_a[0], &keep_b[0]);
-            window_row(stage_c + 14 * kTW, h1, h2, h3, h0, 14, &keep_a[1], &keep_b[1]);
-            window_row(stage_c + 15 * kTW, h2, h3, h0, h1, 15, &keep_a[2], &keep_b[2]);
+            {
+                f32x4 nz0, nz1, nz2;
+                read_row(stage_c + 13 * kTW, 13, keep_a[0], keep_b[0], nz0);
+                read_row(stage_c + 14 * kTW, 14, keep_a[1], keep_b[1], nz1);
+                read_row(stage_c + 15 * kTW, 15, keep_a[2], keep_b[2], nz2);
+                window_row(keep_a[0], keep_b[0], nz0, h0, h1, h2, h3, 13);
+                window_row(keep_a[1], keep_b[1], nz1, h1, h2, h3, h0, 14);
+                window_row(keep_a[2], keep_b[2], nz2, h2, h3, h0, h1, 15);
+            }
             lds_barrier();
             // -- the last three T rows of this step become the carry of these 8 channels --
             float* const carry_w = carry + ch * (kCarryRows * kTW) + 4 * cg;

@@ -1,7 +1,7 @@
 #!/bin/bash
-# Timing ablations of the fused up kernel (GANCE_DEBUG_UPFIR / stagger knobs): per-layer times from bench.py's step table.
-for cfg in "0 -1" "0 1" "0 8" "1 -1" "2 -1" "4 -1" "6 -1" "12 -1"; do
-  set -- $cfg
-  GANCE_DEBUG_UPFIR=$1 GANCE_TUNE_UPFIR_PHASES=$2 python bench.py --steps 3 --warmup 1 --no-cpu-baseline --print-steps > /dev/null 2> gpurun_out/ab_$1_$2.steps
-  echo "debug=$1 phases=$2: $(grep convTF gpurun_out/ab_$1_$2.steps | awk '{printf "%s ", $2}')"
+# Per-launch times of the fused up layers under the timing ablations of the debug build (make -C gance_amd/csrc upfirdbg):
+# tools/gpu_upfir_ablate.sh 0 1 2 16 32 48 ...   (GANCE_DEBUG_UPFIR flag sets; wrong results by design)
+for f in "$@"; do
+  GANCE_HIP_LIBRARY=$PWD/gance_amd/libgance_hip_upfirdbg.so GANCE_DEBUG_UPFIR=$f timeout -k 10 200 python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-extras --print-steps 2> gpurun_out/upfir_ab_$f.steps > gpurun_out/upfir_ab_$f.json
+  echo "flags=$f: $(grep convTF gpurun_out/upfir_ab_$f.steps | awk '{printf "%s ", $2}')"
 done
