@@ -198,7 +198,10 @@ def ordered_device_chunks(synthesize_piece, num_frames: int, frames_per_rank: in
     more, and whoever reads it must do so on `reader_stream` (a side stream that already waits for the gather; None
     on the CPU): the generator makes the gather that overwrites the buffer wait for that stream. Other ranks yield
     nothing. Chunk k is handed out after chunk k+1's synthesis and gather have been issued, so the consumer's work
-    on it (overlay, host drain) overlaps them.
+    on it (overlay, host drain) overlaps them: the reader stream waits for chunk k's OWN gather (an event recorded
+    behind it), not for what was issued since -- a consumer that blocks the host on the reader stream (the overlay
+    gate copies frames to the host for the landmark detector) would otherwise sit out chunk k+1's synthesis first and
+    leave the GPU idle while it works.
     Failure handling: every rank exchanges one status word per chunk on the host-side control group; an exception in
     `synthesize_piece` on any rank ends the generator on EVERY rank (the failing rank re-raises its exception, the
     others raise StreamRankError) instead of leaving them blocked in the next gather.
@@ -211,19 +214,25 @@ def ordered_device_chunks(synthesize_piece, num_frames: int, frames_per_rank: in
     gathered = [torch.empty((per_chunk, *frame_shape), dtype=torch.uint8, device=device) for _ in range(2)] if rank == 0 else None
     local = [torch.zeros((frames_per_rank, *frame_shape), dtype=torch.uint8, device=device) for _ in range(2)]
     reader_stream = torch.cuda.Stream(device) if on_gpu and rank == 0 else None
+    issued = [None, None]  # per gather buffer: event behind the last copy / gather issued into it
     works = [None, None]
     produced = 0
 
     def hand_out(chunk: int):
         """Gather of `chunk` done (in stream order on the reader stream) -> its view of the gather buffer."""
         slot = chunk & 1
-        if works[slot] is not None:
-            works[slot].wait()
-            works[slot] = None
         first = chunk * per_chunk
         count = min(num_frames, first + per_chunk) - first
-        if reader_stream is not None:
-            reader_stream.wait_stream(torch.cuda.current_stream(device))
+        if reader_stream is None:
+            if works[slot] is not None:
+                works[slot].wait()
+                works[slot] = None
+            return first, gathered[slot][:count], None
+        with torch.cuda.stream(reader_stream):  # (an asynchronous collective's wait() makes the CURRENT stream wait for it)
+            if works[slot] is not None:
+                works[slot].wait()
+                works[slot] = None
+            reader_stream.wait_event(issued[slot])
         return first, gathered[slot][:count], reader_stream
 
     for chunk in range(chunks):
@@ -255,6 +264,9 @@ def ordered_device_chunks(synthesize_piece, num_frames: int, frames_per_rank: in
             works[slot] = dist.gather(local[slot], gather_list=list(gathered[slot].chunk(world_size, dim=0)) if rank == 0 else None, dst=0, async_op=True)
         elif rank == 0:
             gathered[slot][:frames_per_rank].copy_(local[slot])
+        if reader_stream is not None:
+            issued[slot] = torch.cuda.Event()
+            issued[slot].record(torch.cuda.current_stream(device))
         if rank == 0 and chunk >= 1:
             yield hand_out(chunk - 1)
     if rank == 0 and chunks >= 1:
