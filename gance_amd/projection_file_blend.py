@@ -107,7 +107,8 @@ def synthesize_device_frames_network_major(  # pylint: disable=too-many-locals
     the result is the frame order.
     """
     device = dlatents.device
-    indices = network_indices.cpu().numpy()
+    # (a host array is taken as it is: the stream hands slices of one host copy, not a device-to-host sync per window)
+    indices = network_indices if isinstance(network_indices, np.ndarray) else network_indices.cpu().numpy()
     num_frames = int(dlatents.shape[0])
     out_side = _common_output_side(networks, indices, output_side_length)
     out = torch.empty((num_frames, out_side, out_side, 3), dtype=torch.uint8, device=device)
@@ -121,7 +122,13 @@ def synthesize_device_frames_network_major(  # pylint: disable=too-many-locals
             first = int(host_members[0])
             # a run of consecutive frames (always, with one network) is produced in place
             in_place = int(host_members[-1]) - first + 1 == count
-            members = torch.from_numpy(host_members).to(device)
+            # (only a scattered call needs its frame numbers on the device; from pinned memory, without blocking: a pageable
+            # copy is synchronous IN STREAM ORDER, i.e. the host would wait for the previous engine call before it could
+            # issue this one, and the GPU would idle for the launch sequence of every call)
+            members = None
+            if not in_place:
+                members = torch.from_numpy(host_members)
+                members = (members.pin_memory() if device.type == "cuda" else members).to(device, non_blocking=True)
             native = out[first : first + count] if in_place and out_side == side else torch.empty(
                 (count, side, side, 3), dtype=torch.uint8, device=device
             )
@@ -323,6 +330,12 @@ def _prepare_blend_inputs(  # pylint: disable=too-many-arguments,too-many-locals
     return _BlendInputs(dlatents, indices, int(dlatents.shape[0]), target_images, audio, int(frame_multiplier))
 
 
+# Pieces per network in a window of the multi-network stream: a window of w * networks pieces ends in up to `networks` short
+# engine calls, so the loss against full batches shrinks as 1 / w; the window's frames wait in HBM (uint8, 3 MiB each at
+# 1024^2: 768 frames = 2.4 GB with three networks)
+STREAM_WINDOW_PIECES_PER_NETWORK = 4
+
+
 class _WindowSynthesizer:  # pylint: disable=too-few-public-methods
     """
     `synthesize_piece(offset, count)` of the frame stream, batched by network ACROSS a window of pieces: the rank's
@@ -334,7 +347,7 @@ class _WindowSynthesizer:  # pylint: disable=too-few-public-methods
     """
 
     def __init__(self, dlatents: torch.Tensor, indices: torch.Tensor, networks: MultiNetwork, side: int, frames_per_call: int, window: int) -> None:
-        self._dlatents, self._indices, self._networks, self._side = dlatents, indices, networks, side
+        self._dlatents, self._indices, self._networks, self._side = dlatents, indices.cpu().numpy(), networks, side
         self._frames_per_call, self._window = frames_per_call, max(1, window)
         self._start, self._frames = 0, None
 
@@ -496,7 +509,7 @@ def projection_file_blend_frame_chunks(  # pylint: disable=too-many-arguments,to
         indices = frame_sharding.scatter_for_stream(inputs.indices, num_frames, frames_per_call, device)
         side = _common_output_side(networks, np.asarray(networks.network_indices), output_side_length)
         num_networks = len(set(networks.network_paths))
-        synthesize_piece = _WindowSynthesizer(dlatents, indices, networks, side, frames_per_call, 1 if num_networks == 1 else 2 * num_networks)
+        synthesize_piece = _WindowSynthesizer(dlatents, indices, networks, side, frames_per_call, 1 if num_networks == 1 else STREAM_WINDOW_PIECES_PER_NETWORK * num_networks)
         stage = None
         if overlay is not None and rank == 0:
             music_mask = overlay.complexity_change_rolling_sum_window is not None and overlay.complexity_change_threshold is not None
