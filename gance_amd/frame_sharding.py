@@ -192,7 +192,11 @@ def ordered_device_chunks(synthesize_piece, num_frames: int, frames_per_rank: in
     """
     Generator (collective: every rank must exhaust it). `synthesize_piece(offset, count)` returns this rank's
     next `count` frames as a uint8 tensor [count, *frame_shape] on `device`, where `offset` counts the frames
-    the rank has produced so far (an index into its `scatter_for_stream` inputs).
+    the rank has produced so far (an index into its `scatter_for_stream` inputs). A callable with a true attribute
+    `writes_into` is called as `synthesize_piece(offset, count, out)` instead and writes the frames into `out`, a
+    view of the stream's own buffer: no copy of the chunk (a device-to-device copy of 64 frames of 1024^2 is a blit
+    kernel of about a millisecond in the stream of the synthesis). With one rank the chunk is handed out from that
+    buffer; only several ranks need gather buffers.
     On rank 0 it yields (first_frame_index, frames, reader_stream) per chunk, in frame order: `frames` is a view of
     one of two gather buffers in HBM, [n, *frame_shape] uint8. It is valid until the generator is advanced TWICE
     more, and whoever reads it must do so on `reader_stream` (a side stream that already waits for the gather; None
@@ -211,8 +215,11 @@ def ordered_device_chunks(synthesize_piece, num_frames: int, frames_per_rank: in
     chunks = stream_chunks(num_frames, world_size, frames_per_rank)
     per_chunk = world_size * frames_per_rank
     on_gpu = device.type == "cuda"
-    gathered = [torch.empty((per_chunk, *frame_shape), dtype=torch.uint8, device=device) for _ in range(2)] if rank == 0 else None
     local = [torch.zeros((frames_per_rank, *frame_shape), dtype=torch.uint8, device=device) for _ in range(2)]
+    gathered = None
+    if rank == 0:
+        gathered = local if world_size == 1 else [torch.empty((per_chunk, *frame_shape), dtype=torch.uint8, device=device) for _ in range(2)]
+    writes_into = bool(getattr(synthesize_piece, "writes_into", False))
     reader_stream = torch.cuda.Stream(device) if on_gpu and rank == 0 else None
     issued = [None, None]  # per gather buffer: event behind the last copy / gather issued into it
     works = [None, None]
@@ -248,8 +255,10 @@ def ordered_device_chunks(synthesize_piece, num_frames: int, frames_per_rank: in
         failure = None
         if count:
             try:
-                frames = synthesize_piece(produced, count)
-                local[slot][:count].copy_(frames)
+                if writes_into:
+                    synthesize_piece(produced, count, local[slot][:count])
+                else:
+                    local[slot][:count].copy_(synthesize_piece(produced, count))
             except Exception as error:  # pylint: disable=broad-except
                 failure = error
             produced += count
@@ -262,8 +271,6 @@ def ordered_device_chunks(synthesize_piece, num_frames: int, frames_per_rank: in
             raise failure
         if world_size > 1:
             works[slot] = dist.gather(local[slot], gather_list=list(gathered[slot].chunk(world_size, dim=0)) if rank == 0 else None, dst=0, async_op=True)
-        elif rank == 0:
-            gathered[slot][:frames_per_rank].copy_(local[slot])
         if reader_stream is not None:
             issued[slot] = torch.cuda.Event()
             issued[slot].record(torch.cuda.current_stream(device))

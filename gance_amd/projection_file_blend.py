@@ -98,9 +98,10 @@ def synthesize_device_frames_network_major(  # pylint: disable=too-many-locals
     networks: MultiNetwork,
     output_side_length: Optional[int] = None,
     batch: int = DEFAULT_MAX_BATCH,
+    out: Optional[torch.Tensor] = None,
 ) -> torch.Tensor:
     """
-    The same frames as `synthesize_device_frames`, as one tensor [n, S, S, 3], computed network by
+    The same frames as `synthesize_device_frames`, as one tensor [n, S, S, 3] (`out`, if given), computed network by
     network: every engine call is a full batch however often the index switches (the reference
     sorts by network for the same reason, network_visualization.py:653-674: there a switch costs a
     process restart, here only a short batch). Frames land at their own positions, so the order of
@@ -111,7 +112,10 @@ def synthesize_device_frames_network_major(  # pylint: disable=too-many-locals
     indices = network_indices if isinstance(network_indices, np.ndarray) else network_indices.cpu().numpy()
     num_frames = int(dlatents.shape[0])
     out_side = _common_output_side(networks, indices, output_side_length)
-    out = torch.empty((num_frames, out_side, out_side, 3), dtype=torch.uint8, device=device)
+    if out is None:
+        out = torch.empty((num_frames, out_side, out_side, 3), dtype=torch.uint8, device=device)
+    elif tuple(out.shape) != (num_frames, out_side, out_side, 3) or out.dtype != torch.uint8 or not out.is_contiguous():
+        raise ValueError(f"`out` must be a contiguous uint8 tensor of shape {(num_frames, out_side, out_side, 3)}")
     for network_index in np.unique(indices):
         engine = networks._network_at(int(network_index)).engine  # pylint: disable=protected-access
         side = engine.resolution
@@ -351,14 +355,21 @@ class _WindowSynthesizer:  # pylint: disable=too-few-public-methods
         self._frames_per_call, self._window = frames_per_call, max(1, window)
         self._start, self._frames = 0, None
 
-    def __call__(self, offset: int, count: int) -> torch.Tensor:
+    writes_into = True  # (frame_sharding.ordered_device_chunks: the frames go straight into the stream's buffer)
+
+    def __call__(self, offset: int, count: int, out: torch.Tensor) -> None:
+        if self._window == 1:  # one network: every engine call writes its frames in place
+            synthesize_device_frames_network_major(
+                self._dlatents[offset : offset + count], self._indices[offset : offset + count], self._networks, self._side, self._frames_per_call, out=out
+            )
+            return
         if self._frames is None or not self._start <= offset < self._start + int(self._frames.shape[0]):
             stop = min(int(self._dlatents.shape[0]), offset + self._window * self._frames_per_call)
             self._start = offset
             self._frames = synthesize_device_frames_network_major(
                 self._dlatents[offset:stop], self._indices[offset:stop], self._networks, self._side, self._frames_per_call
             )
-        return self._frames[offset - self._start : offset - self._start + count]
+        out.copy_(self._frames[offset - self._start : offset - self._start + count])
 
 
 def decided_prefix(gated: List[bool], track_length: int, final: bool) -> int:
