@@ -8,10 +8,12 @@
 // float64 on the host).
 //
 // What it costs on gfx950. The fp32 MFMA runs at the fp32 VECTOR rate and shares the vector ALUs, so the 144 vector
-// instructions of a 6x6 input transform are not hidden beside the 36 MFMAs they feed -- they add their issue time. A
-// wave alone on its SIMD issues a vector instruction every 4 cycles, two waves together every 2: this kernel therefore
-// runs TWO waves per SIMD (8 per block, <= 256 registers each): 36 positions x one 16 x 16 accumulator tile = 144
-// accumulators per wave, 36 MFMAs (1152 cycles) per k-step of four input channels against ~290 cycles of transform.
+// operations of a 6x6 input transform (84 instructions here: packed column pass, eight-instruction row pass) are not hidden
+// beside the 36 MFMAs they feed -- they add their issue time. This kernel runs TWO waves per SIMD (8 per block, <= 256
+// registers each): 36 positions x one 16 x 16 accumulator tile = 144 accumulators per wave, 36 MFMAs (1152 cycles) per
+// k-step of four input channels against ~340 cycles of transform; while one wave waits for LDS, a barrier or the issue
+// of an LDS-DMA piece the other keeps the matrix pipe busy. (One wave per SIMD with 32 channels x 16 tiles does the
+// transform once for two channel tiles, but pays every such wait in full: measured 12 % slower)
 //
 // Geometry. Block = 8 waves = 2 channel tiles of 16 x 4 tile rows; a wave owns 16 channels x one row of sixteen 4x4 output
 // tiles (4 x 64 pixels): the block 32 channels x 16 x 64 pixels. Lane (n = lane % 16, g = lane / 16) transforms the 6x6
