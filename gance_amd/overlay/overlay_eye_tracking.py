@@ -75,6 +75,9 @@ def _as_device_frames(images: Iterable[RGBInt8ImageType]) -> torch.Tensor:
 
 
 _HOST_STAGING: Dict[Tuple[int, Tuple[int, ...]], torch.Tensor] = {}
+# the staging buffers stay allocated (page-locked) for the life of the process: sized for the stream's chunks, not for a
+# whole video handed to the one-shot form
+HOST_STAGING_LIMIT_BYTES = 1 << 30
 
 
 def _copy_to_host_staging(frames: torch.Tensor, slot: int) -> np.ndarray:
@@ -85,6 +88,8 @@ def _copy_to_host_staging(frames: torch.Tensor, slot: int) -> np.ndarray:
     """
     if frames.device.type != "cuda":
         return frames.numpy()
+    if frames.numel() * frames.element_size() > HOST_STAGING_LIMIT_BYTES:
+        return frames.cpu().numpy()
     key = (slot, tuple(frames.shape[1:]))
     staging = _HOST_STAGING.get(key)
     if staging is None or staging.shape[0] < frames.shape[0]:
