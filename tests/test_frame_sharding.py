@@ -108,16 +108,26 @@ def _stream_worker(rank: int, world_size: int, port: int, num_frames: int, per_r
             values = mine[offset : offset + count, 0].to(torch.int64) % 251
             return values.to(torch.uint8).reshape(count, 1, 1, 1).expand(count, 2, 2, 3).contiguous()
 
-        got = []
-        for first, frames in frame_sharding.ordered_frame_stream(synthesize_piece, num_frames, per_rank, (2, 2, 3), device):
-            assert rank == 0
-            assert first == len(got)
-            got.extend(int(frame[0, 0, 0]) for frame in frames)
-            assert all(bool((frame == frame[0, 0, 0]).all()) for frame in frames)
-        if rank == 0:
-            assert got == [f % 251 for f in range(num_frames)]
-        else:
-            assert not got
+        class WritesInto:  # pylint: disable=too-few-public-methods
+            """The product's form: the frames go straight into the stream's chunk buffer."""
+
+            writes_into = True
+
+            def __call__(self, offset: int, count: int, out: torch.Tensor) -> None:
+                assert tuple(out.shape) == (count, 2, 2, 3) and out.dtype == torch.uint8
+                out.copy_(synthesize_piece(offset, count))
+
+        for producer in (synthesize_piece, WritesInto()):
+            got = []
+            for first, frames in frame_sharding.ordered_frame_stream(producer, num_frames, per_rank, (2, 2, 3), device):
+                assert rank == 0
+                assert first == len(got)
+                got.extend(int(frame[0, 0, 0]) for frame in frames)
+                assert all(bool((frame == frame[0, 0, 0]).all()) for frame in frames)
+            if rank == 0:
+                assert got == [f % 251 for f in range(num_frames)]
+            else:
+                assert not got
     finally:
         dist.destroy_process_group()
 
@@ -171,3 +181,20 @@ def test_a_failing_rank_ends_the_stream_on_every_rank(failing_rank: int) -> None
     assert results[failing_rank] == ("own: engine call refused", 2)
     other = 1 - failing_rank
     assert results[other][0].startswith(f"relayed: rank {failing_rank} failed synthesising chunk 1") and results[other][1] == 2
+
+
+@pytest.mark.parametrize("num_frames,per_call", [(37, 4), (8, 4), (3, 4)])
+def test_ordered_frame_stream_without_a_process_group(num_frames: int, per_call: int) -> None:
+    """One rank: the chunk is handed out of the buffer the producer wrote into; every frame arrives once, in order."""
+
+    class Producer:  # pylint: disable=too-few-public-methods
+        writes_into = True
+
+        def __call__(self, offset: int, count: int, out: torch.Tensor) -> None:
+            out.copy_((torch.arange(offset, offset + count) % 251).to(torch.uint8).reshape(count, 1, 1, 1).expand(count, 2, 2, 3))
+
+    got = []
+    for first, frames in frame_sharding.ordered_frame_stream(Producer(), num_frames, per_call, (2, 2, 3), torch.device("cpu")):
+        assert first == len(got)
+        got.extend(int(frame[0, 0, 0]) for frame in frames.copy())
+    assert got == [f % 251 for f in range(num_frames)]
