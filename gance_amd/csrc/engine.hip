@@ -417,6 +417,12 @@ int run_conv(gance_engine* e, const ConvLayerHost& c, int li, const LayerPlan& p
     a.x_b_stride = x_b_stride;
     static const int debug_flags = [] { const char* v = std::getenv("GANCE_DEBUG_CONV"); return v ? std::atoi(v) : 0; }();
     a.debug_flags = debug_flags;
+    // Blocks per CU of the F(4x4,3x3) launches (ConvArgs::grid_rounds). Four: measured as fast as one persistent block per
+    // CU (1234 ... 1236 frames/s with 2 / 4 / 8 / 16 against 1228 with 1: the prologue of a block is a few k-steps of
+    // thousands), and a CU that something else holds for a while -- the RCCL copy kernels of the frame gather on a multi-GPU
+    // job -- then delays a quarter of its share instead of the tail of the launch. GANCE_TUNE_W43_ROUNDS=1: one block per CU.
+    static const int env_rounds = [] { const char* v = std::getenv("GANCE_TUNE_W43_ROUNDS"); return v ? std::atoi(v) : 0; }();
+    a.grid_rounds = env_rounds > 0 ? env_rounds : 4;
     static unsigned long long* stamps = nullptr;
     if (debug_flags & 16) {
         if (stamps == nullptr) hipMalloc((void**)&stamps, (size_t)5 * 8 * 65536);

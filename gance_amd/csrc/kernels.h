@@ -122,6 +122,10 @@ struct ConvArgs {
     // activation is multiplied by it (the fused up kernel then skips the style scale in its K loop)
     const float* s_next;
     const float* rgb_coef;  // kEpilogueFullRgbPart: [B][Cout / 4][64], launch_winograd64_rgb_coef; rgb_y: [Cout / 64 or 1][B][3][OH][OW]
+    // winograd43 kernels: blocks queued per CU (0 or 1: one persistent block per CU; k: k blocks per CU, each with 1/k of
+    // the tiles, handed to the CUs by the hardware dispatcher as they come free -- the hardware is the tile queue: a CU that
+    // something else holds for a while (a copy kernel of a collective) delays 1/k of its share, not the launch's tail)
+    int grid_rounds;
     unsigned long long* debug_stamps;  // [blocks][4] s_memrealtime stamps when debug_flags & 16
     int debug_flags;       // timing ablations only (GANCE_DEBUG_CONV): 1 no stores, 2 no DMA after chunk 0, 4 no MFMA
 };

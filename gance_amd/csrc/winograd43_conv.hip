@@ -619,7 +619,7 @@ hipError_t launch_winograd43_conv(const ConvArgs& args, hipStream_t stream) {
     a.m_tiles = a.Cout / kBM;
     a.total_chunks = a.Cin / kKC;
     a.total_tiles = a.m_tiles * a.tiles_x * a.tiles_y * a.B;
-    hipLaunchKernelGGL(kernel, dim3(std::min(a.total_tiles, resident_blocks)), dim3(512), lds_bytes, stream, a);
+    hipLaunchKernelGGL(kernel, dim3(std::min(a.total_tiles, resident_blocks * std::max(1, a.grid_rounds))), dim3(512), lds_bytes, stream, a);
     return hipGetLastError();
 }
 

@@ -358,7 +358,10 @@ np.savez(sys.argv[2], frames=frames, image=image)
 
 @pytest.mark.parametrize(
     "variable,off_value,up_form",
-    [("GANCE_TUNE_W64_RGB", "0", "auto"), ("GANCE_TUNE_W64_RGB", "0", "fused"), ("GANCE_TUNE_WINO64", "0", "auto"), ("GANCE_TUNE_PRESCALE_UP", "0", "fused")],
+    [
+        ("GANCE_TUNE_W64_RGB", "0", "auto"), ("GANCE_TUNE_W64_RGB", "0", "fused"), ("GANCE_TUNE_WINO64", "0", "auto"), ("GANCE_TUNE_PRESCALE_UP", "0", "fused"),
+        ("GANCE_TUNE_W43_ROUNDS", "1", "fused"),  # one persistent block per CU in the F(4x4,3x3) launches instead of four queued ones: same tiles, other blocks
+    ],
 )
 def test_winograd_kernel_fallback_forms_agree_with_the_default(library, tmp_path, variable: str, off_value: str, up_form: str) -> None:
     """
