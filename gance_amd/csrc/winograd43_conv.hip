@@ -619,7 +619,12 @@ hipError_t launch_winograd43_conv(const ConvArgs& args, hipStream_t stream) {
     a.m_tiles = a.Cout / kBM;
     a.total_chunks = a.Cin / kKC;
     a.total_tiles = a.m_tiles * a.tiles_x * a.tiles_y * a.B;
-    hipLaunchKernelGGL(kernel, dim3(std::min(a.total_tiles, resident_blocks * std::max(1, a.grid_rounds))), dim3(512), lds_bytes, stream, a);
+    // blocks per CU (ConvArgs::grid_rounds), as long as a block's stream stays long beside its ring prologue (about two k-steps):
+    // at least 64 k-steps per block, else fewer, larger blocks (one frame per call: one block per CU as before)
+    int rounds = std::max(1, a.grid_rounds);
+    const int min_tiles = std::max(1, 64 / a.total_chunks);
+    while (rounds > 1 && a.total_tiles < resident_blocks * rounds * min_tiles) --rounds;
+    hipLaunchKernelGGL(kernel, dim3(std::min(a.total_tiles, resident_blocks * rounds)), dim3(512), lds_bytes, stream, a);
     return hipGetLastError();
 }
 

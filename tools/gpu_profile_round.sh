@@ -23,6 +23,8 @@ python3 tools/pmc_summary.py $(find $out/${tag}_pmc_sq -name "*counter_collectio
 cp $(find $out/${tag}_trace -name "*kernel_stats.csv" | head -1) $out/${tag}_kernel_stats.csv
 # the product's blend job (files on disk -> frames on the host): every kernel incl. the audio -> latent ones
 cp $(find $out/${tag}_audio_trace -name "*kernel_stats.csv" | head -1) $out/${tag}_audio_kernel_stats.csv
+# (the record takes the workload and the per-launch table from a bench line: a short one first, the full one after it)
+python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-extras --print-steps > $out/${tag}_bench.json 2> $out/${tag}_steps.txt
 python3 tools/make_traffic_record.py ${tag} $out && cp profiles/traffic_latest.json $out/${tag}_traffic_latest.json
 # the un-profiled default line last: its roofline.traffic then comes from THIS set's record
 python3 bench.py --steps 20 --warmup 3 --print-steps > $out/${tag}_bench.json 2> $out/${tag}_steps.txt
