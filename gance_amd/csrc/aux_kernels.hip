@@ -142,7 +142,8 @@ __global__ __launch_bounds__(256) void styles_kernel(const float* __restrict__ d
     const int cb = blockIdx.x;
     const int row = blk_row[cb];
     const int col = cb * 32 + (threadIdx.x & 31);
-    for (int b0 = 0; b0 < B; b0 += 8) {
+    {  // (a block per group of eight samples, like demod_kernel)
+        const int b0 = blockIdx.y * 8;
         const int nb = min(8, B - b0);
         float r[1];
         int rb;
@@ -155,7 +156,7 @@ __global__ __launch_bounds__(256) void styles_kernel(const float* __restrict__ d
 
 hipError_t launch_styles(const float* dlat, const float* A, const float* bias1, const int* blk_row,
                          float* s, int B, int num_rows, int ctot, hipStream_t stream) {
-    hipLaunchKernelGGL(styles_kernel, dim3(ctot / 32), dim3(256), 0, stream, dlat, A, bias1,
+    hipLaunchKernelGGL(styles_kernel, dim3(ctot / 32, (B + 7) / 8), dim3(256), 0, stream, dlat, A, bias1,
                        blk_row, s, B, num_rows, ctot);
     return hipGetLastError();
 }
@@ -171,7 +172,9 @@ __global__ __launch_bounds__(256) void demod_kernel(const float* __restrict__ s,
     const int co0 = blockIdx.x * 32;
     if (co0 >= L.cout) return;
     const int col = co0 + (threadIdx.x & 31);
-    for (int b0 = 0; b0 < B; b0 += 8) {
+    // (a block per group of eight samples: walked in one block, the eight passes of a 64-frame batch were 97 us of latency)
+    {
+        const int b0 = blockIdx.z * 8;
         const int nb = min(8, B - b0);
         float r[1];
         int rb;
@@ -184,7 +187,7 @@ __global__ __launch_bounds__(256) void demod_kernel(const float* __restrict__ s,
 
 hipError_t launch_demod(const float* s, const float* w2_pool, const DemodLayer* layers,
                         int num_layers, float* d, int B, int ctot, int dtot, hipStream_t stream) {
-    hipLaunchKernelGGL(demod_kernel, dim3(16, num_layers), dim3(256), 0, stream, s, w2_pool,
+    hipLaunchKernelGGL(demod_kernel, dim3(16, num_layers, (B + 7) / 8), dim3(256), 0, stream, s, w2_pool,
                        layers, d, B, ctot, dtot);
     return hipGetLastError();
 }
@@ -395,7 +398,10 @@ __global__ __launch_bounds__(256) void torgb_kernel(const ToRgbArgs p) {
     if (p.partial != nullptr) {  // the conv kernel's epilogue did the channel sum (kEpilogueFullRgbPart)
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-            for (int m = 0; m < p.partials; ++m) {  // (fixed order: reproducible)
+            // (fixed order: reproducible; eight loads in flight: rolled, one load per trip waited for its own latency -- 32
+            // partial images at 32^2 made this pass 50 us of latency)
+#pragma unroll 8
+            for (int m = 0; m < p.partials; ++m) {
                 const float4 v = *reinterpret_cast<const float4*>(p.partial + (((size_t)m * p.B + b) * 3 + c) * npix + p4);
                 acc[c][0] += v.x; acc[c][1] += v.y; acc[c][2] += v.z; acc[c][3] += v.w;
             }
