@@ -1101,7 +1101,7 @@ int gance_engine_create(const gance_engine_config* config, const float* host_wei
         const ConvLayerHost& c = e->convs[i];
         if (!c.up && c.cout > 64 && gance::winograd64_rgb_supported(c.cout))
             e->rgb_part_floats = std::max(e->rgb_part_floats, (size_t)gance::winograd64_rgb_partials(c.cout) * Bmax * 3 << (2 * c.res_log2));
-        // ... and of the F(4x4,3x3) launches: one partial image per 16-channel tile
+        // ... and of the F(4x4,3x3) launches: one partial image per block of 32 channels
         if (e->wino43_w[i] != SIZE_MAX && gance::winograd43_rgb_supported(c.cout))
             e->rgb_part_floats = std::max(e->rgb_part_floats, (size_t)gance::winograd43_rgb_partials(c.cout) * Bmax * 3 << (2 * c.res_log2));
     }

@@ -163,8 +163,8 @@ bool winograd43_supported(int cin, int cout, int H, int W);
 size_t winograd43_weight_floats(int cin, int cout);
 void winograd43_transform_weights(const float* w_in /*[9][cin][cout]*/, int cin, int cout, float* w_out);
 hipError_t launch_winograd43_conv(const ConvArgs& args, hipStream_t stream);
-// kEpilogueFullRgbPart: every 16-channel tile writes its own partial ToRGB image, rgb_y [Cout / 16][B][3][OH][OW]; rgb_coef is
-// launch_winograd64_rgb_coef's table
+// kEpilogueFullRgbPart: every block (32 channels: the two channel-tile waves of a SIMD add their sums through LDS) writes its
+// own partial ToRGB image, rgb_y [Cout / 32][B][3][OH][OW]; rgb_coef is launch_winograd64_rgb_coef's table
 bool winograd43_rgb_supported(int cout);
 int winograd43_rgb_partials(int cout);
 

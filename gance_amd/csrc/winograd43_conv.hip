@@ -16,7 +16,9 @@
 // transform once for two channel tiles, but pays every such wait in full: measured 12 % slower)
 //
 // Geometry. Block = 8 waves = 2 channel tiles of 16 x 4 tile rows; a wave owns 16 channels x one row of sixteen 4x4 output
-// tiles (4 x 64 pixels): the block 32 channels x 16 x 64 pixels. Lane (n = lane % 16, g = lane / 16) transforms the 6x6
+// tiles (4 x 64 pixels): the block 32 channels x 16 x 64 pixels. The two waves of a SIMD take the two channel tiles of the
+// SAME tile row (tile row = SIMD id, channel tile = the wave's ticket on that SIMD): they run the two halves of the pipeline,
+// and the ToRGB sums of the first reach the second through LDS, so a block writes ONE partial ToRGB image. Lane (n = lane % 16, g = lane / 16) transforms the 6x6
 // window of tile n for input channel 4 ks + g; as A operand it holds output channel n of its channel tile for the same
 // input channel. The input arrives ALREADY multiplied by this layer's style (ConvArgs::x contract, as for the
 // 32-channel geometry of winograd64_conv.hip: the producing up layer folds s[b][ci] into its leaky ReLU; V is linear in d).
@@ -84,6 +86,9 @@ constexpr int kNBUF = 3;                       // ring slots: chunk G + 2 is iss
 // noise [16][64] | (RGB) A operands of the ToRGB product [2 channel tiles][4 steps][64 lanes]
 constexpr int kConstD = 0, kConstB = 64, kConstS = 128, kConstNoise = 192, kConstRgb = kConstNoise + 1024, kConstFloats = kConstRgb + 512;
 constexpr int kStoresPerEpilogue = 16, kRgbStores = 12;
+// (RGB) hand-over of a wave's ToRGB sums to the wave that holds the OTHER sixteen channels of the same pixels:
+// [tile row][output row x colour = 12][16 lanes] float4
+constexpr int kRgbXchgFloats = 4 * 12 * 16 * 4;
 
 // B^T of F(4,3), points 0, +-1, +-2 (Lavin & Gray): 12 vector instructions, on one window line or on two at once
 template <typename T>
@@ -151,7 +156,19 @@ __device__ __forceinline__ void winograd43_body(const ConvArgs& p) {
     float* const const0 = smem + kNBUF * kSlot;  // two sets of tile constants (tile parity)
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int cot = wave >> 2, pg = wave & 3;  // channel tile and tile row of this wave
+    // Work of this wave: tile row = the SIMD it runs on, channel tile = its ticket there (two waves of 256 registers fill a
+    // SIMD, so each SIMD holds exactly two of the block's eight). The two waves of a SIMD then hold the two channel tiles of
+    // the SAME pixels and run the two halves of the pipeline (see the stream loop): the ticket is the wave's role as well, and
+    // the hand-over of the ToRGB sums between them (epilogue) needs no atomic: role 0 is always a barrier ahead of role 1.
+    // Which waves share a SIMD is the dispatcher's choice, so the wave asks the hardware (HW_ID.simd_id).
+    __shared__ int simd_tickets[4];
+    if (tid < 4) simd_tickets[tid] = 0;
+    __syncthreads();
+    const int pg = __builtin_amdgcn_s_getreg((1 << 11) | (4 << 6) | 4) & 3;  // hwreg(HW_REG_HW_ID, 4, 2)
+    int ticket = 0;
+    if ((tid & 63) == 0) ticket = atomicAdd(&simd_tickets[pg], 1) & 1;
+    const int cot = __builtin_amdgcn_readfirstlane(ticket);
+    const int role = cot;
     const int Hp = p.H + 2, Wp = p.W + 8;
     const int n = p.total_chunks;               // chunks per tile
     const int my_tiles = (p.total_tiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
@@ -267,14 +284,7 @@ __device__ __forceinline__ void winograd43_body(const ConvArgs& p) {
             __builtin_amdgcn_raw_ptr_buffer_load_lds(st_x_rsrc, (lds_ptr_t)(base + kWFloats + (piece - kWPieces) * 256), 16, piece_voff[r], cur_x, 0, 0);
     };
 
-    // Which half of the pipeline this wave runs (see the stream loop): the two waves that share a SIMD must differ, and which
-    // waves share one is the dispatcher's choice, so the wave asks the hardware (HW_ID.simd_id) and takes a ticket per SIMD.
-    __shared__ int simd_tickets[4];
-    if (tid < 4) simd_tickets[tid] = 0;
-    __syncthreads();
-    int role = 0;
-    if ((tid & 63) == 0) role = atomicAdd(&simd_tickets[__builtin_amdgcn_s_getreg((1 << 11) | (4 << 6) | 4) & 3], 1) & 1;  // hwreg(HW_REG_HW_ID, 4, 2)
-    role = __builtin_amdgcn_readfirstlane(role);
+    float* const rgb_xchg = const0 + 2 * kConstFloats;
 
     f32x4 acc[36];  // (every tile's first k-step overwrites them: multiply(first))
 
@@ -439,15 +449,27 @@ __device__ __forceinline__ void winograd43_body(const ConvArgs& p) {
         }
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (RGB) {
-            // partial image of this 16-channel tile: [Cout / 16][B][3][OH][OW]; lanes 0 .. 15 hold (R, G, B, 0) of their tile's pixels
-            if (g == 0) {
-                float* const y_base = p.rgb_y + (((size_t)ct * p.B + t.b0) * 3) * p.OH * p.OW + (size_t)oy0 * p.OW + ox0;
+            // Partial image of the block's 32 channels: [Cout / 32][B][3][OH][OW]. Lanes 0 .. 15 of a wave hold (R, G, B, 0)
+            // of their tile's pixels for the wave's 16 channels; the other wave of the SIMD holds the other 16 channels of the
+            // same pixels. The role-0 wave (channel tile 0) leaves its sums in LDS: its epilogue ends an interval; the role-1
+            // wave (channel tile 1) runs its epilogue of the same tile behind the next barrier, adds them to its own and stores.
+            f32x4* const xchg = reinterpret_cast<f32x4*>(rgb_xchg) + (pg * 12) * 16 + n16;
+            if (cot == 0) {
+                if (g == 0) {
+#pragma unroll
+                    for (int c = 0; c < 3; ++c)
+#pragma unroll
+                        for (int oy = 0; oy < 4; ++oy) xchg[(c * 4 + oy) * 16] = f32x4{rgbacc[oy][0][c], rgbacc[oy][1][c], rgbacc[oy][2][c], rgbacc[oy][3][c]};
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (in LDS before this wave's next barrier)
+            } else if (g == 0) {
+                float* const y_base = p.rgb_y + (((size_t)t.m_tile * p.B + t.b0) * 3) * p.OH * p.OW + (size_t)oy0 * p.OW + ox0;
 #pragma unroll
                 for (int c = 0; c < 3; ++c)
 #pragma unroll
                     for (int oy = 0; oy < 4; ++oy)
                         *reinterpret_cast<f32x4*>(y_base + ((size_t)c * p.OH + oy) * p.OW) =
-                            f32x4{rgbacc[oy][0][c], rgbacc[oy][1][c], rgbacc[oy][2][c], rgbacc[oy][3][c]};
+                            f32x4{rgbacc[oy][0][c], rgbacc[oy][1][c], rgbacc[oy][2][c], rgbacc[oy][3][c]} + xchg[(c * 4 + oy) * 16];
             }
         }
         lane_setup();
@@ -475,11 +497,13 @@ __device__ __forceinline__ void winograd43_body(const ConvArgs& p) {
     int slot = 0, G = 0;
     // opens interval G: chunk G must have landed; chunk G + 1 (five pieces) may stay in flight, and so may the stores of an
     // epilogue this wave ran in the previous interval (vmcnt counts in issue order: they are younger than chunk G's pieces)
-    auto open_interval = [&](bool stores_behind) {
+    auto open_interval = [&](bool stores_behind, bool rgb_stores = false) {
         if (G + 1 >= total)
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else if (stores_behind && rgb_stores)  // (only the role-1 wave stores the partial ToRGB image)
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kPiecesPerWave + kStoresPerEpilogue + kRgbStores) : "memory");
         else if (stores_behind)
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kPiecesPerWave + kStoresPerEpilogue + (RGB ? kRgbStores : 0)) : "memory");
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kPiecesPerWave + kStoresPerEpilogue) : "memory");
         else
             asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kPiecesPerWave) : "memory");
         if (!(GANCE_W43_ABLATE & 16)) __builtin_amdgcn_s_barrier();
@@ -510,6 +534,7 @@ __device__ __forceinline__ void winograd43_body(const ConvArgs& p) {
             } while (++q < n);
             epilogue(tile);
         } while (++tile < my_tiles);
+        if constexpr (RGB) __builtin_amdgcn_s_barrier();  // the block's last ToRGB sums are in LDS (the role-1 waves wait for this in front of their last epilogue)
     } else {
         open_interval(false);  // interval 0: nothing to multiply yet; this interval's DMA pieces go out in one burst
         if (cur_valid) {
@@ -520,7 +545,7 @@ __device__ __forceinline__ void winograd43_body(const ConvArgs& p) {
         close_interval();
         int tile = 0;
         do {
-            open_interval(tile > 0);
+            open_interval(tile > 0, RGB);
             multiply(std::true_type{});  // chunk 0 of the tile
             __builtin_amdgcn_sched_barrier(0);
             load_transform(slot);
@@ -536,10 +561,12 @@ __device__ __forceinline__ void winograd43_body(const ConvArgs& p) {
             // the tile's last chunk: multiplied in the first interval of the next tile (if there is one), then the epilogue,
             // then that interval's own load + transform
             const bool more = tile + 1 < my_tiles;
-            if (more)
+            if (more) {
                 open_interval(false);
-            else
+            } else {
                 cur_valid = false;
+                if constexpr (RGB) __builtin_amdgcn_s_barrier();
+            }
             multiply(std::false_type{});
             __builtin_amdgcn_sched_barrier(0);
             epilogue(tile);
@@ -566,7 +593,7 @@ bool winograd43_supported(int cin, int cout, int H, int W) {
 size_t winograd43_weight_floats(int cin, int cout) { return (size_t)(cout / kBM) * (cin / kKC) * kWFloats; }
 
 bool winograd43_rgb_supported(int cout) { return winograd64_rgb_supported(cout); }  // (shares launch_winograd64_rgb_coef's table: Cout = 32 or a multiple of 64)
-int winograd43_rgb_partials(int cout) { return cout / 16; }
+int winograd43_rgb_partials(int cout) { return cout / kBM; }
 
 // w_in: the layer's runtime-scaled weights [tap = ky*3+kx][ci][co]; w_out: [m tile of 32][chunk of 4][channel tile][ci][co % 16][36],
 // position j * 6 + i = (G g G^T)[i][j], i along y
@@ -599,7 +626,7 @@ hipError_t launch_winograd43_conv(const ConvArgs& args, hipStream_t stream) {
     const bool narrow = args.W % 64 != 0;  // the 32 x 32 pixel geometry
     void (*const kernel)(const ConvArgs) = narrow ? (rgb ? winograd43_w32_rgb_kernel : winograd43_w32_kernel) : (rgb ? winograd43_rgb_kernel : winograd43_kernel);
     const int tw = narrow ? 32 : 64, th = 1024 / tw;
-    const size_t lds_bytes = sizeof(float) * ((size_t)kNBUF * (narrow ? Geo43<32>::kSlot : Geo43<64>::kSlot) + 2 * kConstFloats);
+    const size_t lds_bytes = sizeof(float) * ((size_t)kNBUF * (narrow ? Geo43<32>::kSlot : Geo43<64>::kSlot) + 2 * kConstFloats + (rgb ? kRgbXchgFloats : 0));
     static PerDeviceInt resident[4];  // per device: the dynamic-LDS opt-in and the launch size = one block per CU, a multiple of 8 (XCDs)
     int resident_blocks = 0;
     hipError_t e = resident[(narrow ? 2 : 0) + (rgb ? 1 : 0)].get(
