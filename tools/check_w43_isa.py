@@ -1,5 +1,6 @@
 """Compile winograd43_conv.hip to ISA (no GPU needed) and check what its speed depends on: no scratch (a spill reload is a
-vector-memory load: the wait behind it drains the LDS-DMA ring), two waves per SIMD (<= 256 registers), no 64-bit register
+vector-memory load: the wait behind it drains the LDS-DMA ring), exactly two waves per SIMD (171 ... 256 registers: the kernel
+derives a wave's work from its SIMD and its ticket there), no 64-bit register
 moves in the blocks that hold MFMAs (accumulator copies through phi nodes)."""
 import re, subprocess, sys, tempfile
 from pathlib import Path
@@ -29,6 +30,7 @@ for name in ("winograd43_kernel", "winograd43_rgb_kernel", "winograd43_w32_kerne
     moves = sum(sum(i.startswith("v_mov_b64") for i in b) for b in mfma_blocks)
     mfmas = sum(sum(i.startswith("v_mfma") for i in b) for b in blocks)
     print(f"{name:24s} VGPRs {vgprs:3d} scratch {scratch:4d} B, MFMAs {mfmas} (36 per k-step copy), 64-bit moves beside MFMAs: {moves}")
-    if vgprs > 256 or scratch != 0 or mfmas < 72 or moves > 8:
+    # (> 170 registers: a third wave must not fit on a SIMD -- the kernel takes a wave's tile row from the SIMD it runs on)
+    if vgprs > 256 or vgprs <= 170 or scratch != 0 or mfmas < 72 or moves > 8:
         bad = True
 sys.exit(1 if bad else 0)
