@@ -297,7 +297,7 @@ __global__ __launch_bounds__(256) void fir_epilogue_kernel(const FirArgs p) {
         for (int i = 0; i < 8; ++i)
             r[i] = 0.25f * hrow[k][i] + 0.75f * hrow[k + 1][i] + 0.75f * hrow[k + 2][i] + 0.25f * hrow[k + 3][i];
         if (p.noise != nullptr) {
-            const float* nz = p.noise + (size_t)(2 * Y + k) * OW + 2 * X;
+            const float* nz = p.noise + (size_t)b * p.noise_b_stride + (size_t)(2 * Y + k) * OW + 2 * X;
 #pragma unroll
             for (int i = 0; i < 8; ++i) r[i] += nz[i] * p.noise_strength;
         }
@@ -328,7 +328,7 @@ hipError_t launch_fir_epilogue(const FirArgs& args, hipStream_t stream) {
 __global__ __launch_bounds__(256) void splitk_finish_kernel(const float* __restrict__ slabs,
                                                             long long slab_stride, int nsplit,
                                                             const float* __restrict__ noise,
-                                                            float noise_strength,
+                                                            float noise_strength, int noise_b_stride,
                                                             const float* __restrict__ bias,
                                                             float* __restrict__ out, int C, int H,
                                                             int W, size_t total) {
@@ -350,16 +350,16 @@ __global__ __launch_bounds__(256) void splitk_finish_kernel(const float* __restr
     const int y = (int)((i / W) % H);
     const size_t bc = i / ((size_t)W * H);
     const int c = (int)(bc % C);
-    if (noise != nullptr) v += noise[(size_t)y * W + x] * noise_strength;
+    if (noise != nullptr) v += noise[(bc / C) * (size_t)noise_b_stride + (size_t)y * W + x] * noise_strength;
     out[(bc * (H + 2) + y + 1) * (size_t)(W + 8) + x + 4] = lrelu_gain(v + bias[c]);
 }
 
 hipError_t launch_splitk_finish(const float* slabs, long long slab_stride, int nsplit,
-                                const float* noise, float noise_strength, const float* bias,
+                                const float* noise, float noise_strength, int noise_b_stride, const float* bias,
                                 float* out, int B, int C, int H, int W, hipStream_t stream) {
     const size_t total = (size_t)B * C * H * W;
     hipLaunchKernelGGL(splitk_finish_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
-                       stream, slabs, slab_stride, nsplit, noise, noise_strength, bias, out, C, H,
+                       stream, slabs, slab_stride, nsplit, noise, noise_strength, noise_b_stride, bias, out, C, H,
                        W, total);
     return hipGetLastError();
 }
@@ -676,23 +676,31 @@ __device__ __forceinline__ unsigned long long splitmix64(unsigned long long x) {
     x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
     return x ^ (x >> 31);
 }
-__global__ void normal_noise_kernel(float* __restrict__ out, size_t count, unsigned long long seed, unsigned long long stream_id) {
+// One plane of `plane` floats per sample: sample b of the launch has the id sample_ids[b] (or first_sample + b), and its
+// draws are a function of (seed, layer, id, index) only: a frame's noise does not depend on how the frames were batched.
+__global__ void normal_noise_kernel(float* __restrict__ out, size_t plane, unsigned long long seed, unsigned long long layer,
+                                    unsigned long long first_sample, const long long* __restrict__ sample_ids) {
     const size_t pair = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (2 * pair >= count) return;
-    const unsigned long long bits = splitmix64(splitmix64(seed ^ (stream_id * 0xD1B54A32D192ED03ull)) + pair);
+    if (2 * pair >= plane) return;
+    const unsigned long long id = sample_ids != nullptr ? (unsigned long long)sample_ids[blockIdx.y] : first_sample + blockIdx.y;
+    const unsigned long long key = splitmix64(splitmix64(seed ^ (layer * 0xD1B54A32D192ED03ull)) ^ (id * 0x9FB21C651E98DF25ull));
+    const unsigned long long bits = splitmix64(key + pair);
     const float u1 = ((float)(unsigned)(bits >> 40) + 1.0f) * (1.0f / 16777216.0f);  // (0, 1]
     const float u2 = (float)(unsigned)((bits >> 8) & 0xFFFFFFu) * (1.0f / 16777216.0f);  // [0, 1)
     const float radius = sqrtf(-2.0f * logf(u1));
     float sn, cs;
     sincosf(6.283185307179586f * u2, &sn, &cs);
-    out[2 * pair] = radius * cs;
-    if (2 * pair + 1 < count) out[2 * pair + 1] = radius * sn;
+    float* const dst = out + (size_t)blockIdx.y * plane;
+    dst[2 * pair] = radius * cs;
+    if (2 * pair + 1 < plane) dst[2 * pair + 1] = radius * sn;
 }
 
-hipError_t launch_normal_noise(float* out, size_t count, unsigned long long seed, unsigned long long stream_id, hipStream_t stream) {
-    if (count == 0) return hipSuccess;
-    const size_t pairs = (count + 1) / 2;
-    hipLaunchKernelGGL(normal_noise_kernel, dim3((unsigned)((pairs + 255) / 256)), dim3(256), 0, stream, out, count, seed, stream_id);
+hipError_t launch_normal_noise(float* out, size_t plane, int samples, unsigned long long seed, unsigned long long layer,
+                               unsigned long long first_sample, const long long* sample_ids, hipStream_t stream) {
+    if (plane == 0 || samples <= 0) return hipSuccess;
+    const size_t pairs = (plane + 1) / 2;
+    hipLaunchKernelGGL(normal_noise_kernel, dim3((unsigned)((pairs + 255) / 256), (unsigned)samples), dim3(256), 0, stream, out, plane, seed, layer,
+                       first_sample, sample_ids);
     return hipGetLastError();
 }
 

@@ -570,7 +570,7 @@ __global__ __launch_bounds__(256, UP ? ((RT && KC >= 4) || (!RT && BM > 64) ? 2 
                 const int ox = x0 + (RT ? (n & ((1 << tw_log2) - 1)) : n % TW);
                 nzv[j] = 0.f;
                 if (kFull && p.noise != nullptr && b0 + tb < p.B && oy < p.OH && ox < p.OW)
-                    nzv[j] = p.noise[(size_t)oy * p.OW + ox];
+                    nzv[j] = p.noise[(size_t)(b0 + tb) * p.noise_b_stride + (size_t)oy * p.OW + ox];
             }
 #pragma unroll
             for (int i = 0; i < MT; ++i) {
@@ -635,7 +635,7 @@ __global__ __launch_bounds__(256, UP ? ((RT && KC >= 4) || (!RT && BM > 64) ? 2 
                 const int oy = y0 + (n / TW) % TH;
                 const int ox = x0 + n % TW;
                 const bool ok = b0 < p.B && oy < p.OH && ox < p.OW;
-                nzv[j] = (p.noise != nullptr && ok) ? p.noise[(size_t)oy * p.OW + ox] : 0.f;
+                nzv[j] = (p.noise != nullptr && ok) ? p.noise[(size_t)b0 * p.noise_b_stride + (size_t)oy * p.OW + ox] : 0.f;
                 const int ya = (oy & 1) ? (oy >> 1) : (oy >> 1) - 1;
                 const int row = ya + lh;
                 const float wrow = ((oy & 1) != 0) == (lh == 0) ? 0.75f : 0.25f;  // (odd: .75, .25) (even: .25, .75)

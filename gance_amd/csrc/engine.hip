@@ -216,12 +216,14 @@ struct gance_workspace {
     size_t bytes = 0;
     // host-buffer entry points: their own stream and pinned staging (latents in, uint8 frames out)
     hipStream_t host_stream = nullptr;
+    int* fault_flag = nullptr;  // host-mapped word: kernels whose wave-placement assumption failed at run time set it (ConvArgs::fault_flag)
     float* pinned_in = nullptr;
     uint8_t* pinned_out = nullptr;
     ~gance_workspace() {
         gance::DeviceGuard guard(device);
         if (host_stream) hipStreamDestroy(host_stream);
         if (pinned_in) hipHostFree(pinned_in);
+        if (fault_flag) hipHostFree(fault_flag);
         if (pinned_out) hipHostFree(pinned_out);
         hipFree(dlat);
         hipFree(map_a);
@@ -265,7 +267,12 @@ struct gance_engine {
     std::vector<size_t> conv_w, conv_bias, conv_noise;
     std::vector<size_t> wino_w;  // Winograd-domain weights of the stride-1 layers that support them (else SIZE_MAX)
     std::vector<size_t> wino64_w;  // the same for the 64-channel Winograd kernel (layers with >= 64 output channels)
-    float* noise_backup = nullptr;  // the stored noise buffers, saved by the first gance_engine_randomize_noise (layer by layer, packed)
+    // randomize_noise (the vector path): per-sample planes drawn by gance_engine_randomize_noise, layer li at
+    // noise_rand + noise_rand_off[li] as [max_batch][res][res] (SIZE_MAX: the layer's strength is zero, it reads no noise);
+    // while noise_randomized the conv launches read these (a plane per sample), else the stored buffers in the pool
+    float* noise_rand = nullptr;
+    std::vector<size_t> noise_rand_off;
+    int noise_rand_count = 0;  // samples the last draw covered
     bool noise_randomized = false;
     std::vector<size_t> wino43_w;  // F(4x4, 3x3) weights (winograd43_conv.hip), SIZE_MAX where the layer does not take that form
     std::vector<size_t> upfir_w;  // fused transposed-conv + FIR kernel's weight image of the up layers that support it (else SIZE_MAX)
@@ -280,8 +287,8 @@ struct gance_engine {
 
     // workspace (shared with the other engines of the same device, resolution and max_batch)
     std::shared_ptr<gance_workspace> ws;
-    // captured launch sequences of the host-buffer entry points, by (batch, entry kind, psi bits, float image wanted)
-    std::map<std::tuple<int, int, unsigned, int>, GraphEntry> graphs;
+    // captured launch sequences of the host-buffer entry points, by (batch, entry kind, psi bits, float image wanted, noise source)
+    std::map<std::tuple<int, int, unsigned, int, int>, GraphEntry> graphs;
     std::vector<int> t_units;     // max_units of each up layer's parity planes
     size_t slab_floats = 0, y_floats = 0, rgb_part_floats = 0;
 
@@ -305,7 +312,7 @@ void free_engine(gance_engine* e) {
         hipEventDestroy(s.stop);
     }
     hipFree(e->pool);
-    hipFree(e->noise_backup);
+    hipFree(e->noise_rand);
     hipFree(e->blk_row);
     hipFree(e->demod_layers);
     if (e->ws && e->ws->used) hipEventSynchronize(e->ws->last_use);  // nothing of this engine still runs on the shared scratch
@@ -361,6 +368,19 @@ static int wino43_max_res(int flags) {
     return env_value >= 0 ? env_value : kWino43DefaultMaxRes;
 }
 
+// The noise conv layer li adds, and the distance between the planes of two samples: the stored buffer [res][res] shared by
+// the batch (stride 0), or after gance_engine_randomize_noise the drawn planes [sample][res][res]; nullptr where the
+// layer's strength is zero.
+const float* layer_noise(const gance_engine* e, int li, int* b_stride) {
+    *b_stride = 0;
+    if (e->conv_ns[li] == 0.0f) return nullptr;
+    if (e->noise_randomized && e->noise_rand != nullptr && e->noise_rand_off[li] != SIZE_MAX) {
+        *b_stride = 1 << (2 * e->convs[li].res_log2);
+        return e->noise_rand + e->noise_rand_off[li];
+    }
+    return e->pool + e->conv_noise[li];
+}
+
 int run_conv(gance_engine* e, const ConvLayerHost& c, int li, const LayerPlan& p, const float* x,
              long long x_b_stride, int H, int W, float* out, int epilogue, int out_row_stride,
              int out_y_off, int out_x_off, long long out_b_stride, long long out_c_stride,
@@ -384,8 +404,7 @@ int run_conv(gance_engine* e, const ConvLayerHost& c, int li, const LayerPlan& p
     a.w = e->pool + e->conv_w[li];
     a.s = e->ws->styles + e->conv_s_off[li];
     a.d = e->ws->demod + e->conv_d_off[li];
-    const bool has_noise = e->conv_ns[li] != 0.0f;
-    a.noise = has_noise ? e->pool + e->conv_noise[li] : nullptr;
+    a.noise = layer_noise(e, li, &a.noise_b_stride);
     a.bias = e->pool + e->conv_bias[li];
     a.out = out;
     a.B = B;
@@ -423,6 +442,7 @@ int run_conv(gance_engine* e, const ConvLayerHost& c, int li, const LayerPlan& p
     // job -- then delays a quarter of its share instead of the tail of the launch. GANCE_TUNE_W43_ROUNDS=1: one block per CU.
     static const int env_rounds = [] { const char* v = std::getenv("GANCE_TUNE_W43_ROUNDS"); return v ? std::atoi(v) : 0; }();
     a.grid_rounds = env_rounds > 0 ? env_rounds : 4;
+    a.fault_flag = e->ws->fault_flag;
     static unsigned long long* stamps = nullptr;
     if (debug_flags & 16) {
         if (stamps == nullptr) hipMalloc((void**)&stamps, (size_t)5 * 8 * 65536);
@@ -583,8 +603,8 @@ int synthesize_from_dlat(gance_engine* e, const float* d_dlat, int B, uint8_t* d
         float* x_out = e->ws->act[li];
         const long long out_c = (long long)act_plane(res);
         const long long out_b = out_c * c.cout;
-        const bool has_noise = e->conv_ns[li] != 0.0f;
-        const float* noise = has_noise ? e->pool + e->conv_noise[li] : nullptr;
+        int noise_b_stride = 0;
+        const float* noise = layer_noise(e, li, &noise_b_stride);
         const float* bias = e->pool + e->conv_bias[li];
         bool rgb_part = false;  // this layer's conv launch also did the channel sum of its ToRGB
         int rgb_partials = 1;   // ... in this many partial images (one per channel tile of a pixel)
@@ -647,7 +667,7 @@ int synthesize_from_dlat(gance_engine* e, const float* d_dlat, int B, uint8_t* d
                 std::snprintf(name, sizeof(name), "finish%d_%dx%d", c.layer_idx, res, res);
                 StepScope scope(e, stream, name, 0.0, 4.0 * (double)slab * (p.nsplit + 1));
                 GANCE_HIP_CHECK(gance::launch_splitk_finish(e->ws->slabs, slab, p.nsplit, noise,
-                                                            e->conv_ns[li], bias, x_out, B, c.cout,
+                                                            e->conv_ns[li], noise_b_stride, bias, x_out, B, c.cout,
                                                             res, res, stream));
             }
         } else {
@@ -678,6 +698,7 @@ int synthesize_from_dlat(gance_engine* e, const float* d_dlat, int B, uint8_t* d
                     u.s_stride = e->ctot;
                     u.d_stride = e->dtot;
                     u.noise_strength = e->conv_ns[li];
+                    u.noise_b_stride = noise_b_stride;
                     u.x_b_stride = x_b_stride;
                     u.s_next = s_next;
                     u.input_prescaled = input_prescaled ? 1 : 0;
@@ -714,6 +735,7 @@ int synthesize_from_dlat(gance_engine* e, const float* d_dlat, int B, uint8_t* d
             f.bias = bias;
             f.out = x_out;
             f.noise_strength = e->conv_ns[li];
+            f.noise_b_stride = noise_b_stride;
             f.B = B;
             f.C = c.cout;
             f.H = H;
@@ -825,12 +847,14 @@ int acquire_workspace(gance_engine* e) {
          alloc((void**)&ws->rgb_part, std::max<size_t>(1, e->rgb_part_floats) * sizeof(float), false) && alloc((void**)&ws->u8buf, e->y_floats, false);
     if (ok && (hipEventCreateWithFlags(&ws->last_use, hipEventDisableTiming) != hipSuccess ||
                hipStreamCreateWithFlags(&ws->host_stream, hipStreamNonBlocking) != hipSuccess ||
+               hipHostMalloc((void**)&ws->fault_flag, sizeof(int), hipHostMallocMapped) != hipSuccess ||
                hipHostMalloc((void**)&ws->pinned_in, (size_t)Bmax * e->num_rows * kDlatent * sizeof(float), hipHostMallocDefault) != hipSuccess ||
                hipHostMalloc((void**)&ws->pinned_out, e->y_floats, hipHostMallocDefault) != hipSuccess)) {
         fail(GANCE_ERR_HIP, "stream / event / pinned staging creation failed");
         ok = false;
     }
     if (!ok) return GANCE_ERR_OUT_OF_MEMORY;  // (the partial workspace frees itself; the message is already recorded)
+    *ws->fault_flag = 0;
     if (shared) g_workspaces[key] = ws;
     e->ws = ws;
     return GANCE_OK;
@@ -856,6 +880,15 @@ int check_call(gance_engine* e, const void* in, int batch) {
         return fail(GANCE_ERR_INVALID_ARGUMENT,
                     "batch " + std::to_string(batch) + " outside [1, max_batch=" +
                         std::to_string(e->cfg.max_batch) + "]");
+    if (e->ws && e->ws->fault_flag != nullptr && *(volatile int*)e->ws->fault_flag != 0) {
+        // (sticky: the frames of the call that raised it, and of any call queued behind it, are invalid)
+        return fail(GANCE_ERR_HIP, "a two-waves-per-SIMD kernel (code " + std::to_string(*(volatile int*)e->ws->fault_flag) +
+                                       ") found its waves placed otherwise than its roles assume: frames since the previous successful call are "
+                                       "invalid; rebuild libgance_hip.so with tools/check_w43_isa.py passing, or run with conv_form=\"winograd\"");
+    }
+    if (e->noise_randomized && e->noise_rand != nullptr && batch > e->noise_rand_count)
+        return fail(GANCE_ERR_INVALID_ARGUMENT, "gance_engine_randomize_noise drew noise for " + std::to_string(e->noise_rand_count) +
+                                                    " samples, this call has " + std::to_string(batch));
     return GANCE_OK;
 }
 
@@ -1101,8 +1134,11 @@ int gance_engine_create(const gance_engine_config* config, const float* host_wei
         const ConvLayerHost& c = e->convs[i];
         if (!c.up && c.cout > 64 && gance::winograd64_rgb_supported(c.cout))
             e->rgb_part_floats = std::max(e->rgb_part_floats, (size_t)gance::winograd64_rgb_partials(c.cout) * Bmax * 3 << (2 * c.res_log2));
-        // ... and of the F(4x4,3x3) launches: one partial image per block of 32 channels
-        if (e->wino43_w[i] != SIZE_MAX && gance::winograd43_rgb_supported(c.cout))
+        // ... and of the F(4x4,3x3) launches: one partial image per block of 32 channels. Whatever THIS engine's flags say
+        // about that form: the buffer belongs to the workspace, which every engine of the (device, resolution, max_batch)
+        // shares -- an engine that never runs the form may be the one that allocates it for one that does.
+        if (!c.up && i > 0 && e->convs[i - 1].up && (1 << c.res_log2) >= 32 &&
+            gance::winograd43_supported(c.cin, c.cout, 1 << c.res_log2, 1 << c.res_log2) && gance::winograd43_rgb_supported(c.cout))
             e->rgb_part_floats = std::max(e->rgb_part_floats, (size_t)gance::winograd43_rgb_partials(c.cout) * Bmax * 3 << (2 * c.res_log2));
     }
 
@@ -1222,7 +1258,7 @@ static int host_call(gance_engine* e, const float* h_in, size_t in_floats, int b
     } else {
         unsigned psi_bits = 0;
         std::memcpy(&psi_bits, &psi, sizeof(psi_bits));
-        const auto key = std::make_tuple(batch, is_z ? 1 : 0, is_z ? psi_bits : 0u, h_f32 != nullptr ? 1 : 0);
+        const auto key = std::make_tuple(batch, is_z ? 1 : 0, is_z ? psi_bits : 0u, h_f32 != nullptr ? 1 : 0, e->noise_randomized ? 1 : 0);
         GraphEntry& entry = e->graphs[key];
         if (entry.disabled) {
             rc = run();
@@ -1260,6 +1296,7 @@ static int host_call(gance_engine* e, const float* h_in, size_t in_floats, int b
     hipEventRecord(ws->last_use, hs);
     ws->used = true;
     GANCE_HIP_CHECK(hipStreamSynchronize(hs));
+    if (int rc_fault = check_call(e, h_in, batch)) return rc_fault;  // (a kernel of this very call may have raised the workspace's fault flag)
     if (h_u8) std::memcpy(h_u8, ws->pinned_out, px * batch);
     if (h_f32) {
         // the final skip image is in whichever ybuf the last ToRGB wrote
@@ -1309,27 +1346,39 @@ int gance_engine_step_info(gance_engine* engine, int32_t index, char* name64, fl
     return GANCE_OK;
 }
 
-int gance_engine_randomize_noise(gance_engine* e, uint64_t seed, void* stream_) {
+int gance_engine_randomize_noise(gance_engine* e, uint64_t seed, int32_t count, uint64_t first_sample, const int64_t* d_sample_ids, void* stream_) {
     if (e == nullptr) return fail(GANCE_ERR_INVALID_ARGUMENT, "engine is NULL");
+    if (count == 0) count = e->cfg.max_batch;
+    if (count < 1 || count > e->cfg.max_batch)
+        return fail(GANCE_ERR_INVALID_ARGUMENT, "count " + std::to_string(count) + " outside [1, max_batch=" + std::to_string(e->cfg.max_batch) + "]");
     gance::DeviceGuard guard(e->cfg.device);
     GANCE_HIP_CHECK(guard.status());
     hipStream_t stream = (hipStream_t)stream_;
     const int nconv = (int)e->convs.size();
-    size_t total = 0;
-    for (int i = 0; i < nconv; ++i) total += (size_t)1 << (2 * e->convs[i].res_log2);
-    if (e->noise_backup == nullptr) {  // keep the stored buffers: gance_engine_restore_noise puts them back
-        GANCE_HIP_CHECK(hipMalloc((void**)&e->noise_backup, total * sizeof(float)));
-        size_t at = 0;
+    if (e->noise_rand_off.empty()) {  // planes for max_batch samples of every layer that reads noise (none at random init)
+        size_t total = 0;
+        e->noise_rand_off.assign(nconv, SIZE_MAX);
         for (int i = 0; i < nconv; ++i) {
-            const size_t n = (size_t)1 << (2 * e->convs[i].res_log2);
-            GANCE_HIP_CHECK(hipMemcpyAsync(e->noise_backup + at, e->pool + e->conv_noise[i], n * sizeof(float), hipMemcpyDeviceToDevice, stream));
-            at += n;
+            if (e->conv_ns[i] == 0.0f) continue;
+            e->noise_rand_off[i] = total;
+            total += ((size_t)e->cfg.max_batch << (2 * e->convs[i].res_log2));
+        }
+        if (total > 0) {
+            const hipError_t err = hipMalloc((void**)&e->noise_rand, total * sizeof(float));
+            if (err != hipSuccess) {
+                e->noise_rand_off.clear();
+                return fail(err == hipErrorOutOfMemory ? GANCE_ERR_OUT_OF_MEMORY : GANCE_ERR_HIP, std::string("noise planes: ") + hipGetErrorString(err));
+            }
         }
     }
+    // (the planes may still be read by a call in flight on another stream of the shared workspace: order behind it)
+    if (e->ws && e->ws->used) GANCE_HIP_CHECK(hipStreamWaitEvent(stream, e->ws->last_use, 0));
     for (int i = 0; i < nconv; ++i) {
-        if (e->conv_ns[i] == 0.0f) continue;  // (a layer whose strength is zero never reads its noise)
-        GANCE_HIP_CHECK(gance::launch_normal_noise(e->pool + e->conv_noise[i], (size_t)1 << (2 * e->convs[i].res_log2), seed, (unsigned long long)i, stream));
+        if (e->noise_rand_off[i] == SIZE_MAX) continue;  // (a layer whose strength is zero never reads its noise)
+        GANCE_HIP_CHECK(gance::launch_normal_noise(e->noise_rand + e->noise_rand_off[i], (size_t)1 << (2 * e->convs[i].res_log2), count, seed,
+                                                   (unsigned long long)i, first_sample, (const long long*)d_sample_ids, stream));
     }
+    e->noise_rand_count = count;
     e->noise_randomized = true;
     if (stream == nullptr) GANCE_HIP_CHECK(hipStreamSynchronize(nullptr));  // (the host-buffer entries run on a private stream)
     return GANCE_OK;
@@ -1337,29 +1386,23 @@ int gance_engine_randomize_noise(gance_engine* e, uint64_t seed, void* stream_) 
 
 int gance_engine_restore_noise(gance_engine* e, void* stream_) {
     if (e == nullptr) return fail(GANCE_ERR_INVALID_ARGUMENT, "engine is NULL");
-    if (!e->noise_randomized || e->noise_backup == nullptr) return GANCE_OK;
-    gance::DeviceGuard guard(e->cfg.device);
-    GANCE_HIP_CHECK(guard.status());
-    size_t at = 0;
-    for (size_t i = 0; i < e->convs.size(); ++i) {
-        const size_t n = (size_t)1 << (2 * e->convs[i].res_log2);
-        GANCE_HIP_CHECK(hipMemcpyAsync(e->pool + e->conv_noise[i], e->noise_backup + at, n * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream_));
-        at += n;
-    }
+    (void)stream_;  // (nothing to copy: the stored buffers were never overwritten, the launches go back to reading them)
     e->noise_randomized = false;
-    if (stream_ == nullptr) GANCE_HIP_CHECK(hipStreamSynchronize(nullptr));
     return GANCE_OK;
 }
 
-int gance_engine_debug_read_noise(gance_engine* e, int32_t conv_layer, float* h_out, uint64_t count) {
-    if (e == nullptr || h_out == nullptr || conv_layer < 0 || conv_layer >= (int)e->convs.size())
+int gance_engine_debug_read_noise(gance_engine* e, int32_t conv_layer, int32_t sample, float* h_out, uint64_t count) {
+    if (e == nullptr || h_out == nullptr || conv_layer < 0 || conv_layer >= (int)e->convs.size() || sample < 0 || sample >= e->cfg.max_batch)
         return fail(GANCE_ERR_INVALID_ARGUMENT, "bad argument to gance_engine_debug_read_noise");
     const uint64_t n = (uint64_t)1 << (2 * e->convs[conv_layer].res_log2);
     if (count != n) return fail(GANCE_ERR_INVALID_ARGUMENT, "the layer's noise buffer holds " + std::to_string(n) + " floats");
     gance::DeviceGuard guard(e->cfg.device);
     GANCE_HIP_CHECK(guard.status());
     GANCE_HIP_CHECK(hipDeviceSynchronize());
-    GANCE_HIP_CHECK(hipMemcpy(h_out, e->pool + e->conv_noise[conv_layer], n * sizeof(float), hipMemcpyDeviceToHost));
+    int b_stride = 0;
+    const float* src = layer_noise(e, conv_layer, &b_stride);
+    if (src == nullptr) src = e->pool + e->conv_noise[conv_layer];  // (strength zero: the stored buffer, which no launch reads)
+    GANCE_HIP_CHECK(hipMemcpy(h_out, src + (size_t)sample * b_stride, n * sizeof(float), hipMemcpyDeviceToHost));
     return GANCE_OK;
 }
 

@@ -90,7 +90,7 @@ struct ConvArgs {
     const float* w;      // pre-arranged [m tile][K chunk][tap slot 0..8][KC][BM], runtime-scaled
     const float* s;      // style: s[b * s_stride + ci]
     const float* d;      // demodulation: d[b * d_stride + co]
-    const float* noise;  // [OH][OW] or nullptr (full epilogue only)
+    const float* noise;  // [OH][OW] or nullptr (full epilogue only); sample b reads noise + b * noise_b_stride
     const float* bias;   // [Cout]
     // out[split*slab_stride + cls*cls_stride + b*out_b_stride + co*out_c_stride
     //     + (oy+out_y_off)*out_row_stride + ox + out_x_off]
@@ -99,6 +99,9 @@ struct ConvArgs {
     int OH, OW;              // output grid: H x W for a conv, (H+1) x (W+1) positions when up
     int s_stride, d_stride;
     float noise_strength;
+    int noise_b_stride;  // floats between the noise planes of two samples: 0 = one stored plane for the whole batch
+                         // (randomize_noise=False), OH * OW = a plane per sample (gance_engine_randomize_noise: upstream
+                         // draws tf.random_normal([N, 1, H, W]))
     int tiles_x, tiles_y, m_tiles;
     int total_tiles;  // virtual blocks of the launch (set by launch_modconv; a persistent grid is smaller)
     // runtime-geometry launches (transposed conv, BM = 128): after the tiles_x*tiles_y main tiles
@@ -126,6 +129,9 @@ struct ConvArgs {
     // the tiles, handed to the CUs by the hardware dispatcher as they come free -- the hardware is the tile queue: a CU that
     // something else holds for a while (a copy kernel of a collective) delays 1/k of its share, not the launch's tail)
     int grid_rounds;
+    // winograd43 kernels: host-visible word a block sets (to 43) when its SIMDs did not each get exactly two of its waves
+    // (the pairing the kernel's roles rest on); the launch's output is then invalid and the engine says so on its next call
+    int* fault_flag;
     unsigned long long* debug_stamps;  // [blocks][4] s_memrealtime stamps when debug_flags & 16
     int debug_flags;       // timing ablations only (GANCE_DEBUG_CONV): 1 no stores, 2 no DMA after chunk 0, 4 no MFMA
 };
@@ -175,12 +181,13 @@ struct UpFirArgs {
     const float* w;      // [m tile of 32][chunk of 4][tap slot 0..8][4][32], runtime-scaled
     const float* s;      // style: s[b * s_stride + ci]
     const float* d;      // demodulation: d[b * d_stride + co]
-    const float* noise;  // [2H][2W] or nullptr
+    const float* noise;  // [2H][2W] or nullptr; sample b reads noise + b * noise_b_stride
     const float* bias;   // [Cout]
     float* out;          // zero-bordered [B][Cout][2H+2][2W+8]
     int B, Cin, Cout, H, W;
     int s_stride, d_stride;
     float noise_strength;
+    int noise_b_stride;  // 0 (one plane for the batch) or 4 H W (a plane per sample), as in ConvArgs
     int m_tiles, strips, segs, rows_per_seg, total_blocks;  // set by upfir_plan
     int stagger_phases, stagger_ticks;                       // set by upfir_plan: start delay (phase * ticks of 10 ns)
     int debug_flags;  // timing ablations (GANCE_DEBUG_UPFIR): 1 no stores, 2 no epilogue at all, 4 no MFMA, 8 no DMA after the first chunk
@@ -229,10 +236,11 @@ hipError_t launch_demod(const float* s, const float* w2_pool, const DemodLayer* 
 struct FirArgs {
     const float* t;
     long long cls_stride, unit_stride;
-    const float* noise;  // [2H][2W] or nullptr
+    const float* noise;  // [2H][2W] or nullptr; sample b reads noise + b * noise_b_stride
     const float* bias;   // [C]
     float* out;
     float noise_strength;
+    int noise_b_stride;  // 0 or 4 H W, as in ConvArgs
     int B, C, H, W, nsplit;
     // nullptr, or the style of the NEXT layer, s_next[b * s_next_stride + c]: the stored activation is multiplied by it
     // (the Winograd kernel on 16x16x4 MFMAs takes its input pre-scaled: winograd64_conv.hip)
@@ -244,7 +252,7 @@ hipError_t launch_fir_epilogue(const FirArgs& args, hipStream_t stream);
 // Split-K finish for small stride-1 convs: dense slabs [nsplit][B][C][H][W] ->
 // zero-bordered activation, out = lrelu(sum_slabs + noise*strength + bias) * sqrt2.
 hipError_t launch_splitk_finish(const float* slabs, long long slab_stride, int nsplit,
-                                const float* noise, float noise_strength, const float* bias,
+                                const float* noise, float noise_strength, int noise_b_stride, const float* bias,
                                 float* out, int B, int C, int H, int W, hipStream_t stream);
 
 // ToRGB (modulated 1x1, no demod) + bias + FIR-upsampled skip image; optional uint8 NHWC output.
@@ -264,8 +272,10 @@ struct ToRgbArgs {
 };
 hipError_t launch_torgb(const ToRgbArgs& args, hipStream_t stream);
 
-// out[0 .. count) = standard-normal draws, a function of (seed, stream_id, index) only (randomize_noise of the vector path)
-hipError_t launch_normal_noise(float* out, size_t count, unsigned long long seed, unsigned long long stream_id, hipStream_t stream);
+// out[b][0 .. plane) = standard-normal draws for b < samples, a function of (seed, layer, sample id, index) only, sample id =
+// sample_ids[b] (device memory) or first_sample + b (randomize_noise of the vector path)
+hipError_t launch_normal_noise(float* out, size_t plane, int samples, unsigned long long seed, unsigned long long layer,
+                               unsigned long long first_sample, const long long* sample_ids, hipStream_t stream);
 
 // Bicubic (a = -0.75) resize of uint8 NHWC RGB frames [batch][src][src][3] -> [batch][dst][dst][3].
 hipError_t launch_resize_bicubic_u8(const uint8_t* in, int batch, int src, uint8_t* out, int dst,

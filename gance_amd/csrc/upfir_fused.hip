@@ -274,7 +274,7 @@ __device__ __forceinline__ void upfir_fused_body(const UpFirArgs& p) {
     const int o_voff = (int)((fc * oplane + 4 * cg) * 4);
     const bool has_noise = p.noise != nullptr;
     // (the noise plane [2H][2W] as a bounded resource: a row outside it reads as zeros instead of faulting)
-    const __amdgpu_buffer_rsrc_t nz_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.noise, 0, (2 * H) * (2 * W) * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t nz_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(has_noise ? p.noise + (size_t)b * p.noise_b_stride : nullptr), 0, (2 * H) * (2 * W) * 4, 0x00020000);
     const float ns2 = p.noise_strength * kSqrt2f;
 
     int ring = 0;

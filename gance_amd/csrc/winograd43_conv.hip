@@ -169,6 +169,15 @@ __device__ __forceinline__ void winograd43_body(const ConvArgs& p) {
     if ((tid & 63) == 0) ticket = atomicAdd(&simd_tickets[pg], 1) & 1;
     const int cot = __builtin_amdgcn_readfirstlane(ticket);
     const int role = cot;
+    // Run-time guard of that assumption: were a SIMD ever given one or three of the block's waves (a build whose register
+    // count let a third wave fit, tools/check_w43_isa.py skipped), two waves would share a role and write wrong pixels in
+    // silence. Every wave of the block sees the same four counts: the block records the fault where the host reads it
+    // before the next call (engine.hip: check_call) and leaves, uniformly, before its first barrier-dependent step.
+    __syncthreads();
+    if (simd_tickets[0] != 2 || simd_tickets[1] != 2 || simd_tickets[2] != 2 || simd_tickets[3] != 2) {
+        if (wave == 0 && fresh_lane() == 0 && p.fault_flag != nullptr) __hip_atomic_store(p.fault_flag, 43, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        return;
+    }
     const int Hp = p.H + 2, Wp = p.W + 8;
     const int n = p.total_chunks;               // chunks per tile
     const int my_tiles = (p.total_tiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
@@ -252,7 +261,7 @@ __device__ __forceinline__ void winograd43_body(const ConvArgs& p) {
                     const __amdgpu_buffer_rsrc_t nz_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.noise, 0, 0x7fffffff, 0x00020000);
                     const int row = Geo::kNoiseRowsPerPiece * (wave - 3) + lane / kTC;
                     __builtin_amdgcn_raw_ptr_buffer_load_lds(nz_rsrc, (lds_ptr_t)(set + kConstNoise + (wave - 3) * 256), 16,
-                                                             ((t.y0 + row) * p.OW + t.x0 + 4 * (lane % kTC)) * 4, 0, 0, 0);
+                                                             ((t.y0 + row) * p.OW + t.x0 + 4 * (lane % kTC)) * 4, t.b0 * p.noise_b_stride * 4, 0, 0);
                 }
             } else if (RGB) {  // the A operands of the ToRGB product: [b][Cout / 4 steps][64 lanes], steps 8 m_tile .. + 7: two 16-byte pieces
                 const __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc(

@@ -229,7 +229,7 @@ __device__ __forceinline__ void winograd64_body(const ConvArgs& p) {
                     for (int tg = 0; tg < TG; ++tg) {
                         const int row = 2 * (wave * TG + tg);
                         __builtin_amdgcn_raw_ptr_buffer_load_lds(nz_rsrc, (lds_ptr_t)(set + kConstHead + row * kTW), 4, nz_voff,
-                                                                 ((t.y0 + row) * p.OW + t.x0) * 4, 0, 0);
+                                                                 (b * p.noise_b_stride + (t.y0 + row) * p.OW + t.x0) * 4, 0, 0);
                     }
                 }
                 // ... and (RGB) the A operands of the tile's ToRGB product: [step][lane] for its sample, a row per instruction

@@ -326,7 +326,7 @@ __global__ __launch_bounds__(256, 1) void winograd_conv_kernel(const ConvArgs p)
 #pragma unroll
             for (int dy = 0; dy < 2; ++dy)
 #pragma unroll
-                for (int dx = 0; dx < 2; ++dx) nz[dy][dx] = p.noise[(size_t)(oy + dy) * p.OW + ox + dx] * p.noise_strength;
+                for (int dx = 0; dx < 2; ++dx) nz[dy][dx] = p.noise[(size_t)t.b0 * p.noise_b_stride + (size_t)(oy + dy) * p.OW + ox + dx] * p.noise_strength;
         }
         if constexpr (RGB) {
             // ---- last layer: activation -> ToRGB (32 channels x 3, style * weight) -> + bias + upsampled skip

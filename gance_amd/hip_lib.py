@@ -112,9 +112,11 @@ SIGNATURES = {
         ctypes.c_int,
         [ctypes.c_void_p, _F32P, ctypes.c_int32, ctypes.c_float, _U8P, _F32P],
     ),
-    "gance_engine_randomize_noise": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p]),
+    "gance_engine_randomize_noise": (
+        ctypes.c_int, [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_int32, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_void_p]
+    ),
     "gance_engine_restore_noise": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p]),
-    "gance_engine_debug_read_noise": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32, _F32P, ctypes.c_uint64]),
+    "gance_engine_debug_read_noise": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, _F32P, ctypes.c_uint64]),
     "gance_engine_step_count": (ctypes.c_int32, [ctypes.c_void_p]),
     "gance_engine_step_info": (
         ctypes.c_int,
@@ -423,31 +425,44 @@ class Engine:
 
     # ---- randomize_noise (the reference's vector path draws fresh noise per call) ----
 
-    def randomize_noise(self, seed: Optional[int] = None, stream: int = 0) -> None:
+    def randomize_noise(
+        self, seed: Optional[int] = None, count: Optional[int] = None, first_sample: int = 0, d_sample_ids: int = 0, stream: int = 0
+    ) -> None:
         """
-        Overwrite the noise buffers in HBM with fresh standard-normal draws (asynchronous on `stream`; the draws
-        stay until `restore_noise`). `seed` None: a new seed per call from the OS, as `tf.random_normal` would give.
-        Layers whose noise strength is zero (all of them at random init) are skipped.
+        Draw fresh standard-normal noise planes, one per layer and PER SAMPLE (upstream: tf.random_normal([N, 1, H, W])),
+        for `count` samples (default: max_batch), asynchronously on `stream`; the following calls read them until
+        `restore_noise`. Sample b reads the plane of id `first_sample + b` (or of the int64 id at `d_sample_ids[b]`, a raw
+        device pointer); a plane is a function of (seed, layer, id) only. `seed` None: a new seed from the OS, as
+        `tf.random_normal` would give. Layers whose noise strength is zero (all of them at random init) are skipped.
         """
         self._require_open()
         if seed is None:
             seed = int.from_bytes(os.urandom(8), "little")
-        _check(self._lib, self._lib.gance_engine_randomize_noise(self._handle, ctypes.c_uint64(seed & (2**64 - 1)), stream or None))
+        _check(
+            self._lib,
+            self._lib.gance_engine_randomize_noise(
+                self._handle, ctypes.c_uint64(seed & (2**64 - 1)), int(count or 0), ctypes.c_uint64(int(first_sample)), d_sample_ids or None,
+                stream or None,
+            ),
+        )
         self.noise_randomized = True
 
     def restore_noise(self, stream: int = 0) -> None:
-        """Put the stored noise buffers back (no-op if they are in place)."""
+        """Go back to the stored noise buffers (no-op if they are in use)."""
         self._require_open()
         if getattr(self, "noise_randomized", False):
             _check(self._lib, self._lib.gance_engine_restore_noise(self._handle, stream or None))
             self.noise_randomized = False
 
-    def debug_noise(self, conv_layer: int) -> np.ndarray:
-        """The noise buffer conv layer `conv_layer` currently reads, [res, res] float32 (synchronises)."""
+    def debug_noise(self, conv_layer: int, sample: int = 0) -> np.ndarray:
+        """The noise plane sample `sample` of conv layer `conv_layer` currently reads, [res, res] float32 (synchronises)."""
         self._require_open()
         side = 2 ** sg2_spec.make_spec(self.resolution).convs[conv_layer].res_log2
         out = np.empty((side, side), dtype=np.float32)
-        _check(self._lib, self._lib.gance_engine_debug_read_noise(self._handle, conv_layer, out.ctypes.data_as(_F32P), ctypes.c_uint64(out.size)))
+        _check(
+            self._lib,
+            self._lib.gance_engine_debug_read_noise(self._handle, conv_layer, sample, out.ctypes.data_as(_F32P), ctypes.c_uint64(out.size)),
+        )
         return out
 
     # ---- profiling / debugging ----

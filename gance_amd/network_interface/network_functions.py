@@ -17,6 +17,7 @@ There is no CPU fallback: without libgance_hip.so or without a GPU, loading rais
 
 import json
 import logging
+import os
 import typing
 from functools import wraps
 from pathlib import Path
@@ -84,14 +85,17 @@ class LoadedNetwork:
         """
         z (B, L) -> uint8 (B, H, W, 3): mapping, truncation psi = 1.2, synthesis (network_functions.py:144-158).
         The reference does not pass `randomize_noise` on this path, so the upstream default True applies: fresh noise per
-        call (one draw per engine call here, shared by its frames; `noise_seed` makes it repeatable). A network whose noise
-        strengths are all zero -- every random-init network -- gives the same image either way.
+        call, one plane per layer and per frame as upstream's `tf.random_normal([N, 1, H, W])` (`noise_seed` makes it
+        repeatable: frame k of `data` then reads the planes of (noise_seed, k) however the frames are batched). A network
+        whose noise strengths are all zero -- every random-init network -- gives the same image either way.
         """
         data = np.asarray(data)
         out = []
-        for index, start in enumerate(range(0, len(data), self.max_batch)):
+        if randomize_noise and noise_seed is None:
+            noise_seed = int.from_bytes(os.urandom(8), "little")
+        for start in range(0, len(data), self.max_batch):
             if randomize_noise:
-                self.engine.randomize_noise(None if noise_seed is None else noise_seed + index)
+                self.engine.randomize_noise(noise_seed, count=min(self.max_batch, len(data) - start), first_sample=start)
             else:
                 self.engine.restore_noise()
             out.append(self.engine.synthesize_z(data[start : start + self.max_batch], truncation_psi=TRUNCATION_PSI))

@@ -81,7 +81,8 @@ def synthesize_device_frames(  # pylint: disable=too-many-locals
             members = torch.from_numpy(np.nonzero(chunk == network_index)[0] + start).to(dlatents.device)
             stream = torch.cuda.current_stream(dlatents.device).cuda_stream
             if dlatents.dim() == 2:
-                engine.randomize_noise(stream=stream)  # the reference's vector path draws fresh noise per call (upstream default)
+                # the reference's vector path draws fresh noise per call, a plane per layer and sample (upstream default)
+                engine.randomize_noise(count=int(members.numel()), stream=stream)
                 images = torch.ops.gance.synthesize_z(dlatents.index_select(0, members), engine.op_handle, TRUNCATION_PSI)
             else:
                 engine.restore_noise(stream=stream)  # its matrix path passes randomize_noise=False: the stored buffers
@@ -138,7 +139,8 @@ def synthesize_device_frames_network_major(  # pylint: disable=too-many-locals
             )
             stream = torch.cuda.current_stream(device).cuda_stream
             if dlatents.dim() == 2:
-                engine.randomize_noise(stream=stream)  # the reference's vector path draws fresh noise per call (upstream default)
+                # the reference's vector path draws fresh noise per call, a plane per layer and sample (upstream default)
+                engine.randomize_noise(count=count, stream=stream)
                 selected = dlatents[first : first + count] if in_place else dlatents.index_select(0, members)
                 torch.ops.gance.synthesize_z_out(selected, engine.op_handle, TRUNCATION_PSI, native)
             else:

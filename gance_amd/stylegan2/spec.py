@@ -145,6 +145,46 @@ def make_random_variables(resolution: int, seed: int = 0, perturb: bool = False)
     return variables
 
 
+def make_stress_variables(resolution: int, seed: int = 0) -> Variables:
+    """
+    A generator with the STATISTICS of a trained network, for parity tests only (no trained pickle exists in the
+    reference tree; the legacy importer loads real ones): what a random init never shows a kernel. Conv / ToRGB weights
+    are heavy-tailed (Student-t, 3 degrees of freedom, unit variance) with log-normal per-input-channel and
+    per-output-channel scales spanning 10^-1 ... 10^+1; `mod_bias` ~ N(0, 3) so that |style| reaches ~10; noise strengths
+    uniform in +-[0.1, 1]; biases uniform in [-2, 2]; `dlatent_avg` ~ N(0, 0.5); mapping biases as `perturb=True`.
+    Winograd forms amplify rounding by the norms of their transforms (F(4x4,3x3), points 0, +-1, +-2: ~10 x 20 per
+    layer), which is why the kernels' accuracy is stated on this network beside the random-init one.
+    """
+    spec = make_spec(resolution)
+    rng = np.random.RandomState(seed)
+    variables: Variables = {}
+
+    def log_scale(count: int) -> np.ndarray:
+        return np.exp(np.clip(rng.randn(count) * 1.15, -np.log(10.0), np.log(10.0)))
+
+    for name, shape in variable_shapes(spec).items():
+        leaf = name.rsplit("/", 1)[-1]
+        if name.startswith("G_mapping"):
+            value = rng.randn(*shape) / MAPPING_LRMUL if leaf == "weight" else rng.randn(*shape) * 5.0
+        elif name == "dlatent_avg":
+            value = rng.randn(*shape) * 0.5
+        elif leaf == "weight":  # [k, k, cin, cout]
+            value = rng.standard_t(3, size=shape) / np.sqrt(3.0)
+            value = value * log_scale(shape[2])[None, None, :, None] * log_scale(shape[3])[None, None, None, :]
+            if "ToRGB" in name:
+                value = value * 0.01  # (keeps the image inside a few units, as a trained generator's: most uint8 values unsaturated)
+        elif leaf == "mod_bias":
+            value = rng.randn(*shape) * 3.0
+        elif leaf == "noise_strength":
+            value = np.asarray(rng.uniform(0.1, 1.0) * rng.choice([-1.0, 1.0]))
+        elif leaf == "bias":
+            value = rng.uniform(-2.0, 2.0, size=shape) * (0.1 if "ToRGB" in name else 1.0)
+        else:  # mod_weight, const, noise buffers
+            value = rng.randn(*shape)
+        variables[name] = np.asarray(value, dtype=np.float32).reshape(shape)
+    return variables
+
+
 def pack_variables(variables: Variables, spec: SynthesisSpec) -> np.ndarray:
     """
     Flatten the raw (un-scaled) variables into the float32 blob `gance_engine_create` takes.

@@ -19,7 +19,7 @@
 extern "C" {
 #endif
 
-#define GANCE_ABI_VERSION 4
+#define GANCE_ABI_VERSION 5
 
 enum gance_status {
     GANCE_OK = 0,
@@ -64,7 +64,7 @@ typedef struct gance_engine_config {
  * Calls that share it are ordered by an event, on whatever streams they run. PRIVATE_WORKSPACE gives an engine
  * its own (calls of different engines may then overlap on different streams). */
 #define GANCE_FLAG_PRIVATE_WORKSPACE 32
-#define GANCE_FLAG_WINOGRAD43 64 /* Conv1 layers from 64x64 up in Winograd F(4x4,3x3) form wherever the kernel supports the layer */
+#define GANCE_FLAG_WINOGRAD43 64 /* Conv1 layers from 32x32 up in Winograd F(4x4,3x3) form wherever the kernel supports the layer */
 
 /*
  * Load a network. Replaces load_network_network + wrap_loaded_network
@@ -139,19 +139,22 @@ int gance_engine_step_info(gance_engine* engine, int32_t index, char* name64, fl
                            double* flops, double* bytes);
 /*
  * randomize_noise of the generator. The reference's vector path (create_image_vector, network_functions.py:152-157)
- * leaves `randomize_noise` at the upstream default True: every call draws fresh N(0, 1) noise per layer instead of the
- * stored noise buffers; its matrix path passes randomize_noise=False (:121-125). gance_engine_randomize_noise overwrites
- * the engine's noise buffers in HBM with standard-normal draws that are a function of `seed` only (layers whose
- * noise_strength is zero -- every layer of a random-init network -- are skipped: they never read theirs), asynchronously
- * on `stream` (with a NULL stream both functions return after completion: the host-buffer entries run on a stream of
- * their own); the draws stay until the next call of either function. gance_engine_restore_noise puts the stored buffers
- * back. One noise plane per layer serves the whole batch of a call (upstream draws per sample; at one frame per call,
- * the reference's call pattern, that is the same thing).
+ * leaves `randomize_noise` at the upstream default True: every call draws fresh N(0, 1) noise, one plane per layer AND
+ * PER SAMPLE (upstream: tf.random_normal([N, 1, H, W])), instead of the stored noise buffers; its matrix path passes
+ * randomize_noise=False (:121-125). gance_engine_randomize_noise draws planes for `count` samples (0: max_batch) of every
+ * layer whose noise_strength is non-zero (none in a random-init network) into buffers of the engine's own, asynchronously
+ * on `stream` (with a NULL stream it returns after completion: the host-buffer entries run on a stream of their own).
+ * Sample b of the following calls (batch <= count, else GANCE_ERR_INVALID_ARGUMENT) reads the plane with the id
+ * d_sample_ids[b] (device memory, int64) or, with d_sample_ids NULL, first_sample + b; a plane is a function of
+ * (seed, layer, id) only, so with id = frame number a frame's noise does not depend on how frames were batched or
+ * sharded. The draws stay until the next call of either function; gance_engine_restore_noise goes back to the stored
+ * buffers (which are never overwritten).
  */
-int gance_engine_randomize_noise(gance_engine* engine, uint64_t seed, void* stream);
+int gance_engine_randomize_noise(gance_engine* engine, uint64_t seed, int32_t count, uint64_t first_sample,
+                                 const int64_t* d_sample_ids, void* stream);
 int gance_engine_restore_noise(gance_engine* engine, void* stream);
-/* Debug: the noise buffer conv layer `conv_layer` currently reads ([res][res] floats, count = res * res), to host memory. */
-int gance_engine_debug_read_noise(gance_engine* engine, int32_t conv_layer, float* h_out, uint64_t count);
+/* Debug: the noise plane sample `sample` of conv layer `conv_layer` currently reads ([res][res] floats, count = res * res), to host memory. */
+int gance_engine_debug_read_noise(gance_engine* engine, int32_t conv_layer, int32_t sample, float* h_out, uint64_t count);
 
 /*
  * Debug: run only the first `num_steps` conv layers of the next synthesize_w calls (<=0 = all)

@@ -4,7 +4,9 @@ image stays within 1e-4 of the fp64 oracle.) CPU experiment, no GPU: the oracle'
 with the stride-1 3x3 convs of the chosen resolutions replaced by an emulation of the kernel's arithmetic
 (float32 input transform, float32 products summed in float32, float32 output transform), for two point sets.
 
-    python tools/experiments/winograd_f43_error.py [resolution] [first_res_with_winograd]
+    python tools/experiments/winograd_f43_error.py [resolution] [first_res_with_winograd] [last] [stress]
+
+`stress` (any fourth argument): the trained-statistics network of `spec.make_stress_variables` instead of the random init.
 """
 import sys
 from fractions import Fraction
@@ -77,7 +79,8 @@ def main():
     resolution = int(sys.argv[1]) if len(sys.argv) > 1 else 256
     first = int(sys.argv[2]) if len(sys.argv) > 2 else 64
     last = int(sys.argv[3]) if len(sys.argv) > 3 else 256
-    variables = sg2_spec.make_random_variables(resolution, seed=0, perturb=True)
+    stress = len(sys.argv) > 4
+    variables = sg2_spec.make_stress_variables(resolution, seed=0) if stress else sg2_spec.make_random_variables(resolution, seed=0, perturb=True)
     z = np.random.RandomState(1).randn(2, 512).astype(np.float32)
     want = ref.synthesize_z(z, variables, resolution, truncation_psi=1.2)
     sets = {
