@@ -165,16 +165,22 @@ class SyntheticFaceFinder:  # pylint: disable=too-few-public-methods
 
 
 def product_stream_measurement(  # pylint: disable=too-many-arguments,too-many-locals,too-many-statements
-    label: str, resolution: int, batch: int, num_networks: int, output_side, device, with_cpu_baseline: bool, overlay: bool = False
+    label: str, resolution: int, batch: int, num_networks: int, output_side, device, with_cpu_baseline: bool, overlay: bool = False,
+    drain: str = "rank0",
 ) -> dict:
     """
-    BASELINE.json configs[2] / [3] / [4] on one GPU THROUGH THE PRODUCT: a 30 s synthetic WAV and a projection file of
+    BASELINE.json configs[2] / [3] / [4] THROUGH THE PRODUCT, on one GPU or -- under torch.distributed.run, one rank per GPU:
+    collective, every rank calls this -- frame-sharded over the node: a 30 s synthetic WAV and a projection file of
     900 projected latents ON DISK -> `projection_file_blend_frame_chunks` (read + stretch the WAV, audio -> latents on
     the GPU, chunked synthesis with resident networks, optional bicubic resize / overlay gate in HBM, ordered chunks
     drained to the pinned host ring) -> every chunk consumed on the host. Timed: the call -> the last uint8 frame on
     the host; the networks are resident before the call (the reference loads them before
     its frame loop too, projection_file_blend.py:122). A first, short run warms the process (operator tables,
     kernel attributes, pinned ring) and names the last conv launch; the second, full run is the one reported.
+    With N ranks a chunk is N x `batch` frames; rank 0 alone writes the input files (the others read them: one node, one
+    file system), prints and returns the record (the other ranks return {}); `drain` as in
+    `projection_file_blend_frame_chunks` ("per-rank": every rank consumes its own pieces on its own host link; the time
+    reported is then the slowest rank's).
     """
     import tempfile  # pylint: disable=import-outside-toplevel
 
@@ -186,24 +192,33 @@ def product_stream_measurement(  # pylint: disable=too-many-arguments,too-many-l
 
     num_frames, vector_length, fps_in, fps_out = 1800, 512, 30.0, 60.0
     side = output_side or resolution
-    with tempfile.TemporaryDirectory(prefix="gance_bench_") as directory:
-        directory = Path(directory)
-        audio, latents = synthetic.benchmark_blend_inputs(num_frames)
+    world_size = dist.get_world_size() if dist.is_initialized() else 1
+    rank = dist.get_rank() if dist.is_initialized() else 0
+    holder = tempfile.TemporaryDirectory(prefix="gance_bench_") if rank == 0 else None  # pylint: disable=consider-using-with
+    shared = [holder.name if holder is not None else None]
+    if world_size > 1:
+        dist.broadcast_object_list(shared, src=0)
+    try:
+        directory = Path(shared[0])
         wav_path = directory / "audio.wav"
-        wavfile.write(str(wav_path), int(vector_length * fps_out), audio)
-        targets = None
-        if overlay:  # target frames of the projection: blocky pictures at 128^2, the gate scales them to the output side
-            rng = np.random.RandomState(73)
-            targets = (np.kron(rng.rand(num_frames // 2, 8, 8, 3), np.ones((1, 16, 16, 1))) * 255).astype(np.uint8)
         projection_path = directory / "projection.npz"
-        pfr.write_projection_npz(
-            projection_path, latents.reshape(18, num_frames // 2, vector_length).transpose(1, 0, 2), projection_fps=fps_in, target_images=targets
-        )
-        network_paths = []
-        for seed in range(num_networks):
-            network_paths.append(directory / f"net_{seed}.pkl")
-            network_file.write_random_network(network_paths[-1], resolution, seed=seed)
-        networks = MultiNetwork(network_paths=network_paths, load=True, max_batch=batch)
+        network_paths = [directory / f"net_{seed}.pkl" for seed in range(num_networks)]
+        audio = latents = None
+        if rank == 0:
+            audio, latents = synthetic.benchmark_blend_inputs(num_frames)
+            wavfile.write(str(wav_path), int(vector_length * fps_out), audio)
+            targets = None
+            if overlay:  # target frames of the projection: blocky pictures at 128^2, the gate scales them to the output side
+                rng = np.random.RandomState(73)
+                targets = (np.kron(rng.rand(num_frames // 2, 8, 8, 3), np.ones((1, 16, 16, 1))) * 255).astype(np.uint8)
+            pfr.write_projection_npz(
+                projection_path, latents.reshape(18, num_frames // 2, vector_length).transpose(1, 0, 2), projection_fps=fps_in, target_images=targets
+            )
+            for seed, path in enumerate(network_paths):
+                network_file.write_random_network(path, resolution, seed=seed)
+        if world_size > 1:
+            dist.barrier()  # (the files exist)
+        networks = MultiNetwork(network_paths=network_paths, load=True, max_batch=batch, device=device.index)
         engines = [networks._network_at(index).engine for index in range(num_networks)]  # pylint: disable=protected-access
         overlay_parameters = (
             projection_file_blend.OverlayParameters(phash_distance=64, bbox_distance=5.0, track_length=5, face_finder=SyntheticFaceFinder(side))
@@ -213,33 +228,51 @@ def product_stream_measurement(  # pylint: disable=too-many-arguments,too-many-l
         last_conv_pattern = re.compile(r"^conv[A-Z]*%d[+_].*_%dx%d_" % (2 * int(np.log2(resolution)) - 4, resolution, resolution))
 
         def run(frames_to_visualize, timings):
+            if world_size > 1:
+                torch.cuda.synchronize(device)
+                dist.barrier()
             start = time.perf_counter()
-            checksum, chunks, last_index = 0, 0, -1
+            checksum, chunks, last_index, received = 0, 0, -1, 0
             for first, _total, frames in projection_file_blend.projection_file_blend_frame_chunks(
                 wav=[str(wav_path)], network_paths=network_paths, frames_to_visualize=frames_to_visualize, output_fps=fps_out,
                 output_side_length=side, alpha=0.25, fft_roll_enabled=True, fft_amplitude_range=(-5, 5),
                 projection_file_path=str(projection_path), blend_depth=12, frames_per_call=batch, overlay=overlay_parameters,
-                networks=networks, timings=timings,
+                networks=networks, timings=timings, drain=drain,
             ):
-                assert first == last_index + 1
+                assert first > last_index  # (rank 0 drain: consecutive chunks; per-rank drain: this rank's pieces, ascending)
                 last_index = first + len(frames) - 1
+                received += len(frames)
                 checksum += int(frames[-1, -1, -1, 0]) + int(frames[0, 0, 0, 0])  # the chunk is on the host: touch both ends
                 chunks += 1
-            return time.perf_counter() - start, last_index + 1, chunks, checksum
+            elapsed = time.perf_counter() - start
+            if world_size > 1:  # the job is done when its slowest rank is; frames received over all ranks
+                totals = torch.tensor([elapsed, float(received)], dtype=torch.float64, device=device)
+                slowest = totals.clone()
+                dist.all_reduce(slowest, op=dist.ReduceOp.MAX)
+                dist.all_reduce(totals, op=dist.ReduceOp.SUM)
+                elapsed, received = float(slowest[0].item()), int(totals[1].item())
+            return elapsed, received, chunks, checksum
 
         try:
             for engine in engines:
                 engine.set_profiling(True)
-            run(4 * batch, {})  # warm-up, every launch bracketed: it names the last conv launch
+            run(4 * batch * world_size, {})  # warm-up, every launch bracketed: it names the last conv launch
             last_conv = next((s.name for s in engines[0].steps() if last_conv_pattern.match(s.name)), "conv")
             for engine in engines:
                 engine.set_profiling(True, only_step=last_conv)
             timings: dict = {}
             elapsed, produced, chunks, _ = run(None, timings)
-            assert produced == num_frames
+            assert produced == num_frames, (produced, num_frames)
             timed = [s for engine in engines for s in engine.steps() if s.name.startswith(last_conv)]
         finally:
             networks.unload()
+    finally:
+        if world_size > 1:
+            dist.barrier()  # (nobody still reads the files)
+        if holder is not None:
+            holder.cleanup()
+    if rank != 0:
+        return {}
     split = timings.get("audio_to_latents_split_ms", {})
     audio_ms = float(timings.get("audio_to_latents_ms", 0.0))
     # audio -> latents: algorithmic bytes = the samples read once + the per-frame latent rows written once
@@ -248,9 +281,10 @@ def product_stream_measurement(  # pylint: disable=too-many-arguments,too-many-l
     kernels_ms = float(split.get("kernels_ms", 0.0)) or audio_ms
     result = {
         "metric": label,
-        "value": round(num_frames / elapsed, 3), "unit": "frames/s", "n_gpus": 1,
+        "value": round(num_frames / elapsed, 3), "unit": "frames/s", "n_gpus": world_size,
         "timed": "WAV + projection file on disk -> last uint8 frame on the host, through projection_file_blend_frame_chunks (networks resident)",
-        "frames": num_frames, "chunks": chunks, "frames_per_call": batch, "seconds": round(elapsed, 4),
+        "drain": drain + (" (RCCL gather of every chunk to rank 0, which drains it to its pinned ring)" if drain == "rank0" else " (no gather: every rank drains its own pieces over its own PCIe link)"),
+        "frames": num_frames, "chunks_on_rank_0": chunks, "frames_per_call": batch, "frames_per_chunk": batch * world_size, "seconds": round(elapsed, 4),
         "read_projection_file_ms": round(float(timings.get("read_projection_file_ms", 0.0)), 3),
         "read_and_stretch_wav_ms": round(float(timings.get("read_and_stretch_wav_ms", 0.0)), 3),
         "audio_to_latents_ms": round(audio_ms, 3),
@@ -292,6 +326,14 @@ def product_stream_measurement(  # pylint: disable=too-many-arguments,too-many-l
     return result
 
 
+EXTRAS_WATCHDOG_S = int(os.environ.get("GANCE_BENCH_EXTRAS_WATCHDOG_S", "240"))
+
+
+def rehearsal_skips_extras() -> bool:
+    """GANCE_BENCH_REHEARSAL_EXTRAS=0: a one-GPU rehearsal of the N-rank line without the N-rank extras."""
+    return os.environ.get("GANCE_BENCH_REHEARSAL_EXTRAS", "1") == "0"
+
+
 def guarded(measure, *args, **kwargs) -> dict:
     """An extra measurement must never cost the contract line: its failure is recorded in its slot."""
     try:
@@ -323,16 +365,93 @@ def one_frame_latency(resolution: int, device) -> dict:
     return out
 
 
+def batch_sweep(resolution: int, variables, device, batches, steps: int = 20, warmup: int = 3) -> dict:
+    """
+    SURVEY.md section 8(d) config 2 / BASELINE.md section 5: synthesis only, z vectors resident in HBM, frames stay in HBM, at
+    every batch size of `batches`: HIP-event timed (events on the launch stream), `warmup` + `steps` engine calls each. One
+    engine with the largest batch as capacity (as the product has); per batch the launch name of every Conv0_up / Conv1
+    layer (the form the engine chose: engine.hip conv_form_of / up_runs_fused) and, at one frame per call, the three
+    slowest launches.
+    """
+    batches = sorted(set(int(b) for b in batches))
+    engine = hip_lib.Engine(variables, resolution, max_batch=max(batches), device=device.index, profile=False)
+    stream = torch.cuda.current_stream(device)
+    rows = {}
+    try:
+        for batch in batches:
+            z = torch.from_numpy(np.random.RandomState(batch).randn(batch, 512).astype(np.float32)).to(device)
+            frames = torch.empty((batch, resolution, resolution, 3), dtype=torch.uint8, device=device)
+            engine.set_profiling(False)
+            for _ in range(warmup):
+                engine.synthesize_z_device(z.data_ptr(), batch, 1.2, frames.data_ptr(), 0, stream.cuda_stream)
+            begin, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            begin.record(stream)
+            for _ in range(steps):
+                engine.synthesize_z_device(z.data_ptr(), batch, 1.2, frames.data_ptr(), 0, stream.cuda_stream)
+            end.record(stream)
+            end.synchronize()
+            ms_per_call = begin.elapsed_time(end) / steps
+            engine.set_profiling(True)  # one more call with every launch bracketed: the forms, and the slowest launches
+            engine.synthesize_z_device(z.data_ptr(), batch, 1.2, frames.data_ptr(), 0, stream.cuda_stream)
+            torch.cuda.synchronize(device)
+            launches = engine.steps()
+            forms = {}
+            for info in launches:
+                if info.name.startswith("conv") and info.flops > 0:
+                    kind, _, rest = info.name.partition("_")
+                    forms[rest.split("_")[0] + ("_up" if kind.startswith("convT") else "")] = kind
+            row = {
+                "frames_per_s": round(batch / (ms_per_call * 1e-3), 2), "ms_per_frame": round(ms_per_call / batch, 4), "ms_per_call": round(ms_per_call, 4),
+                "direct_form_frac_of_fp32_mfma_peak": round(
+                    batch / (ms_per_call * 1e-3) * ALGORITHMIC_GFLOP_PER_FRAME_1024 * (resolution / 1024) ** 2 / 1e3 / FP32_MFMA_PEAK_TFLOPS, 4
+                ),
+                "launches": len(launches), "forms": forms,
+            }
+            if batch == 1:
+                slowest = sorted(launches, key=lambda info: -info.ms)[:3]
+                row["gpu_ms_sum_of_launches"] = round(sum(info.ms for info in launches), 4)
+                row["slowest_launches"] = [{"name": info.name, "us": round(info.ms * 1e3, 1)} for info in slowest]
+            rows[str(batch)] = row
+    finally:
+        engine.close()
+    return {
+        "workload": "BASELINE.json configs[1] at other batch sizes (SURVEY.md section 8(d) config 2): random-z synthesis, z and frames resident in HBM",
+        "timing": f"HIP events on the launch stream around {steps} engine calls after {warmup} warm-up calls, per batch size",
+        "forms_legend": "conv<N> direct form, convW F(2x2,3x3), convV F(4x4,3x3), +rgb ToRGB channel sum in the epilogue, +torgb fused ToRGB + uint8; "
+        "convT two-pass up layer (+ fir pass), convTF / convTFp one fused up kernel (p: input pre-scaled by its style)",
+        "by_batch": rows,
+    }
+
+
 METRIC_CONFIG_2 = "projection-file-blend frames/sec at 1024x1024 through the product stream (BASELINE.json configs[2]: 30 s WAV -> FFT + fft-roll -> alpha-blended latents -> synthesis @60 fps), files on disk -> frames on the host"
 METRIC_CONFIG_3 = "projection-file-blend frames/sec at --output-side-length 2160 on ONE GPU through the product stream (BASELINE.json configs[3] without the 8-GPU sharding), files on disk -> 2160x2160 frames on the host"
 METRIC_CONFIG_4 = "projection-file-blend frames/sec at 1024x1024 with three resident networks switched by the RMS index, through the product stream (BASELINE.json configs[4] on one GPU, no overlay)"
 METRIC_CONFIG_4_OVERLAY = "projection-file-blend frames/sec at 1024x1024 with three resident networks AND the streaming phash / bbox overlay gate (BASELINE.json configs[4] on one GPU; synthetic landmark detector)"
 
 
+def sharded(label: str, world_size: int) -> str:
+    """The metric label of a product-stream measurement taken on `world_size` GPUs."""
+    if world_size == 1:
+        return label
+    return label.replace("on ONE GPU ", "").replace(" on one GPU", "").replace("without the 8-GPU sharding", "frame-sharded") + f" -- frame-sharded over {world_size} GPUs"
+
+
 def blend_workload(args, device) -> int:
-    """`--workload blend`: only the configs[2] line (with --networks / --output-side / --overlay: configs[4] / configs[3] on one GPU)."""
+    """
+    `--workload blend`: only the configs[2] line (with --networks / --output-side / --overlay: configs[4] / configs[3]), on
+    --gpus N GPUs (collective: launched by torch.distributed.run like the contract line; rank 0 prints).
+    """
+    world_size = dist.get_world_size() if dist.is_initialized() else 1
     label = METRIC_CONFIG_4_OVERLAY if args.overlay else (METRIC_CONFIG_4 if args.networks > 1 else (METRIC_CONFIG_3 if args.output_side else METRIC_CONFIG_2))
-    print(json.dumps(product_stream_measurement(label, args.resolution, args.batch, args.networks, args.output_side, device, not args.no_cpu_baseline, args.overlay)), flush=True)
+    record = product_stream_measurement(
+        sharded(label, world_size), args.resolution, args.batch, args.networks, args.output_side, device, not args.no_cpu_baseline and world_size == 1,
+        args.overlay, args.drain,
+    )
+    if record:
+        print(json.dumps(record), flush=True)
+    if world_size > 1:
+        dist.barrier()
+        dist.destroy_process_group()
     return 0
 
 
@@ -359,6 +478,12 @@ def main() -> int:
     parser.add_argument("--networks", type=int, default=1, help="blend workload: resident networks the RMS index switches between")
     parser.add_argument("--output-side", type=int, default=None, help="blend workload: --output-side-length (bicubic resize in HBM), e.g. 2160")
     parser.add_argument("--overlay", action="store_true", help="blend workload: the streaming phash / bbox overlay gate (synthetic landmark detector)")
+    parser.add_argument(
+        "--drain", choices=list(frame_sharding.DRAIN_MODES), default="rank0",
+        help="blend workload with --gpus N > 1: rank0 = RCCL gather of every chunk to rank 0, drained over its PCIe link; per-rank = every rank "
+        "drains the pieces it synthesised over its own link (no gather; not with --overlay)",
+    )
+    parser.add_argument("--batch-sweep", default="1,4,8,16,32,64", help="batch sizes of extras.batch_sweep (SURVEY.md section 8(d) config 2); empty: skip")
     args = parser.parse_args()
 
     world_size = int(os.environ.get("WORLD_SIZE", "1"))
@@ -527,16 +652,42 @@ def main() -> int:
         if world_size == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(resolution, variables)
     engine.close()
+    extras = None
+    if not args.no_extras and world_size == 1:
+        # measured beside the contract line, same process, same GPU (each is also reachable alone: --workload blend)
+        extras = {
+            "config_2_blend_stream": guarded(product_stream_measurement, METRIC_CONFIG_2, resolution, batch, 1, None, device, not args.no_cpu_baseline),
+            "config_4_three_networks_stream": guarded(product_stream_measurement, METRIC_CONFIG_4, resolution, batch, 3, None, device, False),
+            "config_4_three_networks_overlay_stream": guarded(product_stream_measurement, METRIC_CONFIG_4_OVERLAY, resolution, batch, 3, None, device, False, True),
+            "config_3_output_side_2160_one_gpu_stream": guarded(product_stream_measurement, METRIC_CONFIG_3, resolution, batch, 1, 2160, device, False),
+            "one_frame_latency": guarded(one_frame_latency, resolution, device),
+        }
+        if args.batch_sweep and not args.all_terms:
+            extras["batch_sweep"] = guarded(batch_sweep, resolution, variables, device, [int(b) for b in args.batch_sweep.split(",") if int(b) <= batch])
+    elif not args.no_extras and not rehearsal_skips_extras():
+        # N GPUs: BASELINE.json configs[3] (2160^2 output, frame-sharded, both drains) and configs[4] (three networks + overlay gate) through
+        # the product stream, collectively, beside the weak-scaling line. A watchdog guarantees the contract line: should a
+        # collective of the extras hang (a rank lost), rank 0 prints the line without them and every rank leaves.
+        import threading  # pylint: disable=import-outside-toplevel
+
+        def give_up() -> None:
+            if rank == 0:
+                result["extras"] = {"error": "the multi-GPU extras did not finish within %d s; the contract line above them is complete" % EXTRAS_WATCHDOG_S}
+                print(json.dumps(result), flush=True)
+            os._exit(0)  # pylint: disable=protected-access
+
+        watchdog = threading.Timer(EXTRAS_WATCHDOG_S, give_up)
+        watchdog.daemon = True
+        watchdog.start()
+        extras = {
+            "config_3_output_side_2160_sharded_rank0_drain": guarded(product_stream_measurement, sharded(METRIC_CONFIG_3, world_size), resolution, batch, 1, 2160, device, False, False, "rank0"),
+            "config_3_output_side_2160_sharded_per_rank_drain": guarded(product_stream_measurement, sharded(METRIC_CONFIG_3, world_size), resolution, batch, 1, 2160, device, False, False, "per-rank"),
+            "config_4_three_networks_overlay_sharded": guarded(product_stream_measurement, sharded(METRIC_CONFIG_4_OVERLAY, world_size), resolution, batch, 3, None, device, False, True, "rank0"),
+        }
+        watchdog.cancel()
     if rank == 0:
-        if world_size == 1 and not args.no_extras:
-            # measured beside the contract line, same process, same GPU (each is also reachable alone: --workload blend)
-            result["extras"] = {
-                "config_2_blend_stream": guarded(product_stream_measurement, METRIC_CONFIG_2, resolution, batch, 1, None, device, not args.no_cpu_baseline),
-                "config_4_three_networks_stream": guarded(product_stream_measurement, METRIC_CONFIG_4, resolution, batch, 3, None, device, False),
-                "config_4_three_networks_overlay_stream": guarded(product_stream_measurement, METRIC_CONFIG_4_OVERLAY, resolution, batch, 3, None, device, False, True),
-                "config_3_output_side_2160_one_gpu_stream": guarded(product_stream_measurement, METRIC_CONFIG_3, resolution, batch, 1, 2160, device, False),
-                "one_frame_latency": guarded(one_frame_latency, resolution, device),
-            }
+        if extras is not None:
+            result["extras"] = extras
         print(json.dumps(result), flush=True)
 
     if world_size > 1:

@@ -365,6 +365,7 @@ static int wino43_max_res(int flags) {
     }();
     if (flags & GANCE_FLAG_DIRECT_CONV) return 0;
     if (flags & GANCE_FLAG_WINOGRAD43) return 1 << 20;
+    if (flags & GANCE_FLAG_FORCE_WINOGRAD) return 0;  // FORCE_WINOGRAD alone = the F(2x2,3x3) kernels on every layer (parity tests of that form)
     return env_value >= 0 ? env_value : kWino43DefaultMaxRes;
 }
 

@@ -11,10 +11,17 @@ frames, in frame order, back to rank 0. No all-reduce anywhere.
 Partitioning: contiguous blocks, rank g owns frames [g*ceil(N/G), min(N, (g+1)*ceil(N/G))).
 """
 
+import datetime
+import os
 from typing import List, Optional, Tuple
 
 import torch
 import torch.distributed as dist
+
+# Host-side control exchanges (one status word per chunk) must not outlive a dead rank by gloo's default 30 minutes:
+# the same knob bench.py passes to init_process_group
+CONTROL_GROUP_TIMEOUT = datetime.timedelta(seconds=int(os.environ.get("GANCE_PROCESS_GROUP_TIMEOUT_S", "180")))
+DRAIN_MODES = ("rank0", "per-rank")
 
 
 def shard_bounds(num_frames: int, world_size: int, rank: int) -> Tuple[int, int]:
@@ -168,27 +175,32 @@ def control_group():
     if dist.get_backend() == "gloo":
         return dist.group.WORLD
     if _CONTROL_GROUP[0] is None:
-        _CONTROL_GROUP[0] = dist.new_group(backend="gloo")
+        _CONTROL_GROUP[0] = dist.new_group(backend="gloo", timeout=CONTROL_GROUP_TIMEOUT)
     return _CONTROL_GROUP[0]
 
 
-def exchange_status(failed: bool, where: str) -> None:
+def exchange_status(failed: bool, where: str, consumer: bool = False) -> None:
     """
     Every rank contributes one word; if any rank reports a failure every rank leaves with StreamRankError (the
     failing rank re-raises its own exception instead: the caller does that). The reference relays a worker's
     start-up error to its parent the same way (network_functions.py:270-278). A rank that has died makes the
-    exchange time out (the process group's timeout) and raise on the survivors.
+    exchange time out (the control group's timeout) and raise on the survivors. `consumer`: the failure is the
+    rank's consumer side (it left the stream between two chunks), not the step `where` names.
     """
     group = control_group()
     if group is None:
         return
-    status = torch.tensor([dist.get_rank() + 1 if failed else 0], dtype=torch.int32)
+    status = torch.tensor([(dist.get_rank() + 1) | ((1 << 16) if consumer else 0) if failed else 0], dtype=torch.int32)
     dist.all_reduce(status, op=dist.ReduceOp.MAX, group=group)
-    if int(status.item()) != 0 and not failed:
-        raise StreamRankError(f"rank {int(status.item()) - 1} failed {where}; rank {dist.get_rank()} stops")
+    word = int(status.item())
+    if word != 0 and not failed:
+        what = "consuming the stream" if word >> 16 else where
+        raise StreamRankError(f"rank {(word & 0xFFFF) - 1} failed {what}; rank {dist.get_rank()} stops")
 
 
-def ordered_device_chunks(synthesize_piece, num_frames: int, frames_per_rank: int, frame_shape: Tuple[int, int, int], device: torch.device):
+def ordered_device_chunks(  # pylint: disable=too-many-arguments,too-many-locals,too-many-branches,too-many-statements
+    synthesize_piece, num_frames: int, frames_per_rank: int, frame_shape: Tuple[int, int, int], device: torch.device, drain: str = "rank0"
+):
     """
     Generator (collective: every rank must exhaust it). `synthesize_piece(offset, count)` returns this rank's
     next `count` frames as a uint8 tensor [count, *frame_shape] on `device`, where `offset` counts the frames
@@ -197,39 +209,62 @@ def ordered_device_chunks(synthesize_piece, num_frames: int, frames_per_rank: in
     view of the stream's own buffer: no copy of the chunk (a device-to-device copy of 64 frames of 1024^2 is a blit
     kernel of about a millisecond in the stream of the synthesis). With one rank the chunk is handed out from that
     buffer; only several ranks need gather buffers.
-    On rank 0 it yields (first_frame_index, frames, reader_stream) per chunk, in frame order: `frames` is a view of
-    one of two gather buffers in HBM, [n, *frame_shape] uint8. It is valid until the generator is advanced TWICE
-    more, and whoever reads it must do so on `reader_stream` (a side stream that already waits for the gather; None
-    on the CPU): the generator makes the gather that overwrites the buffer wait for that stream. Other ranks yield
-    nothing. Chunk k is handed out after chunk k+1's synthesis and gather have been issued, so the consumer's work
-    on it (overlay, host drain) overlaps them: the reader stream waits for chunk k's OWN gather (an event recorded
-    behind it), not for what was issued since -- a consumer that blocks the host on the reader stream (the overlay
-    gate copies frames to the host for the landmark detector) would otherwise sit out chunk k+1's synthesis first and
-    leave the GPU idle while it works.
+
+    `drain="rank0"` (default): ONE gather per chunk lands it in frame order on rank 0, which yields
+    (first_frame_index, frames, reader_stream) per chunk; other ranks yield nothing. This is the form for consumers that
+    need the ordered stream in one place in HBM (the overlay stage, an encoder on rank 0's host).
+    `drain="per-rank"`: no gather at all -- EVERY rank yields its own piece of every chunk,
+    (first_frame_index of the piece, frames, reader_stream), and drains it over its OWN PCIe link (the caller's HostRing):
+    the host-bound legs (2160^2 frames: 14 MB each, ~57 GB/s of pinned D2H per link = ~4 000 frames/s through rank 0
+    alone) then scale with the node. The ranks stay in step through the per-chunk status word, which is also what
+    sequences the chunks: piece (chunk k, rank g) holds frames [k W C + g C, k W C + (g + 1) C).
+
+    `frames` is a view of one of two buffers in HBM, [n, *frame_shape] uint8, valid ONLY UNTIL THE GENERATOR IS ADVANCED
+    AGAIN: whoever reads it must enqueue the read on `reader_stream` (a side stream that already waits for the chunk's
+    gather / synthesis; None on the CPU, where the read must finish) before advancing -- the generator makes whatever
+    overwrites the buffer next wait for that stream. (Chunk k is handed out during iteration k + 1, and iteration k + 2
+    writes the same buffer.) Chunk k is handed out after chunk k+1's synthesis and gather have been issued, so the
+    consumer's work on it (overlay, host drain) overlaps them: the reader stream waits for chunk k's OWN gather (an event
+    recorded behind it), not for what was issued since -- a consumer that blocks the host on the reader stream (the
+    overlay gate copies frames to the host for the landmark detector) would otherwise sit out chunk k+1's synthesis
+    first and leave the GPU idle while it works.
+
     Failure handling: every rank exchanges one status word per chunk on the host-side control group; an exception in
     `synthesize_piece` on any rank ends the generator on EVERY rank (the failing rank re-raises its exception, the
-    others raise StreamRankError) instead of leaving them blocked in the next gather.
+    others raise StreamRankError) instead of leaving them blocked in the next gather. A consumer that fails or drops
+    the generator between two chunks (GeneratorExit / an exception thrown in at the yield) reports that in its next
+    status word, so the other ranks leave with StreamRankError in that chunk instead of waiting out the timeout.
     """
+    if drain not in DRAIN_MODES:
+        raise ValueError(f"drain must be one of {DRAIN_MODES}, got {drain!r}")
     world_size = dist.get_world_size() if dist.is_initialized() else 1
     rank = dist.get_rank() if dist.is_initialized() else 0
+    per_rank_drain = drain == "per-rank" and world_size > 1
     chunks = stream_chunks(num_frames, world_size, frames_per_rank)
     per_chunk = world_size * frames_per_rank
     on_gpu = device.type == "cuda"
     local = [torch.zeros((frames_per_rank, *frame_shape), dtype=torch.uint8, device=device) for _ in range(2)]
+    hands_out = rank == 0 or per_rank_drain
     gathered = None
-    if rank == 0:
-        gathered = local if world_size == 1 else [torch.empty((per_chunk, *frame_shape), dtype=torch.uint8, device=device) for _ in range(2)]
+    if hands_out:
+        gathered = local if world_size == 1 or per_rank_drain else [torch.empty((per_chunk, *frame_shape), dtype=torch.uint8, device=device) for _ in range(2)]
     writes_into = bool(getattr(synthesize_piece, "writes_into", False))
-    reader_stream = torch.cuda.Stream(device) if on_gpu and rank == 0 else None
-    issued = [None, None]  # per gather buffer: event behind the last copy / gather issued into it
+    reader_stream = torch.cuda.Stream(device) if on_gpu and hands_out else None
+    issued = [None, None]  # per buffer: event behind the last synthesis / gather issued into it
     works = [None, None]
     produced = 0
 
     def hand_out(chunk: int):
-        """Gather of `chunk` done (in stream order on the reader stream) -> its view of the gather buffer."""
+        """Gather of `chunk` done (in stream order on the reader stream) -> its view of the buffer (None: an empty tail piece)."""
         slot = chunk & 1
-        first = chunk * per_chunk
-        count = min(num_frames, first + per_chunk) - first
+        if per_rank_drain:
+            first, end = stream_piece(num_frames, world_size, frames_per_rank, chunk, rank)
+            count = end - first
+        else:
+            first = chunk * per_chunk
+            count = min(num_frames, first + per_chunk) - first
+        if count <= 0:
+            return None
         if reader_stream is None:
             if works[slot] is not None:
                 works[slot].wait()
@@ -242,45 +277,67 @@ def ordered_device_chunks(synthesize_piece, num_frames: int, frames_per_rank: in
             reader_stream.wait_event(issued[slot])
         return first, gathered[slot][:count], reader_stream
 
-    for chunk in range(chunks):
-        slot = chunk & 1
-        start, end = stream_piece(num_frames, world_size, frames_per_rank, chunk, rank)
-        count = end - start
-        if reader_stream is not None and chunk >= 2:
-            # the consumer of chunk-2 read gathered[slot] on the reader stream: the gather below may only overwrite it afterwards
-            torch.cuda.current_stream(device).wait_stream(reader_stream)
-        if works[slot] is not None:  # (ranks > 0 hand nothing out: retire the gather that last read local[slot] here)
-            works[slot].wait()
-            works[slot] = None
-        failure = None
-        if count:
+    exchanges = 0      # status words this rank has contributed
+    settled = False    # the stream ended in a way every rank already knows about (normal end, or a relayed failure)
+    try:
+        for chunk in range(chunks):
+            slot = chunk & 1
+            start, end = stream_piece(num_frames, world_size, frames_per_rank, chunk, rank)
+            count = end - start
+            if reader_stream is not None and chunk >= 2:
+                # the consumer of chunk-2 read gathered[slot] on the reader stream: the synthesis / gather below may only overwrite it afterwards
+                torch.cuda.current_stream(device).wait_stream(reader_stream)
+            if works[slot] is not None:  # (ranks > 0 hand nothing out: retire the gather that last read local[slot] here)
+                works[slot].wait()
+                works[slot] = None
+            failure = None
+            if count:
+                try:
+                    if writes_into:
+                        synthesize_piece(produced, count, local[slot][:count])
+                    else:
+                        local[slot][:count].copy_(synthesize_piece(produced, count))
+                except Exception as error:  # pylint: disable=broad-except
+                    failure = error
+                produced += count
+            exchanges += 1
             try:
-                if writes_into:
-                    synthesize_piece(produced, count, local[slot][:count])
-                else:
-                    local[slot][:count].copy_(synthesize_piece(produced, count))
-            except Exception as error:  # pylint: disable=broad-except
-                failure = error
-            produced += count
-        try:
-            exchange_status(failure is not None, f"synthesising chunk {chunk}")
-        except StreamRankError:
-            if failure is None:
+                exchange_status(failure is not None, f"synthesising chunk {chunk}")
+            except StreamRankError:
+                settled = True
+                if failure is None:
+                    raise
+            except Exception:  # (the exchange itself failed: a dead rank, a timeout -- nothing more can be relayed)
+                settled = True
                 raise
-        if failure is not None:
-            raise failure
-        if world_size > 1:
-            works[slot] = dist.gather(local[slot], gather_list=list(gathered[slot].chunk(world_size, dim=0)) if rank == 0 else None, dst=0, async_op=True)
-        if reader_stream is not None:
-            issued[slot] = torch.cuda.Event()
-            issued[slot].record(torch.cuda.current_stream(device))
-        if rank == 0 and chunk >= 1:
-            yield hand_out(chunk - 1)
-    if rank == 0 and chunks >= 1:
-        yield hand_out(chunks - 1)
-    for work in works:
-        if work is not None:
-            work.wait()
+            if failure is not None:
+                settled = True
+                raise failure
+            if world_size > 1 and not per_rank_drain:
+                works[slot] = dist.gather(local[slot], gather_list=list(gathered[slot].chunk(world_size, dim=0)) if rank == 0 else None, dst=0, async_op=True)
+            if reader_stream is not None:
+                issued[slot] = torch.cuda.Event()
+                issued[slot].record(torch.cuda.current_stream(device))
+            if hands_out and chunk >= 1:
+                piece = hand_out(chunk - 1)
+                if piece is not None:
+                    yield piece
+        settled = True
+        if hands_out and chunks >= 1:
+            piece = hand_out(chunks - 1)
+            if piece is not None:
+                yield piece
+    finally:
+        if not settled and exchanges < chunks:
+            # the consumer failed or dropped the generator between two chunks: the other ranks are on their way into the
+            # next status exchange -- tell them there, instead of letting them wait for a word that never comes
+            try:
+                exchange_status(True, "consuming the stream", consumer=True)
+            except Exception:  # pylint: disable=broad-except
+                pass
+        for work in works:
+            if work is not None:
+                work.wait()
 
 
 class HostRing:
@@ -327,18 +384,22 @@ class HostRing:
         return self._finish()
 
 
-def ordered_frame_stream(synthesize_piece, num_frames: int, frames_per_rank: int, frame_shape: Tuple[int, int, int], device: torch.device):
+def ordered_frame_stream(
+    synthesize_piece, num_frames: int, frames_per_rank: int, frame_shape: Tuple[int, int, int], device: torch.device, drain: str = "rank0"
+):
     """
     `ordered_device_chunks` drained to the host (collective: every rank must exhaust it). On rank 0 it yields
     (first_frame_index, frames) per chunk, in frame order, `frames` a uint8 numpy view of a pinned host ring slot
     [n, *frame_shape] that stays valid until the generator is advanced twice more; other ranks yield nothing.
     Chunk k's gather and host drain overlap chunk k+1's synthesis. HBM holds two chunks, the host three.
+    With `drain="per-rank"` every rank yields its OWN pieces (first_frame_index of the piece, frames), drained over its
+    own PCIe link to its own pinned ring; no gather runs.
     """
     world_size = dist.get_world_size() if dist.is_initialized() else 1
     ring = None
-    for first, frames, reader_stream in ordered_device_chunks(synthesize_piece, num_frames, frames_per_rank, frame_shape, device):
+    for first, frames, reader_stream in ordered_device_chunks(synthesize_piece, num_frames, frames_per_rank, frame_shape, device, drain=drain):
         if ring is None:
-            ring = HostRing(world_size * frames_per_rank, frame_shape, device)
+            ring = HostRing(frames_per_rank if drain == "per-rank" else world_size * frames_per_rank, frame_shape, device)
         done = ring.push(first, frames, reader_stream)
         if done is not None:
             yield done

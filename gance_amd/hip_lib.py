@@ -291,11 +291,10 @@ class Engine:
         :param up_form: Conv0_up layers with an input >= 64 wide: "auto" = one fused kernel (transposed conv +
         FIR + noise + bias + leaky ReLU) when the launch fills the chip, else two passes; "split" = always two
         passes; "fused" = the fused kernel whatever the batch.
-        :param conv_form: "auto" = Winograd F(2x2,3x3) for the stride-1 convs of the >= 64x64 layers
-        when a launch has at least one block per CU, else the direct form; "direct" = never Winograd;
-        "winograd" = Winograd on every layer that supports it, whatever the batch; "winograd43" = the same with the
-        F(4x4,3x3) kernel on every Conv1 from 64x64 up that it supports (the default uses it up to the resolution where
-        it measured faster).
+        :param conv_form: "auto" = every Conv1 from 32x32 up in Winograd F(4x4,3x3) form when its launch has a tile per
+        CU, else F(2x2,3x3) when that launch has a block per CU, else the direct form; "direct" = never Winograd;
+        "winograd" = the F(2x2,3x3) kernels on every layer that supports them, whatever the batch; "winograd43" = the
+        F(4x4,3x3) kernel on every Conv1 from 32x32 up (F(2x2,3x3) on what is left), whatever the batch.
         """
         self._lib = load_library()
         self._handle = ctypes.c_void_p()

@@ -25,6 +25,7 @@ from typing import Callable, Dict, List, NamedTuple, Optional, Union
 
 import numpy as np
 import pydantic
+import torch
 from pydantic import BaseModel, FilePath
 from typing_extensions import Protocol
 
@@ -70,7 +71,10 @@ class NetworkInterfaceInProcess(NamedTuple):
 class LoadedNetwork:
     """One generator resident in HBM and its image functions (single and batched)."""
 
-    def __init__(self, network_path: Path, max_batch: int = DEFAULT_MAX_BATCH, device: int = DEFAULT_DEVICE) -> None:
+    def __init__(self, network_path: Path, max_batch: int = DEFAULT_MAX_BATCH, device: Optional[int] = None) -> None:
+        """`device` None: the process's current GPU (one process per GPU: `torch.cuda.set_device(LOCAL_RANK)` decides)."""
+        if device is None:
+            device = torch.cuda.current_device() if torch.cuda.is_available() else DEFAULT_DEVICE
         loaded = network_file.load_network(network_path)  # RuntimeError if not loadable
         self.network_path = network_path
         self.engine = hip_lib.Engine(loaded.variables, loaded.resolution, max_batch=max_batch, device=device)
@@ -178,9 +182,15 @@ class MultiNetwork:
     network files are resident at once; an index change is a dictionary lookup.
     """
 
-    def __init__(self: "MultiNetwork", network_paths: List[Path], load: bool = False, max_batch: int = DEFAULT_MAX_BATCH) -> None:
-        """`max_batch` (not in the reference): frames per engine call of the batched entry points."""
+    def __init__(
+        self: "MultiNetwork", network_paths: List[Path], load: bool = False, max_batch: int = DEFAULT_MAX_BATCH, device: Optional[int] = None
+    ) -> None:
+        """
+        `max_batch` (not in the reference): frames per engine call of the batched entry points; `device` (not in the
+        reference): the GPU the networks live on, default the process's current one.
+        """
         self._max_batch = max_batch
+        self._device = device
         self._network_paths: List[Path] = network_paths
         self._loaded: Optional[Dict[Path, LoadedNetwork]] = None
         self._expected_vector_length: Optional[int] = None
@@ -214,7 +224,7 @@ class MultiNetwork:
             for path in self._network_paths:
                 if path not in loaded:
                     LOGGER.info(f"Loading network: {path}")
-                    loaded[path] = LoadedNetwork(path, max_batch=self._max_batch)
+                    loaded[path] = LoadedNetwork(path, max_batch=self._max_batch, device=self._device)
         except Exception:
             for network in loaded.values():
                 network.stop()

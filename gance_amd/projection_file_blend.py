@@ -16,9 +16,10 @@ projection-file-blend end to end: WAV(s) + projection file + network(s) -> frame
   NotImplementedError.
 """
 
+import os
 import time
 from pathlib import Path
-from typing import Dict, Iterator, List, NamedTuple, Optional, Tuple
+from typing import Callable, Dict, Iterator, List, NamedTuple, Optional, Tuple
 
 import numpy as np
 import pandas as pd
@@ -474,6 +475,8 @@ def projection_file_blend_frame_chunks(  # pylint: disable=too-many-arguments,to
     overlay: Optional[OverlayParameters] = None,
     networks: Optional[MultiNetwork] = None,
     timings: Optional[Dict[str, object]] = None,
+    drain: str = "rank0",
+    on_total: Optional[Callable[[int], None]] = None,
 ) -> Iterator[Tuple[int, int, np.ndarray]]:
     """
     The frame stream of the reference's pipeline (gance/projection_file_blend.py:343 hands an iterator of frames to
@@ -487,7 +490,19 @@ def projection_file_blend_frame_chunks(  # pylint: disable=too-many-arguments,to
     fails, every rank leaves the generator with an exception (frame_sharding.exchange_status).
     :param networks: networks already resident (not unloaded at the end); default: load `network_paths`, unload after.
     :param timings: if given, rank 0 records the wall-clock split of the call there (milliseconds).
+    :param drain: "rank0" (default): the RCCL gather lands every chunk on rank 0, which alone receives chunks -- for
+    consumers of the ordered stream in one place (the overlay stage; an encoder fed by rank 0). "per-rank": no gather; EVERY
+    rank receives its own pieces (first_frame_index of the piece, total, frames) and drains them over its own PCIe link
+    into its own pinned ring -- for host-bound legs: at 2160^2 a frame is 14 MB, one link sustains ~57 GB/s pinned,
+    i.e. ~4 000 frames/s through rank 0 alone, less than four GPUs synthesise. Not with `overlay`
+    (its run-length filter needs the ordered stream in one place).
+    :param on_total: called once on every rank with the total frame count as soon as it is known, rank 0 first and the
+    other ranks after rank 0's call has returned (so rank 0 can create an output file the others then open).
     """
+    if drain not in frame_sharding.DRAIN_MODES:
+        raise ValueError(f"drain must be one of {frame_sharding.DRAIN_MODES}, got {drain!r}")
+    if drain == "per-rank" and overlay is not None:
+        raise ValueError("the eye-tracking overlay needs the ordered stream on rank 0: drain=\"rank0\"")
     rank = dist.get_rank() if dist.is_initialized() else 0
     world_size = dist.get_world_size() if dist.is_initialized() else 1
     device = torch.device("cuda", torch.cuda.current_device())
@@ -517,6 +532,22 @@ def projection_file_blend_frame_chunks(  # pylint: disable=too-many-arguments,to
             count = [num_frames]
             dist.broadcast_object_list(count, src=0)
             num_frames = count[0]
+        if on_total is not None:
+            failure = None
+            if rank == 0:
+                try:
+                    on_total(num_frames)
+                except Exception as error:  # pylint: disable=broad-except
+                    failure = error
+            try:
+                frame_sharding.exchange_status(failure is not None, "preparing the output")
+            except frame_sharding.StreamRankError:
+                if failure is None:
+                    raise
+            if failure is not None:
+                raise failure
+            if rank != 0:
+                on_total(num_frames)
         clock = time.perf_counter()
         dlatents = frame_sharding.scatter_for_stream(inputs.dlatents, num_frames, frames_per_call, device)
         indices = frame_sharding.scatter_for_stream(inputs.indices, num_frames, frames_per_call, device)
@@ -536,9 +567,11 @@ def projection_file_blend_frame_chunks(  # pylint: disable=too-many-arguments,to
             stage = _StreamingOverlay(inputs.target_images, inputs.frame_multiplier, overlay, skip_mask, num_frames, side, device)
         ring = None
         bytes_to_host = 0
-        for first, frames, reader_stream in frame_sharding.ordered_device_chunks(synthesize_piece, num_frames, frames_per_call, (side, side, 3), device):
+        for first, frames, reader_stream in frame_sharding.ordered_device_chunks(
+            synthesize_piece, num_frames, frames_per_call, (side, side, 3), device, drain=drain
+        ):
             if ring is None:
-                ring = frame_sharding.HostRing(world_size * frames_per_call, (side, side, 3), device, slots=3)
+                ring = frame_sharding.HostRing((1 if drain == "per-rank" else world_size) * frames_per_call, (side, side, 3), device, slots=3)
             if stage is None:
                 ready = [(first, frames)]
             else:
@@ -563,7 +596,7 @@ def projection_file_blend_frame_chunks(  # pylint: disable=too-many-arguments,to
             if last is not None:
                 yield last[0], num_frames, last[1]
         torch.cuda.synchronize(device)
-        if timings is not None and rank == 0:
+        if timings is not None and (rank == 0 or drain == "per-rank"):
             elapsed = time.perf_counter() - clock
             timings["synthesis_to_host_ms"] = elapsed * 1e3
             timings["frames"] = num_frames
@@ -635,6 +668,7 @@ def projection_file_blend_api(  # pylint: disable=too-many-arguments,too-many-lo
     phash_distance: Optional[int],
     bbox_distance: Optional[float],
     track_length: Optional[int],
+    drain: Optional[str] = None,
 ) -> None:
     """
     Same parameter list as the reference API (gance/projection_file_blend.py:56-76). Frames are
@@ -643,7 +677,11 @@ def projection_file_blend_api(  # pylint: disable=too-many-arguments,too-many-lo
     non-integer fps ratio).
     :raises NotImplementedError: debug video requested (out of scope), or the overlay requested
     without a landmark detector (face_recognition / dlib is not installed; see overlay_eye_tracking).
+    :param drain: (not a parameter of the reference) how frames reach the output file under `torch.distributed`:
+    "rank0" = gathered over RCCL and written by rank 0; "per-rank" = every rank writes the pieces it synthesised into
+    the same memory-mapped file over its own PCIe link. Default: GANCE_STREAM_DRAIN, else "rank0"; the overlay forces "rank0".
     """
+    drain = drain or os.environ.get("GANCE_STREAM_DRAIN", "rank0")
     overlay_enabled = all(param is not None for param in (phash_distance, bbox_distance, track_length))
     overlay_music_mask_enabled = all(
         param is not None for param in (complexity_change_rolling_sum_window, complexity_change_threshold)
@@ -659,20 +697,30 @@ def projection_file_blend_api(  # pylint: disable=too-many-arguments,too-many-lo
         if overlay_enabled
         else None
     )
+    if overlay is not None:
+        drain = "rank0"
     # frame chunks go straight from the pinned ring into the (memory-mapped) output file: nothing holds the video
-    writer = None
-    total_frames = 0
-    for first, total, frames in projection_file_blend_frame_chunks(
+    rank = dist.get_rank() if dist.is_initialized() else 0
+    state: Dict[str, object] = {"writer": None, "total": 0}
+
+    def open_output(total: int) -> None:
+        # rank 0 creates the file (the frame side is known up front: every frame is resized to output_side_length); with
+        # drain="per-rank" the other ranks then map the same file and write their own pieces into it
+        state["total"] = total
+        if output_path is None or (rank != 0 and drain != "per-rank"):
+            return
+        if rank == 0:
+            state["writer"] = np.lib.format.open_memmap(
+                _npy_path(output_path), mode="w+", dtype=np.uint8, shape=(total, output_side_length, output_side_length, 3)
+            )
+        elif total > 0:
+            state["writer"] = np.load(_npy_path(output_path), mmap_mode="r+")
+
+    for first, _total, frames in projection_file_blend_frame_chunks(
         wav, network_paths, frames_to_visualize, output_fps, output_side_length, alpha, fft_roll_enabled,
-        fft_amplitude_range, projection_file_path, blend_depth, overlay=overlay,
+        fft_amplitude_range, projection_file_path, blend_depth, overlay=overlay, drain=drain, on_total=open_output,
     ):
-        total_frames = total
-        if output_path is None:
-            continue
-        if writer is None:
-            writer = np.lib.format.open_memmap(_npy_path(output_path), mode="w+", dtype=np.uint8, shape=(total, *frames.shape[1:]))
-        writer[first : first + len(frames)] = frames
-    if writer is not None:
-        writer.flush()
-    elif output_path is not None and total_frames == 0 and (not dist.is_initialized() or dist.get_rank() == 0):
-        np.save(_npy_path(output_path), np.empty((0, output_side_length, output_side_length, 3), dtype=np.uint8))
+        if state["writer"] is not None:
+            state["writer"][first : first + len(frames)] = frames
+    if state["writer"] is not None:
+        state["writer"].flush()

@@ -47,10 +47,11 @@ typedef struct gance_engine_config {
 } gance_engine_config;
 
 #define GANCE_FLAG_PROFILE_STEPS 1 /* record a hipEvent pair around every kernel launch        */
-/* The stride-1 3x3 convs of the >= 64x64 layers run in Winograd F(2x2,3x3) form (4/9 of the multiply-adds;
- * results differ from the direct form by fp32 rounding only, ~1e-6 relative) whenever a launch has at
- * least one block per CU. DIRECT_CONV keeps every layer in direct form; FORCE_WINOGRAD drops the
- * block-count condition (small batches: slower, used by the parity tests). */
+/* The Conv1 layers from 32x32 up run in Winograd form whenever a launch has at least one tile per CU: F(4x4,3x3) (1/4 of
+ * the multiply-adds) where the launch fills the chip with its 16 x 64 pixel tiles, else F(2x2,3x3) (4/9), else the direct
+ * form; results differ between the forms by fp32 rounding only (~1e-6 of the activation range). DIRECT_CONV keeps every
+ * layer in direct form; FORCE_WINOGRAD alone puts every layer that supports it on the F(2x2,3x3) kernels whatever the
+ * batch, FORCE_WINOGRAD | WINOGRAD43 on the F(4x4,3x3) kernel where that supports the layer (parity tests of each form). */
 #define GANCE_FLAG_DIRECT_CONV 2
 #define GANCE_FLAG_FORCE_WINOGRAD 4
 /* Conv0_up of the layers whose input is >= 64 wide runs as ONE kernel (transposed conv + FIR + noise + bias +
@@ -64,7 +65,7 @@ typedef struct gance_engine_config {
  * Calls that share it are ordered by an event, on whatever streams they run. PRIVATE_WORKSPACE gives an engine
  * its own (calls of different engines may then overlap on different streams). */
 #define GANCE_FLAG_PRIVATE_WORKSPACE 32
-#define GANCE_FLAG_WINOGRAD43 64 /* Conv1 layers from 32x32 up in Winograd F(4x4,3x3) form wherever the kernel supports the layer */
+#define GANCE_FLAG_WINOGRAD43 64 /* with FORCE_WINOGRAD: Conv1 layers from 32x32 up in Winograd F(4x4,3x3) form wherever the kernel supports the layer */
 
 /*
  * Load a network. Replaces load_network_network + wrap_loaded_network

@@ -198,3 +198,79 @@ def test_ordered_frame_stream_without_a_process_group(num_frames: int, per_call:
         assert first == len(got)
         got.extend(int(frame[0, 0, 0]) for frame in frames.copy())
     assert got == [f % 251 for f in range(num_frames)]
+
+
+def _per_rank_stream_worker(rank: int, world_size: int, port: int, num_frames: int, per_rank: int, results) -> None:
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world_size)
+    try:
+        device = torch.device("cpu")
+        all_inputs = torch.arange(num_frames, dtype=torch.float32).reshape(num_frames, 1) if rank == 0 else None
+        mine = frame_sharding.scatter_for_stream(all_inputs, num_frames, per_rank, device)
+
+        class Producer:  # pylint: disable=too-few-public-methods
+            writes_into = True
+
+            def __call__(self, offset: int, count: int, out: torch.Tensor) -> None:
+                values = (mine[offset : offset + count, 0].to(torch.int64) % 251).to(torch.uint8)
+                out.copy_(values.reshape(count, 1, 1, 1).expand(count, 2, 2, 3))
+
+        got = {}
+        firsts = []
+        for first, frames in frame_sharding.ordered_frame_stream(Producer(), num_frames, per_rank, (2, 2, 3), device, drain="per-rank"):
+            firsts.append(first)
+            for i, frame in enumerate(frames):
+                assert bool((frame == frame[0, 0, 0]).all())
+                got[first + i] = int(frame[0, 0, 0])
+        assert firsts == sorted(firsts)
+        # every rank received exactly the frames of its own stream order, each with its own value
+        assert sorted(got) == frame_sharding.stream_order(num_frames, world_size, per_rank, rank)
+        assert all(value == index % 251 for index, value in got.items())
+        results[rank] = sorted(got)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world_size,num_frames,per_rank", [(2, 37, 4), (3, 50, 3), (2, 3, 4)])
+def test_per_rank_drain_hands_every_rank_its_own_pieces(world_size: int, num_frames: int, per_rank: int) -> None:
+    """`drain="per-rank"`: no gather; every rank drains the pieces it synthesised; together they are every frame once."""
+    manager = mp.Manager()
+    results = manager.dict()
+    mp.spawn(_per_rank_stream_worker, args=(world_size, _free_port(), num_frames, per_rank, results), nprocs=world_size, join=True)
+    assert sorted(sum((list(results[rank]) for rank in range(world_size)), [])) == list(range(num_frames))
+
+
+def _failing_consumer_worker(rank: int, world_size: int, port: int, results) -> None:
+    import datetime  # pylint: disable=import-outside-toplevel
+    import time  # pylint: disable=import-outside-toplevel
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world_size, timeout=datetime.timedelta(seconds=60))
+    try:
+        def synthesize_piece(offset: int, count: int) -> torch.Tensor:
+            return torch.zeros((count, 2, 2, 3), dtype=torch.uint8)
+
+        outcome = "finished"
+        start = time.perf_counter()
+        try:
+            for index, _ in enumerate(frame_sharding.ordered_frame_stream(synthesize_piece, 40, 4, (2, 2, 3), torch.device("cpu"))):
+                if index == 1:
+                    raise KeyError("the consumer of rank 0 failed")  # (the overlay stage, the writer, ...)
+        except frame_sharding.StreamRankError as error:
+            outcome = f"relayed: {error}"
+        except KeyError:
+            outcome = "own"
+        results[rank] = (outcome, time.perf_counter() - start)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_a_failing_consumer_on_rank_0_ends_the_stream_on_the_other_ranks_promptly() -> None:
+    """Rank 0's consumer raises between two chunks: the other rank leaves in its next status exchange, not after the group's timeout."""
+    manager = mp.Manager()
+    results = manager.dict()
+    mp.spawn(_failing_consumer_worker, args=(2, _free_port(), results), nprocs=2, join=True)
+    assert results[0][0] == "own", dict(results)
+    assert results[1][0].startswith("relayed: rank 0 failed consuming the stream") and results[1][1] < 30.0, dict(results)

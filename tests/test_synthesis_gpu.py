@@ -266,7 +266,8 @@ def test_config_f_1024_at_the_batch_sizes_the_product_stream_issues(library) -> 
     not (engine.hip: conv_form_of, up_runs_fused, plan_layer). The product stream issues every batch size in [1, 64] at
     1024^2 (three networks: calls of ~21 frames; ragged window ends; a tail chunk of 8), so the frames are checked at
     such sizes, every term on: first and last frame of each batch against the same z alone (the one-frame call is
-    oracle-checked above), and for two of the sizes the last frame against the fp64 oracle as well. The launch names of
+    oracle-checked above), and for one of the sizes the last frame against the fp64 oracle as well (the 64-frame batch
+    is oracle-checked by test_bench_configuration_batch_64...). The launch names of
     every size are logged, and the test insists that the sizes really crossed the thresholds.
     """
     resolution = 1024
@@ -282,7 +283,7 @@ def test_config_f_1024_at_the_batch_sizes_the_product_stream_issues(library) -> 
             forms[batch] = _conv_forms(engine)
             _assert_same_frames(frames[0], alone[0])
             _assert_same_frames(frames[batch - 1], alone[batch - 1])
-            if batch in (21, 63):
+            if batch == 21:
                 last = slice(batch - 1, batch)
                 _check_frames(frames[last], image[last], ref.synthesize_z(z[last], variables, resolution, truncation_psi=1.2))
     finally:
@@ -450,7 +451,7 @@ res = int(sys.argv[1])
 spec = sg2_spec.make_spec(res)
 variables = sg2_spec.make_random_variables(res, seed=3, perturb=True)
 dlatents = np.random.RandomState(5).randn(2, spec.num_layers, 512).astype(np.float32)
-engine = hip_lib.Engine(variables, res, max_batch=2, conv_form="winograd", up_form=sys.argv[3])
+engine = hip_lib.Engine(variables, res, max_batch=2, conv_form=sys.argv[4], up_form=sys.argv[3])
 frames, image = engine.synthesize_w(dlatents, want_float=True)
 np.savez(sys.argv[2], frames=frames, image=image)
 """
@@ -482,7 +483,8 @@ def test_winograd_kernel_fallback_forms_agree_with_the_default(library, tmp_path
     for label, env_extra in (("default", {}), ("switched", {variable: off_value})):
         path = tmp_path / f"{label}.npz"
         env = dict(os.environ, PYTHONPATH=str(repo_root), **env_extra)
-        subprocess.run([sys.executable, "-c", _FORM_SCRIPT, "256", str(path), up_form], check=True, env=env, cwd=repo_root, timeout=300)
+        conv_form = "winograd43" if "W43" in variable else "winograd"  # (the F(4x4,3x3) kernel's switches need that kernel running)
+        subprocess.run([sys.executable, "-c", _FORM_SCRIPT, "256", str(path), up_form, conv_form], check=True, env=env, cwd=repo_root, timeout=300)
         outputs[label] = np.load(path)
     scale = float(np.abs(outputs["default"]["image"]).max())
     assert float(np.abs(outputs["switched"]["image"] - outputs["default"]["image"]).max()) < 5e-5 * max(1.0, scale)
@@ -530,7 +532,7 @@ def test_stress_network_256_layerwise_and_image(library, conv_form: str) -> None
 
 
 def test_stress_network_1024_batch_64_frame_on_the_default_kernels(library) -> None:
-    """The bench configuration's kernels (64 frames per call, auto selection) on the stress network: first and last frame vs the fp64 oracle."""
+    """The bench configuration's kernels (64 frames per call, auto selection) on the stress network: the last frame vs the fp64 oracle."""
     resolution, batch = 1024, 64
     variables = sg2_spec.make_stress_variables(resolution, seed=0)
     z = np.random.RandomState(1).randn(batch, 512).astype(np.float32)
@@ -539,7 +541,7 @@ def test_stress_network_1024_batch_64_frame_on_the_default_kernels(library) -> N
         frames, image = engine.synthesize_z(z, truncation_psi=1.2, want_float=True)
     finally:
         engine.close()
-    for i in (0, batch - 1):
+    for i in (batch - 1,):
         want = ref.synthesize_z(z[i : i + 1], variables, resolution, truncation_psi=1.2)
         scale = float(want.abs().max())
         err = float(np.abs(image[i : i + 1] - want.numpy()).max())

@@ -6,6 +6,8 @@ the same job on one rank. Launch from the shell, never from a process that has t
     python tools/rehearse_stream_ranks.py --prepare /tmp/rehearsal              # inputs + the 1-rank result
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29517 \
         tools/rehearse_stream_ranks.py --check /tmp/rehearsal                    # 2 ranks, compare
+    ... --check /tmp/rehearsal --drain per-rank    # no gather: every rank writes its own pieces into one memory-mapped
+                                                   # .npy through projection_file_blend_api (not with the overlay)
 
 The numbers of such a run mean nothing (the ranks share one GPU); it only shows that the scatter of per-chunk
 latent pieces, the chunked synthesis with resident networks, the ordered gather and the host drain give the
@@ -43,6 +45,31 @@ class BrightPicturesHaveAFace:  # pylint: disable=too-few-public-methods
         }]
 
 
+def job_per_rank(directory: Path):
+    """The API function with drain="per-rank": every rank writes the pieces it synthesised into one memory-mapped file."""
+    import torch  # pylint: disable=import-outside-toplevel
+    import torch.distributed as dist  # pylint: disable=import-outside-toplevel
+
+    from gance_amd import projection_file_blend  # pylint: disable=import-outside-toplevel
+
+    torch.cuda.set_device(0)
+    output = directory / "per_rank_drain.npy"
+    if dist.get_rank() == 0 and output.exists():
+        output.unlink()
+    dist.barrier()
+    projection_file_blend.projection_file_blend_api(
+        wav=[str(directory / "audio.wav")], output_path=str(output), network_paths=[directory / f"net_{i}.pkl" for i in range(NETWORKS)],
+        frames_to_visualize=None, output_fps=FPS_OUT, output_side_length=OUT_SIDE, debug_path=None, debug_window=None, debug_side_length=None,
+        alpha=0.25, fft_roll_enabled=True, fft_amplitude_range=(-5, 5), projection_file_path=str(directory / "projection.npz"), blend_depth=12,
+        complexity_change_rolling_sum_window=None, complexity_change_threshold=None, phash_distance=None, bbox_distance=None, track_length=None,
+        drain="per-rank",
+    )
+    dist.barrier()  # (every rank has flushed its pieces)
+    if dist.get_rank() != 0:
+        return None, []
+    return np.load(output), [0]
+
+
 def job(directory: Path):
     import torch  # pylint: disable=import-outside-toplevel
 
@@ -71,6 +98,7 @@ def main() -> int:
     parser = argparse.ArgumentParser()
     parser.add_argument("--prepare", type=Path)
     parser.add_argument("--check", type=Path)
+    parser.add_argument("--drain", choices=["rank0", "per-rank"], default="rank0")
     args = parser.parse_args()
     if args.prepare is not None:
         from scipy.io import wavfile  # pylint: disable=import-outside-toplevel
@@ -100,7 +128,7 @@ def main() -> int:
     dist.init_process_group(backend="gloo", timeout=datetime.timedelta(seconds=300))
     rank, world_size = dist.get_rank(), dist.get_world_size()
     start = time.perf_counter()
-    frames, firsts = job(args.check)
+    frames, firsts = job_per_rank(args.check) if args.drain == "per-rank" else job(args.check)
     elapsed = time.perf_counter() - start
     status = 0
     if rank == 0:
@@ -116,7 +144,7 @@ def main() -> int:
             same = worst <= (2 if OUT_SIDE != SIDE else 1) and differing < 1e-3  # (the bicubic resize can double a 1-LSB difference)
         ordered = firsts == sorted(firsts) and firsts[0] == 0
         print(
-            f"{world_size} ranks on one GPU over gloo, {SIDE}^2 -> {OUT_SIDE}^2, {NETWORKS} networks, {PER_CALL} frames per call, overlay {bool(OVERLAY)}: "
+            f"{world_size} ranks on one GPU over gloo, drain {args.drain}, {SIDE}^2 -> {OUT_SIDE}^2, {NETWORKS} networks, {PER_CALL} frames per call, overlay {bool(OVERLAY)}: "
             f"{0 if frames is None else frames.shape[0]} frames in {len(firsts)} ordered chunks "
             f"({elapsed:.2f} s incl. network loading), same frames as the single-rank run: {same} (max |diff| {worst} LSB on "
             f"{100.0 * differing:.4f} % of the values), chunk order ok: {ordered}"
