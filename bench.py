@@ -60,10 +60,8 @@ def usable_cores() -> int:
 
 def kernel_of_step(step_name: str) -> str:
     """The HIP kernel behind a conv launch of the engine's step table (names: engine.hip)."""
-    if step_name.startswith("convTFp"):
-        return "upfir_fused_pre_kernel"  # input pre-scaled by the Winograd launch before it
-    if step_name.startswith("convTF"):
-        return "upfir_fused_kernel"
+    if step_name.startswith("convTF"):  # ("p": input pre-scaled by the Winograd launch before it; "/16": the 16-channel geometry)
+        return ("upfir16_fused" if step_name.endswith("/16") else "upfir_fused") + ("_pre_kernel" if step_name.startswith("convTFp") else "_kernel")
     if step_name.startswith("convV"):
         narrow = "_32x32_" in step_name  # the 32 x 32 pixel geometry
         return ("winograd43_w32" if narrow else "winograd43") + ("_rgb_kernel" if "+rgb" in step_name else "_kernel")

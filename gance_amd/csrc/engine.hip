@@ -276,6 +276,7 @@ struct gance_engine {
     bool noise_randomized = false;
     std::vector<size_t> wino43_w;  // F(4x4, 3x3) weights (winograd43_conv.hip), SIZE_MAX where the layer does not take that form
     std::vector<size_t> upfir_w;  // fused transposed-conv + FIR kernel's weight image of the up layers that support it (else SIZE_MAX)
+    std::vector<size_t> upfir16_w;  // the same for its 16-channel, two-blocks-per-CU geometry (upfir16_fused.hip)
     int num_cus = 256;
     std::vector<float> conv_ns;
     std::vector<int> conv_s_off, conv_d_off;
@@ -354,6 +355,16 @@ struct FusedRgb {
     float* y;
     uint8_t* u8;
 };
+
+// Geometry of the fused up kernel: GANCE_TUNE_UPFIR16 (read once per process) = 0: always 32 channels per block, one block per
+// CU (upfir_fused.hip); 1: 16 channels per block, two blocks per CU (upfir16_fused.hip) wherever that kernel supports the layer.
+static int upfir16_mode() {
+    static const int mode = [] {
+        const char* v = std::getenv("GANCE_TUNE_UPFIR16");
+        return v ? std::atoi(v) : 1;
+    }();
+    return mode;
+}
 
 // Largest resolution whose Conv1 runs in Winograd F(4x4, 3x3) form (winograd43_conv.hip) in an engine with these
 // flags: GANCE_FLAG_WINOGRAD43 = every resolution the kernel supports; otherwise the default limit, which
@@ -589,7 +600,10 @@ int synthesize_from_dlat(gance_engine* e, const float* d_dlat, int B, uint8_t* d
         if (!c.up || upfir_mode == 0 || e->upfir_w[idx] == SIZE_MAX) return false;
         gance::UpFirArgs u{};
         u.Cin = c.cin;
-        gance::upfir_plan(B, c.cout, H, H, e->num_cus, &u);
+        if (e->upfir16_w[idx] != SIZE_MAX)
+            gance::upfir16_plan(B, c.cout, H, H, e->num_cus, &u);
+        else
+            gance::upfir_plan(B, c.cout, H, H, e->num_cus, &u);
         const int steps_per_seg = u.rows_per_seg / 8;
         if (plan != nullptr) *plan = u;
         return upfir_mode == 2 || (u.total_blocks >= e->num_cus * 3 / 4 && (u.segs == 1 || steps_per_seg >= 4));
@@ -684,8 +698,9 @@ int synthesize_from_dlat(gance_engine* e, const float* d_dlat, int B, uint8_t* d
             {
                 gance::UpFirArgs u{};
                 if (up_runs_fused(li, &u)) {
+                    const bool geometry16 = e->upfir16_w[li] != SIZE_MAX;
                     u.x = x_in;
-                    u.w = e->pool + e->upfir_w[li];
+                    u.w = e->pool + (geometry16 ? e->upfir16_w[li] : e->upfir_w[li]);
                     u.s = e->ws->styles + e->conv_s_off[li];
                     u.d = e->ws->demod + e->conv_d_off[li];
                     u.noise = noise;
@@ -704,12 +719,14 @@ int synthesize_from_dlat(gance_engine* e, const float* d_dlat, int B, uint8_t* d
                     u.s_next = s_next;
                     u.input_prescaled = input_prescaled ? 1 : 0;
                     // ("convTFp": upfir_fused_pre_kernel, the input arrives multiplied by this layer's style)
-                    std::snprintf(name, sizeof(name), input_prescaled ? "convTFp%d_%dx%d_%d->%d" : "convTF%d_%dx%d_%d->%d", c.layer_idx, res, res, c.cin, c.cout);
+                    // (a trailing "/16": the 16-channel, two-blocks-per-CU geometry, upfir16_fused*_kernel)
+                    std::snprintf(name, sizeof(name), input_prescaled ? "convTFp%d_%dx%d_%d->%d%s" : "convTF%d_%dx%d_%d->%d%s", c.layer_idx, res, res, c.cin,
+                                  c.cout, geometry16 ? "/16" : "");
                     {
                         const double flops = 2.0 * 9 * (double)c.cin * c.cout * H * W * B;
                         const double bytes = 4.0 * ((double)B * c.cin * H * W + (double)B * c.cout * res * res + 9.0 * c.cin * c.cout);
                         StepScope scope(e, stream, name, flops, bytes);
-                        GANCE_HIP_CHECK(gance::launch_upfir_fused(u, stream));
+                        GANCE_HIP_CHECK(geometry16 ? gance::launch_upfir16_fused(u, stream) : gance::launch_upfir_fused(u, stream));
                     }
                     x_in = x_out;
                     x_b_stride = out_b;
@@ -1056,6 +1073,13 @@ int gance_engine_create(const gance_engine_config* config, const float* host_wei
             for (size_t j = 0; j < wn; ++j) scaled[j] = src[j] * coef;
             e->upfir_w[i] = reserve(gance::upfir_weight_floats(c.cin, c.cout));
             gance::upfir_arrange_weights(scaled.data(), c.cin, c.cout, kUpTapWeight, &pool[e->upfir_w[i]]);
+        }
+        e->upfir16_w.push_back(SIZE_MAX);
+        if (c.up && upfir16_mode() != 0 && gance::upfir16_supported(c.cin, c.cout, (1 << c.res_log2) / 2, (1 << c.res_log2) / 2)) {
+            std::vector<float> scaled(wn);
+            for (size_t j = 0; j < wn; ++j) scaled[j] = src[j] * coef;
+            e->upfir16_w[i] = reserve(gance::upfir16_weight_floats(c.cin, c.cout));
+            gance::upfir16_arrange_weights(scaled.data(), c.cin, c.cout, kUpTapWeight, &pool[e->upfir16_w[i]]);
         }
         src += wn;
         demod_layers[i] = {(long long)w2_cursor, e->conv_s_off[i], e->conv_d_off[i], c.cin, c.cout};

@@ -203,6 +203,14 @@ void upfir_arrange_weights(const float* w_in /*[9][cin][cout] scaled*/, int cin,
 void upfir_plan(int B, int cout, int H, int W, int num_cus, UpFirArgs* args);
 hipError_t launch_upfir_fused(const UpFirArgs& args, hipStream_t stream);
 
+// The same layer with 16 output channels per block and two blocks per CU (upfir16_fused.hip): w points at
+// [m tile of 16][chunk of 8][1280 floats]; the plan gives every CU two blocks before it cuts row segments.
+bool upfir16_supported(int cin, int cout, int H, int W);
+size_t upfir16_weight_floats(int cin, int cout);
+void upfir16_arrange_weights(const float* w_in /*[9][cin][cout] scaled*/, int cin, int cout, const int* up_tap_weight, float* w_out);
+void upfir16_plan(int B, int cout, int H, int W, int num_cus, UpFirArgs* args);
+hipError_t launch_upfir16_fused(const UpFirArgs& args, hipStream_t stream);
+
 // ---- aux_kernels.hip ----
 
 // Mapping network: one dense 512->512 layer with lrelu*sqrt2 (G_mapping DenseN).

@@ -1,0 +1,614 @@
+// Conv0_up in ONE kernel, second geometry (round 4): 16 output channels per block, TWO blocks per CU.
+//
+// Same layer, same decomposition and same layout contracts as upfir_fused.hip (read its header first): stride-2 transposed
+// modulated 3x3 convolution as four parity classes on the fp32 matrix cores, [1,3,3,1] x [1,3,3,1] FIR, noise, bias, leaky
+// ReLU, one launch, the (2H+1)^2 intermediate T never in HBM; a block sweeps a strip of 64 position columns top to bottom in
+// steps of 8 position rows, the two halo position columns are one extra tile, the last three T rows of a step are carried in
+// LDS. Replaces, for the reference's synthesis call (gance/network_interface/network_functions.py:168), the un-vendored
+// `upsample_conv_2d` + `fused_bias_act` pair.
+//
+// What is different, and why. upfir_fused.hip holds 32 channels x 8 x 64 positions x 4 classes = 256 accumulator registers per
+// lane: one wave per SIMD, one block per CU, and whatever a wave does besides MFMAs -- the FIR epilogue (a fifth of a step at
+// 1024^2), the accumulator dump, barriers, LDS latencies -- leaves the matrix pipe idle (0.59 of the roof at 1024^2, flat for
+// two rounds). Nothing inside one block can overlap them: the tile's results (262 KB per step) have nowhere to wait while the
+// next K loop runs. Two INDEPENDENT blocks per CU can: while one filters and stores, the other multiplies. That needs half the
+// registers and half the LDS per block:
+//   * 16 channels per block on v_mfma_f32_16x16x4_f32: 8 position tiles of 16 x 4 classes = 32 accumulator tiles of 4
+//     registers = 128 per lane; a wave owns position rows w and w + 4 of the step (so that each HALF of the step holds one
+//     row of every wave). A = weights (lane: channel slot m = lane % 16, input channel k = lane / 16), B = patch (lane:
+//     input channel k, position n = lane % 16). MFMA row m = 4 q + r holds channel 4 r + q of the block (the host permutes
+//     the weight image): accumulator REGISTER r of every lane is then channel group r, and the epilogue pass of channel
+//     group g dumps register g of all 64 lanes (lane quarter q = channel g * 4 + q) -- full lanes, no register shuffles.
+//   * LDS 77 KB: ring of two slots (weights [9][8][16] padded to 5 KB + haloed patch [8][9][72] = 25 KB each), carry
+//     [16][3][132], and the T window of an epilogue pass -- 4 channels x 8 T rows x 132 = 17 KB -- lying over the ring slot
+//     that is idle after an even number of chunks. A step's epilogue is therefore EIGHT passes: two halves of four position
+//     rows x four channel groups; thread (wave = channel of the pass, column group of 4, row group of 4 output rows) filters
+//     a 7-row window (rows 0..2 of the upper row group come from the carry).
+//   * the noise tile does not fit: the FIR threads load their noise rows from HBM, one pass ahead (the loads of pass p + 1
+//     are issued before the stores of pass p: gfx9 has ONE vector-memory counter, a load behind a store waits for it).
+//   * no block is special: nothing depends on which waves share a SIMD.
+// The halo tile (16 slots x 16 channels) is one more 16x16x4 tile whose four classes are split over the four waves, as before.
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdlib>
+#include <type_traits>
+
+#include "kernels.h"
+
+// Timing ablations (GANCE_DEBUG_UPFIR: 1 no stores, 2 no epilogue, 4 no MFMA, 8 no DMA after the first chunk, 16 no
+// accumulator dump into the T window, 32 no FIR rows, 64 no barrier per chunk, 128 no operand reads in the K loop) exist only in a -DGANCE_UPFIR16_DEBUG=1 build (Makefile target
+// upfir16dbg): wrong results, and their uniform branches cost scalar registers.
+#ifndef GANCE_UPFIR16_DEBUG
+#define GANCE_UPFIR16_DEBUG 0
+#endif
+#define UPFIR16_DBG (GANCE_UPFIR16_DEBUG ? p.debug_flags : 0)
+
+namespace gance {
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+
+constexpr int kTH = 8;                    // position rows per step
+constexpr int kSW = 64;                   // position columns per strip
+constexpr int kBM = 16;                   // output channels per block
+constexpr int kKC = 8;                    // input channels per chunk (two k-steps of the 16x16x4 MFMA)
+constexpr int kPH = kTH + 1;              // patch rows: input rows y0-1 .. y0+7
+constexpr int kPW = kSW + 8;              // patch columns: input columns X0-4 .. X0+67
+constexpr int kPlane = kPH * kPW;         // 648
+constexpr int kWlPieces = 5;              // 1 KiB DMA pieces (the image is padded to 1280 floats in HBM and in LDS)
+constexpr int kWlRegion = kWlPieces * 256;
+constexpr int kPlFloats = kKC * kPlane;   // 5184
+constexpr int kPlF4 = kPlFloats / 4;      // 1296
+constexpr int kPlPieces = 21;             // the last one a quarter full
+constexpr int kPieces = kWlPieces + kPlPieces;        // 26
+constexpr int kPiecesPerWave = (kPieces + 3) / 4;     // 7
+constexpr int kSlot = kWlRegion + kPlFloats;          // 6464 floats
+constexpr int kTW = 132;                              // T window row: T columns 2X0-1 .. 2X0+129 (+ pad)
+constexpr int kCarryRows = 3;
+constexpr int kCarryFloats = kBM * kCarryRows * kTW;  // 6336
+constexpr int kPassCh = 4;                            // channels per epilogue pass
+constexpr int kPassRows = kTH;                        // T rows per pass: four position rows
+constexpr int kStageFloats = kPassCh * kPassRows * kTW;  // 4224
+static_assert(kStageFloats <= kSlot, "the T window of a pass lies over the idle ring slot");
+constexpr float kSqrt2f = 1.4142135623730951f;
+
+// transposed-conv tap tables, in the order the weights are stored (engine.hip kUpTapWeight):
+// EE (0,0) (0,-1) (-1,0) (-1,-1) | EO (0,0) (-1,0) | OE (0,0) (0,-1) | OO (0,0); class = 2*py + px
+__host__ __device__ constexpr int tap_cls(int t) { return t < 4 ? 0 : (t < 6 ? 1 : (t < 8 ? 2 : 3)); }
+// shift of a tap: bit 1 = input row above (dy = -1), bit 0 = input column to the left (dx = -1)
+__host__ __device__ constexpr int tap_shift(int t) {
+    return ((t == 2 || t == 3 || t == 5) ? 2 : 0) + ((t == 1 || t == 3 || t == 7) ? 1 : 0);
+}
+
+// LDS hand-over between the waves of the block without __syncthreads: its fence would also drain the
+// vector-memory counter, i.e. wait for every output store of the previous pass
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+
+// The lane id, computed where it is used: per-lane values derived once at kernel entry would stay live across the K loop, where
+// every register is taken (128 accumulators + two sets of operand fragments); hipcc then spills INSIDE the loop, and a scratch
+// reload there is a vector-memory load whose wait drains the LDS-DMA ring. The epilogue re-derives its per-lane values from this.
+__device__ __forceinline__ int fresh_lane() {
+    int l;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+    return l;
+}
+
+}  // namespace
+
+// LDS (floats): ring slot 0 | ring slot 1 = T window of a pass | carry | style [Cin] | demod [16] | bias [16] | next style [16]
+constexpr int kStageOff16 = kSlot;
+constexpr int kCarryOff16 = 2 * kSlot;
+constexpr int kConstOff16 = kCarryOff16 + kCarryFloats;
+size_t upfir16_lds_bytes(int cin) { return sizeof(float) * ((size_t)kConstOff16 + cin + 3 * kBM); }
+
+// kNoise: the layer adds noise (a compile-time form: as a run-time flag the four selects per output row stayed in the no-noise path)
+template <bool kPre, bool kNoise>
+__device__ __forceinline__ void upfir16_body(const UpFirArgs& p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* const ring0 = smem;
+    float* const stage = smem + kStageOff16;    // [4 ch][8 rows][132], over ring slot 1
+    float* const carry = smem + kCarryOff16;    // [16 ch][3 rows][132]
+    float* const s_lds = smem + kConstOff16;    // style [Cin]
+    float* const d_lds = s_lds + (kPre ? 0 : p.Cin);  // demod [16] (the pre-scaled form keeps no style vector)
+    float* const b_lds = d_lds + kBM;           // bias [16]
+    float* const sn_lds = b_lds + kBM;          // the next layer's style of these 16 channels (or 1): rides on the leaky ReLU
+
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63;
+    const int n16 = lane & 15;  // MFMA: position of a tile (B operand, accumulator column) / channel slot (A operand)
+    const int q4 = lane >> 4;   // MFMA: input channel of a k-step (operands) / channel quarter (accumulator rows 4 q .. 4 q + 3)
+
+    // ---- block -> (sample, channel tile, strip, row segment); blocks of one XCD take contiguous ids so
+    // that the channel tiles of one strip (same input patch) and neighbouring strips share its L2 ----
+    int id;
+    {
+        const int v = blockIdx.x, nwg = p.total_blocks;
+        const int q = nwg >> 3, r = nwg & 7, xcd = v & 7;
+        id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (v >> 3);
+    }
+    const int m_tile = id % p.m_tiles;
+    id /= p.m_tiles;
+    const int strip = id % p.strips;
+    id /= p.strips;
+    const int seg = id % p.segs;
+    const int b = id / p.segs;
+    const int m0 = m_tile * kBM;
+    const int X0 = strip * kSW;
+    const int H = p.H, W = p.W;
+    const int Hp = H + 2, Wp = W + 8;
+    const int y_begin = seg * p.rows_per_seg;
+    const int y_end = min(H, y_begin + p.rows_per_seg);
+    // steps: one priming step above a segment that does not start at the image top (fills the carried T
+    // rows, emits nothing), the segment's own steps, and after the image's last rows one flush step on
+    // position row y' = H (T row 2H) that emits output rows 2H-2 and 2H-1
+    const int step_first = seg > 0 ? -1 : 0;
+    const int step_main = (y_end - y_begin) / kTH;
+    const int step_last = step_main + (y_end == H ? 1 : 0);  // exclusive
+    const int nchunks = p.Cin / kKC;
+
+    const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(p.w + (size_t)m_tile * nchunks * kWlRegion), 0, 0x7fffffff, 0x00020000);
+    // (bounded by the sample's tensor: the flush step stages patch rows below the buffer's last row -- rows it never reads
+    // from LDS; inside the tensor they are the next channel's first rows, behind its end they read as zeros instead of faulting)
+    const __amdgpu_buffer_rsrc_t x_rsrc =
+        __builtin_amdgcn_make_buffer_rsrc((void*)(p.x + (size_t)b * p.x_b_stride), 0, p.Cin * Hp * Wp * 4, 0x00020000);
+
+    // ---- LDS-DMA staging: pieces 0..4 = weight image, 5..25 = patch; wave w issues pieces w, w+4, ... ----
+    // Per-lane source byte offsets of this wave's patch pieces at patch row 0 = buffer row 0 (-1: none): constants of the
+    // kernel. The step being staged only moves the SCALAR offset (y_stage buffer rows): recomputing the offsets per step put
+    // their integer divisions -- hoisted by hipcc to the top of every chunk, operands reloaded from scratch -- into the K loop.
+    int poff[kPiecesPerWave];
+#pragma unroll
+    for (int r = 0; r < kPiecesPerWave; ++r) {
+        const int i = wave + 4 * r - kWlPieces;
+        const int f = i * 64 + lane;
+        poff[r] = -1;
+        if (i >= 0 && f < kPlF4) {
+            const int q = f % (kPW / 4);
+            const int row = (f / (kPW / 4)) % kPH;
+            const int c = f / (kPW / 4 * kPH);
+            poff[r] = ((c * Hp + row) * Wp + X0 + 4 * q) * 4;
+        }
+    }
+    int y_stage = 0;  // first patch row of the step being staged, as a buffer row (= image row y0 - 1, + 1 for the border)
+    auto stage_setup = [&](int y0) { y_stage = y0; };
+    // one DMA piece (r = 0..6 of this wave: piece g = wave + 4 r) of `chunk` into ring slot `buf`. Which kind a piece is is
+    // known at compile time except for r = 1 (g = 4 is the last weight piece, 5..7 are patch pieces) and r = 6 (g = 24, 25
+    // exist, 26, 27 do not); only piece 25 is partial (16 of its 64 lanes).
+    auto stage_piece = [&](auto rtag, int chunk, float* buf) {
+        constexpr int r = decltype(rtag)::value;
+        const int g = wave + 4 * r;
+        const bool weights = r < 1 || (r == 1 && wave == 0);
+        if (weights) {
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, (lds_ptr_t)(buf + g * 256), 16, (g * 256 + lane * 4) * 4,
+                                                     chunk * kWlRegion * 4, 0, 0);
+        } else if (r < 6 || wave < 2) {
+            if (r < 6 || poff[r] >= 0)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(x_rsrc, (lds_ptr_t)(buf + kWlRegion + (g - kWlPieces) * 256), 16, poff[r],
+                                                         (chunk * kKC * Hp + y_stage) * Wp * 4, 0, 0);
+        }
+    };
+    // (r is a constant wherever this is called from an unrolled loop: the switch folds away)
+    auto stage_piece_n = [&](int r, int chunk, float* buf) {
+        switch (r) {
+            case 0: stage_piece(std::integral_constant<int, 0>{}, chunk, buf); break;
+            case 1: stage_piece(std::integral_constant<int, 1>{}, chunk, buf); break;
+            case 2: stage_piece(std::integral_constant<int, 2>{}, chunk, buf); break;
+            case 3: stage_piece(std::integral_constant<int, 3>{}, chunk, buf); break;
+            case 4: stage_piece(std::integral_constant<int, 4>{}, chunk, buf); break;
+            case 5: stage_piece(std::integral_constant<int, 5>{}, chunk, buf); break;
+            default: stage_piece(std::integral_constant<int, 6>{}, chunk, buf); break;
+        }
+    };
+    auto stage_chunk = [&](int chunk, float* buf) {
+#pragma unroll
+        for (int r = 0; r < kPiecesPerWave; ++r) stage_piece_n(r, chunk, buf);
+    };
+
+    stage_setup(y_begin + kTH * step_first);
+    stage_chunk(0, ring0);
+
+    // ---- per-block constants and the zeroed carry ----
+    if constexpr (!kPre)
+        for (int i = tid; i < p.Cin; i += 256) s_lds[i] = p.s[(size_t)b * p.s_stride + i];
+    if (tid < kBM) {
+        d_lds[tid] = p.d[(size_t)b * p.d_stride + m0 + tid];
+        b_lds[tid] = p.bias[m0 + tid];
+        sn_lds[tid] = p.s_next != nullptr ? p.s_next[(size_t)b * p.s_stride + m0 + tid] : 1.0f;
+    }
+    for (int i = tid; i < kCarryFloats; i += 256) carry[i] = 0.f;
+
+    // ---- per-lane operand offsets (floats; lds_*: byte addresses in LDS of ring slot 0's fragments, shifted up / left by one patch
+    // row and column so that every tap shift is a non-negative immediate) ----
+    // A (weights): [tap][ci 0..7][channel slot 0..15]; lane (m = n16, k = q4) reads slot m of input channel 4 j + k
+    const int aoff = q4 * kBM + n16;
+    // B (patch) of main tile (half h, column tile ct): position row w + 4 h, columns 16 ct + n; interior at column + 4
+    const int boff = q4 * kPlane + (wave + 1) * kPW + n16 + 4;  // + 4 j kPlane + 4 h kPW - dy kPW + 16 ct - dx
+    // halo tile: slot n16: position row slot & 7, column -1 (slot < 8) or 64
+    const int boffh = q4 * kPlane + ((n16 & 7) + 1) * kPW + ((n16 >> 3) ? 64 : -1) + 4;
+    const unsigned lds_0 = (unsigned)(unsigned long long)(__attribute__((address_space(3))) float*)smem;
+    const unsigned lds_a = lds_0 + aoff * 4;
+    const unsigned lds_b = lds_0 + (kWlRegion + boff - kPW - 1) * 4;
+    const unsigned lds_h = lds_0 + (kWlRegion + boffh - kPW - 1) * 4;
+
+    const int OW = 2 * W, OWp = OW + 8;
+    const long long oplane = (long long)(2 * H + 2) * OWp;
+    // (the resource starts TWO ROWS ABOVE the block's first channel plane: a half's first window row lies two rows above the image
+    // in the image's first step, and both parts of a store's offset -- per-lane rows in the vector offset, the row of the unrolled
+    // loop in the scalar one -- must stay non-negative: a negative offset is a 4 GB jump, not a subtraction. Rows above the
+    // image are never stored.)
+    const __amdgpu_buffer_rsrc_t o_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(p.out + ((size_t)b * p.Cout + m0) * oplane - 2 * OWp), 0, 0x7fffffff, 0x00020000);
+    constexpr bool has_noise = kNoise;
+    // (the sample's noise plane [2H][2W] as a bounded resource: a row outside it reads as zeros instead of faulting)
+    const __amdgpu_buffer_rsrc_t nz_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(has_noise ? p.noise + (size_t)b * p.noise_b_stride : nullptr), 0, has_noise ? (2 * H) * (2 * W) * 4 : 0, 0x00020000);
+    const float ns2 = p.noise_strength * kSqrt2f;
+
+    int ring = 0;
+    bool landed = false;  // the chunk about to be consumed was already waited for (before the previous epilogue)
+    // One step; the flush form (position row y' = H only) is a separate instantiation so that the two K loops
+    // do not meet in one control-flow graph.
+    auto run_step = [&](auto flush_tag, const int si) {
+        constexpr bool kFlush = decltype(flush_tag)::value;
+        const int y0 = y_begin + kTH * si;
+        f32x4 acc[4][8];  // [class][tile: half h * 4 + column tile ct]
+        f32x4 acch = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int tl = 0; tl < 8; ++tl) acc[c][tl] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+        for (int k = 0; k < nchunks; ++k) {
+            if (!(k == 0 && landed)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (!(UPFIR16_DBG & 64)) __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            float* const cur_buf = ring0 + ring * kSlot;
+            float* const nxt_buf = ring0 + (ring ^ 1) * kSlot;
+            const unsigned ring_bytes = ring * (kSlot * 4);
+            // the next chunk of the stream (this step's k+1, or the first one of the next step): its seven DMA pieces
+            // are issued one at a time BETWEEN the MFMA groups below
+            int next_chunk = -1;
+            if (UPFIR16_DBG & 8) {
+            } else if (k + 1 < nchunks) {
+                next_chunk = k + 1;
+            } else if (si + 1 < step_last) {
+                stage_setup(y0 + kTH);
+                next_chunk = 0;
+            }
+            ring ^= 1;
+            const float* const Wl = cur_buf + aoff;
+            const float* const Pl = cur_buf + kWlRegion;
+
+            if (UPFIR16_DBG & 4) {
+                if (next_chunk >= 0) stage_chunk(next_chunk, nxt_buf);
+                continue;
+            }
+            if constexpr (!kFlush) {
+                // A chunk = two k-steps (input channels 4 j .. 4 j + 3) x two halves (tiles of the wave's position row w + 4 h): four
+                // groups of 36 MFMAs. The operands of group i + 1 -- the half's patch fragments at the four tap shifts (dx = 0 / -1 are
+                // neighbours in LDS: one ds_read2 per pair) and, per k-step, the nine weight fragments and the halo tile's
+                // fragments -- are read from LDS BEFORE the MFMAs of group i are issued: a wave issues in order, so the reads'
+                // latency passes under its own 1 152 matrix cycles (the other block's wave fills what is left; alone on the SIMD,
+                // while that one filters, this wave must not stall at every group).
+                // The reads are single ds_read_b32 from THREE base registers per chunk (weights, patch, halo slot) with the
+                // fragment's place as the instruction's 16-bit immediate, in inline assembly: left to hipcc, every pair of
+                // neighbouring patch values became one ds_read2_b32 (8-bit offsets) behind its own v_add_u32 for the base -- 18
+                // vector-ALU instructions per group, and a vector instruction is what an fp32 MFMA stream cannot hide. The
+                // compiler does not know these loads are in flight: every group ends in an explicit wait that ties the registers.
+                float a[2][9], bf[2][4][4], bh[4];
+                const unsigned a_lb = lds_a + ring_bytes, b_lb = lds_b + ring_bytes, h_lb = lds_h + ring_bytes;
+                auto load_a = [&](int jj, float(&dst)[9]) {
+                    if (UPFIR16_DBG & 128) return;
+#pragma unroll
+                    for (int t = 0; t < 9; ++t) asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(dst[t]) : "v"(a_lb), "i"((t * kKC + 4 * jj) * kBM * 4));
+                };
+                auto load_b = [&](int jj, int h, float(&dst)[4][4]) {
+                    if (UPFIR16_DBG & 128) return;
+#pragma unroll
+                    for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+                        for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+                            for (int dx = 0; dx < 2; ++dx)
+                                asm volatile("ds_read_b32 %0, %1 offset:%2"
+                                             : "=v"(dst[2 * dy + dx][ct])
+                                             : "v"(b_lb), "i"((4 * jj * kPlane + (4 * h - dy + 1) * kPW + 16 * ct + 1 - dx) * 4));
+                };
+                auto load_halo = [&](int jj) {
+#pragma unroll
+                    for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+                        for (int dx = 0; dx < 2; ++dx)
+                            asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(bh[2 * dy + dx]) : "v"(h_lb), "i"((4 * jj * kPlane + (1 - dy) * kPW + 1 - dx) * 4));
+                };
+                // wait for every LDS read in flight and tie the registers they fill to this point
+                auto land_b = [&](float(&x)[4][4]) {
+                    asm volatile("s_waitcnt lgkmcnt(0)"
+                                 : "+v"(x[0][0]), "+v"(x[0][1]), "+v"(x[0][2]), "+v"(x[0][3]), "+v"(x[1][0]), "+v"(x[1][1]), "+v"(x[1][2]), "+v"(x[1][3]),
+                                   "+v"(x[2][0]), "+v"(x[2][1]), "+v"(x[2][2]), "+v"(x[2][3]), "+v"(x[3][0]), "+v"(x[3][1]), "+v"(x[3][2]), "+v"(x[3][3]));
+                };
+                auto land_a = [&](int jj, float(&x)[9]) {
+                    asm volatile("" : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(x[4]), "+v"(x[5]), "+v"(x[6]), "+v"(x[7]), "+v"(x[8]));
+                    if constexpr (!kPre) {
+                        const float sv = s_lds[k * kKC + 4 * jj + q4];
+#pragma unroll
+                        for (int t = 0; t < 9; ++t) x[t] *= sv;
+                    }
+                };
+                auto land_halo = [&]() { asm volatile("" : "+v"(bh[0]), "+v"(bh[1]), "+v"(bh[2]), "+v"(bh[3])); };
+                load_a(0, a[0]);
+                load_b(0, 0, bf[0]);
+                load_halo(0);
+                land_b(bf[0]);
+                land_a(0, a[0]);
+                land_halo();
+#pragma unroll
+                for (int grp = 0; grp < 4; ++grp) {
+                    const int jj = grp >> 1, h = grp & 1;
+                    // the next group's operands go out before this group's MFMAs
+                    if (grp == 0) load_b(0, 1, bf[1]);
+                    if (grp == 1) {
+                        load_a(1, a[1]);
+                        load_b(1, 0, bf[0]);
+                    }
+                    if (grp == 2) load_b(1, 1, bf[1]);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int t = 0; t < 9; ++t) {
+#pragma unroll
+                        for (int ct = 0; ct < 4; ++ct)
+                            acc[tap_cls(t)][4 * h + ct] =
+                                __builtin_amdgcn_mfma_f32_16x16x4f32(a[jj][t], bf[grp & 1][tap_shift(t)][ct], acc[tap_cls(t)][4 * h + ct], 0, 0, 0);
+                        // the halo tile: one class per wave, with the k-step's first half
+                        if (h == 0 && wave == tap_cls(t)) acch = __builtin_amdgcn_mfma_f32_16x16x4f32(a[jj][t], bh[tap_shift(t)], acch, 0, 0, 0);
+                        __builtin_amdgcn_sched_barrier(0);
+                        // one DMA piece of the next chunk behind every other tap of the chunk's first two groups (7 pieces)
+                        if (grp < 2 && (t & 1) == 1 && grp * 4 + (t >> 1) < kPiecesPerWave) {
+                            if (next_chunk >= 0) stage_piece_n(grp * 4 + (t >> 1), next_chunk, nxt_buf);
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                    }
+                    if (grp == 1) load_halo(1);  // (the halo fragments of the second k-step: the first one's were consumed with group 0)
+                    if (grp < 3) {
+                        land_b(bf[(grp + 1) & 1]);
+                        if (grp == 1) {
+                            land_a(1, a[1]);
+                            land_halo();
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            } else {
+                if (next_chunk >= 0) stage_chunk(next_chunk, nxt_buf);
+                // flush step (si == step_main): only T row 2H exists below the image = position row y' = H (local row 0: wave
+                // 0's first tile row), even row parity, and only its taps on input row H-1 are non-zero: EE taps 2, 3 and EO
+                // tap 5 (wave 0: its four tiles of that row and the halo tile's EE class; wave 1: the halo tile's EO class)
+                if (wave < 2) {
+#pragma unroll
+                    for (int j = 0; j < kKC / 4; ++j) {
+                        const float sv = kPre ? 1.0f : s_lds[k * kKC + 4 * j + q4];
+#pragma unroll
+                        for (int t = 2; t <= 5; ++t) {
+                            if (t == 4) continue;
+                            const float a = Wl[(t * kKC + 4 * j) * kBM] * sv;
+                            const int dx = tap_shift(t) & 1;
+                            if (wave == 0) {
+#pragma unroll
+                                for (int ct = 0; ct < 4; ++ct)
+                                    acc[tap_cls(t)][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(
+                                        a, Pl[boff + 4 * j * kPlane - kPW + 16 * ct - dx], acc[tap_cls(t)][ct], 0, 0, 0);
+                            }
+                            if (wave == tap_cls(t)) acch = __builtin_amdgcn_mfma_f32_16x16x4f32(a, Pl[boffh + 4 * j * kPlane - kPW - dx], acch, 0, 0, 0);
+                        }
+                    }
+                }
+            }
+        }
+        // (the T window lies over ring slot 1, which the last chunk was read from)
+        lds_barrier();
+
+        // ---- epilogue: eight passes (half of the step x channel group) ----
+        if (UPFIR16_DBG & 2) return;
+        // per-lane roles (re-derived here: see fresh_lane)
+        const int elane = fresh_lane();
+        const int en16 = elane & 15, eq4 = elane >> 4;
+        // dump: register g of accumulator tile (class, h, ct) = channel 4 g + q4 of the block at position (w + 4 h, 16 ct + n16):
+        // T window [q4][2 w + py][2 (16 ct + n16) + px + 1]
+        const int dump_base = eq4 * (kPassRows * kTW) + (2 * wave) * kTW + 2 * en16 + 1;
+        const int hpy = wave >> 1, hpx = wave & 1;  // the halo tile's class held by this wave
+        const bool halo_writes = (en16 >> 3) == 1 || hpx == 1;
+        const int halo_half = (en16 & 7) >> 2;      // the half of the step the lane's halo slot lies in
+        const int dump_halo = eq4 * (kPassRows * kTW) + (2 * (en16 & 3) + hpy) * kTW + ((en16 >> 3) ? 129 + hpx : 0);
+        // filter: thread = (channel fc of the pass, column group cg: output columns 2 X0 + 4 cg .. + 3, row group rg: output rows 4 rg .. + 3 of the half)
+        const int fc = wave;
+        const int cg = elane & 31;
+        const int rg = elane >> 5;
+        // (per lane: channel plane, the row group's first row, column group)
+        const int o_voff = (int)((fc * oplane + (long long)(4 * rg) * OWp + 4 * cg) * 4);
+        const bool emit = si >= 0 && !(UPFIR16_DBG & 32);
+        // the next step's first chunk must have landed before the first store is issued
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        landed = true;
+
+        // noise rows of a pass's four output rows, loaded one pass ahead (see the header)
+        f32x4 nz_next[4];
+        auto load_noise = [&](int h) {
+            const int oy = 2 * (y0 + 4 * h) - 2 + 4 * rg;
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                nz_next[r] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(nz_rsrc, ((oy + r) * OW + 2 * X0 + 4 * cg) * 4, 0, 0));
+        };
+        if (has_noise && emit) load_noise(0);
+
+#pragma unroll
+        for (int h = 0; h < (kFlush ? 1 : 2); ++h) {
+            const int oy0 = 2 * (y0 + 4 * h) - 2;       // output row of the half's window row r = 0
+            const int r_lo = max(0, -oy0);               // first image step: rows -2, -1 do not exist
+            const int r_hi = min(kPassRows, 2 * H - oy0);  // flush step: only rows 2H-2, 2H-1
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                // -- dump: accumulator register g = channel 4 g + q4 (g, h are unrolled: register indices are static) --
+                if (!(UPFIR16_DBG & 16))
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+#pragma unroll
+                    for (int ct = 0; ct < 4; ++ct)
+                        stage[dump_base + (c >> 1) * kTW + 32 * ct + (c & 1)] = acc[c][4 * h + ct][g];
+                if (halo_writes && halo_half == h) stage[dump_halo] = acch[g];
+                lds_barrier();
+
+                // -- filter: window row i of row group rg = T row 4 rg - 3 + i of the half; rows 0..2 of rg = 0 from the carry --
+                const int ch = 4 * g + fc;
+                const float dsc = d_lds[ch] * kSqrt2f;
+                const float kh0 = 0.25f * dsc, kh1 = 0.75f * dsc;
+                const float bias2 = b_lds[ch] * kSqrt2f;
+                const float lr6 = 0.6f * sn_lds[ch], lr4 = 0.4f * sn_lds[ch];  // leaky ReLU x the next layer's style
+                const float* const stage_c = stage + fc * (kPassRows * kTW) + 4 * cg;
+                const float* const carry_c = carry + ch * (kCarryRows * kTW) + 4 * cg;
+                const float* const base_a = rg ? stage_c + kTW : carry_c;          // window rows 0..2
+                const float* const base_b = rg ? stage_c + 4 * kTW : stage_c;      // window rows 3..6
+                f32x4 ta[7], tb[7];
+#pragma unroll
+                for (int i = 0; i < 7; ++i) {
+                    const float* const rowp = i < 3 ? base_a + i * kTW : base_b + (i - 3) * kTW;
+                    ta[i] = *reinterpret_cast<const f32x4*>(rowp);
+                    tb[i] = *reinterpret_cast<const f32x4*>(rowp + 4);
+                }
+                f32x4 nz[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) nz[r] = nz_next[r];
+                // the next pass's noise rows go out before this pass's stores
+                if (has_noise && emit && g == 3 && h + 1 < (kFlush ? 1 : 2)) load_noise(h + 1);
+                if (emit) {
+                    // Vertical taps FIRST, on the raw window: an output row's seven columns are four aligned register pairs of
+                    // its rows' two 16-byte reads, so the pass is 16 PACKED operations per output row (v_pk_mul / v_pk_fma_f32:
+                    // the fp32 vector instructions are what this epilogue costs -- they do not run beside another wave's fp32
+                    // MFMAs, SQ_VALU_MFMA_COEXEC_CYCLES = 0 --, and filtering seven rows horizontally for four output rows
+                    // was 28 per row); then the horizontal taps, which carry demod * sqrt 2 and the bias: 16 per row.
+                    // (row oy0 + 4 rg + r of the image = row oy0 + 3 + 4 rg + r of the resource: oy0 >= -2)
+                    const int o_soff = (int)((4 * g * oplane + (long long)(oy0 + 3) * OWp + 2 * X0 + 4) * 4);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int rr = 4 * rg + r;
+                        if (rr >= r_lo && rr < r_hi) {
+                            f32x2 tv[4];
+#pragma unroll
+                            for (int c2 = 0; c2 < 4; ++c2) {
+                                auto pair = [&](int i) { return c2 < 2 ? f32x2{ta[i][2 * c2], ta[i][2 * c2 + 1]} : f32x2{tb[i][2 * c2 - 4], tb[i][2 * c2 - 3]}; };
+                                tv[c2] = 0.25f * pair(r) + 0.75f * pair(r + 1) + 0.75f * pair(r + 2) + 0.25f * pair(r + 3);
+                            }
+                            const float t[7] = {tv[0][0], tv[0][1], tv[1][0], tv[1][1], tv[2][0], tv[2][1], tv[3][0]};
+                            f32x4 v;
+#pragma unroll
+                            for (int o = 0; o < 4; ++o) v[o] = fmaf(kh0, t[o + 3], fmaf(kh1, t[o + 2], fmaf(kh1, t[o + 1], fmaf(kh0, t[o], bias2))));
+                            if (has_noise) v += ns2 * nz[r];
+#pragma unroll
+                            for (int o = 0; o < 4; ++o) v[o] = fmaf(lr6, v[o], lr4 * __builtin_fabsf(v[o]));
+                            if (!(UPFIR16_DBG & 1) || v[0] == 12345.f)
+                                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), o_rsrc, o_voff, o_soff + r * OWp * 4, 0);
+                        }
+                    }
+                }
+                lds_barrier();
+                // -- the last three T rows of this half become the carry of these 4 channels (row group 1 read them as its
+                // window rows 4..6) --
+                if (rg == 1) {
+                    float* const carry_w = carry + ch * (kCarryRows * kTW) + 4 * cg;
+#pragma unroll
+                    for (int i = 0; i < 3; ++i) {
+                        *reinterpret_cast<f32x4*>(carry_w + i * kTW) = ta[4 + i];
+                        if (cg == 31) *reinterpret_cast<f32x4*>(carry_w + i * kTW + 4) = tb[4 + i];
+                    }
+                }
+            }
+        }
+    };
+#pragma unroll 1
+    for (int si = step_first; si < step_main; ++si) run_step(std::false_type{}, si);
+    if (step_last > step_main) run_step(std::true_type{}, step_main);
+}
+
+bool upfir16_supported(int cin, int cout, int H, int W) {
+    // (an even number of chunks per step: the T window lies over the ring slot that is idle after an even count)
+    return H == W && W % kSW == 0 && H % kTH == 0 && cin % (2 * kKC) == 0 && cout % kBM == 0 && cin <= 512;
+}
+
+size_t upfir16_weight_floats(int cin, int cout) { return (size_t)(cout / kBM) * (cin / kKC) * kWlRegion; }
+
+// w_in: scaled filter [tap = wy*3+wx][cin][cout]; w_out: [m tile of 16][chunk of 8][1280]: [slot][ci 0..7][row m 0..15] + padding, slot t =
+// filter tap up_tap_weight[t], MFMA row m = 4 q + r holds channel 4 r + q of the tile (see the header)
+void upfir16_arrange_weights(const float* w_in, int cin, int cout, const int* up_tap_weight, float* w_out) {
+    const int m_tiles = cout / kBM, chunks = cin / kKC;
+    std::fill(w_out, w_out + upfir16_weight_floats(cin, cout), 0.f);
+    for (int mt = 0; mt < m_tiles; ++mt)
+        for (int ch = 0; ch < chunks; ++ch)
+            for (int t = 0; t < 9; ++t)
+                for (int kc = 0; kc < kKC; ++kc)
+                    for (int m = 0; m < kBM; ++m) {
+                        const int channel = 4 * (m & 3) + (m >> 2);
+                        w_out[((size_t)mt * chunks + ch) * kWlRegion + (t * kKC + kc) * kBM + m] =
+                            w_in[((size_t)up_tap_weight[t] * cin + ch * kKC + kc) * cout + mt * kBM + channel];
+                    }
+}
+
+// Row segments: as few as give every CU TWO blocks (a segment costs one extra priming step).
+void upfir16_plan(int B, int cout, int H, int W, int num_cus, UpFirArgs* a) {
+    a->m_tiles = cout / kBM;
+    a->strips = W / kSW;
+    const int base = B * a->m_tiles * a->strips;
+    const int steps = H / kTH;
+    int segs = 1;
+    while (base * segs < 2 * num_cus && segs * 2 <= steps && steps % (segs * 2) == 0) segs *= 2;
+    a->segs = segs;
+    a->rows_per_seg = H / segs;
+    a->total_blocks = base * segs;
+    a->stagger_phases = 1;
+    a->stagger_ticks = 0;
+    static const int env_debug = [] { const char* v = std::getenv("GANCE_DEBUG_UPFIR"); return v ? std::atoi(v) : 0; }();
+    a->debug_flags = env_debug;
+}
+
+// (plain kernels around the templated body: see winograd64_conv.hip on kernel templates and the host pass)
+__global__ __launch_bounds__(256, 2) void upfir16_fused_kernel(const UpFirArgs p) { upfir16_body<false, false>(p); }
+__global__ __launch_bounds__(256, 2) void upfir16_fused_pre_kernel(const UpFirArgs p) { upfir16_body<true, false>(p); }
+__global__ __launch_bounds__(256, 2) void upfir16_fused_noise_kernel(const UpFirArgs p) { upfir16_body<false, true>(p); }
+__global__ __launch_bounds__(256, 2) void upfir16_fused_pre_noise_kernel(const UpFirArgs p) { upfir16_body<true, true>(p); }
+
+hipError_t launch_upfir16_fused(const UpFirArgs& args, hipStream_t stream) {
+    static PerDeviceInt ready;  // the dynamic-LDS opt-in is per device
+    int unused = 0;
+    const hipError_t e = ready.get(
+        [&](int, int* value) {
+            *value = 1;
+            for (const void* kernel : {reinterpret_cast<const void*>(upfir16_fused_kernel), reinterpret_cast<const void*>(upfir16_fused_noise_kernel)}) {
+                const hipError_t err = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)upfir16_lds_bytes(512));
+                if (err != hipSuccess) return err;
+            }
+            for (const void* kernel : {reinterpret_cast<const void*>(upfir16_fused_pre_kernel), reinterpret_cast<const void*>(upfir16_fused_pre_noise_kernel)}) {
+                const hipError_t err = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)upfir16_lds_bytes(0));
+                if (err != hipSuccess) return err;
+            }
+            return hipSuccess;
+        },
+        &unused);
+    if (e != hipSuccess) return e;
+    const bool noise = args.noise != nullptr;
+    auto* const kernel = args.input_prescaled ? (noise ? upfir16_fused_pre_noise_kernel : upfir16_fused_pre_kernel)
+                                              : (noise ? upfir16_fused_noise_kernel : upfir16_fused_kernel);
+    hipLaunchKernelGGL(kernel, dim3(args.total_blocks), dim3(256), upfir16_lds_bytes(args.input_prescaled ? 0 : args.Cin), stream, args);
+    return hipGetLastError();
+}
+
+}  // namespace gance

@@ -20,6 +20,7 @@ def test_step_names_map_to_kernels_and_executed_flops() -> None:
     bench = _bench_module()
     assert bench.kernel_of_step("convTF15_1024x1024_64->32") == "upfir_fused_kernel"
     assert bench.kernel_of_step("convTFp15_1024x1024_64->32") == "upfir_fused_pre_kernel"
+    assert bench.kernel_of_step("convTFp15_1024x1024_64->32/16") == "upfir16_fused_pre_kernel"
     assert bench.kernel_of_step("convW16+rgb_1024x1024_32->32") == "winograd64_c32_rgb_kernel"
     assert bench.kernel_of_step("convW8+rgb_64x64_512->512") == "winograd64_rgb_kernel"
     assert bench.kernel_of_step("convW14_512x512_64->64") == "winograd64_kernel"
