@@ -597,15 +597,16 @@ int synthesize_from_dlat(gance_engine* e, const float* d_dlat, int B, uint8_t* d
         static const int upfir_env = [] { const char* v = std::getenv("GANCE_TUNE_UPFIR"); return v ? std::atoi(v) : -1; }();
         const int upfir_mode = upfir_env >= 0 ? upfir_env
                                               : ((e->cfg.flags & GANCE_FLAG_SPLIT_UPFIR) ? 0 : ((e->cfg.flags & GANCE_FLAG_FORCE_FUSED_UPFIR) ? 2 : 1));
-        if (!c.up || upfir_mode == 0 || e->upfir_w[idx] == SIZE_MAX) return false;
+        if (!c.up || upfir_mode == 0 || (e->upfir_w[idx] == SIZE_MAX && e->upfir16_w[idx] == SIZE_MAX)) return false;
         gance::UpFirArgs u{};
         u.Cin = c.cin;
         if (e->upfir16_w[idx] != SIZE_MAX)
             gance::upfir16_plan(B, c.cout, H, H, e->num_cus, &u);
         else
             gance::upfir_plan(B, c.cout, H, H, e->num_cus, &u);
-        const int steps_per_seg = u.rows_per_seg / 8;
+        const int steps_per_seg = u.rows_per_seg / u.step_rows;
         if (plan != nullptr) *plan = u;
+        // (the narrow strip geometries -- inputs 32 and 16 wide -- have one or two steps per image: never cut into segments)
         return upfir_mode == 2 || (u.total_blocks >= e->num_cus * 3 / 4 && (u.segs == 1 || steps_per_seg >= 4));
     };
     static const bool prescale_up = [] { const char* v = std::getenv("GANCE_TUNE_PRESCALE_UP"); return !(v && std::atoi(v) == 0); }();

@@ -189,6 +189,7 @@ struct UpFirArgs {
     float noise_strength;
     int noise_b_stride;  // 0 (one plane for the batch) or 4 H W (a plane per sample), as in ConvArgs
     int m_tiles, strips, segs, rows_per_seg, total_blocks;  // set by upfir_plan
+    int step_rows;                                           // position rows per step (set by the plan: 8, or 16 in the narrow strip geometries of upfir16_fused.hip)
     int stagger_phases, stagger_ticks;                       // set by upfir_plan: start delay (phase * ticks of 10 ns)
     int debug_flags;  // timing ablations (GANCE_DEBUG_UPFIR): 1 no stores, 2 no epilogue at all, 4 no MFMA, 8 no DMA after the first chunk
     long long x_b_stride;

@@ -28,6 +28,12 @@
 //     are issued before the stores of pass p: gfx9 has ONE vector-memory counter, a load behind a store waits for it).
 //   * no block is special: nothing depends on which waves share a SIMD.
 // The halo tile (16 slots x 16 channels) is one more 16x16x4 tile whose four classes are split over the four waves, as before.
+//
+// Three strip geometries (template Geo16<CT, RW>: CT column tiles of 16 per position row, RW position rows per wave, a step =
+// 4 RW rows): <4, 2> = strips of 64 columns, steps of 8 rows (inputs >= 64 wide, the layers upfir_fused.hip also takes);
+// <2, 4> = 32 columns x 16 rows (the 32 -> 64 layer); <1, 4> = 16 columns x 16 rows, four tiles per wave (the 16 -> 32
+// layer): the layers that ran as two passes (transposed conv into T planes in HBM + FIR pass) until round 4. An epilogue pass
+// always covers four position rows (one per wave) x four channels: 4 RW passes per step.
 
 #include <hip/hip_runtime.h>
 
@@ -54,29 +60,44 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
-constexpr int kTH = 8;                    // position rows per step
-constexpr int kSW = 64;                   // position columns per strip
-constexpr int kBM = 16;                   // output channels per block
-constexpr int kKC = 8;                    // input channels per chunk (two k-steps of the 16x16x4 MFMA)
-constexpr int kPH = kTH + 1;              // patch rows: input rows y0-1 .. y0+7
-constexpr int kPW = kSW + 8;              // patch columns: input columns X0-4 .. X0+67
-constexpr int kPlane = kPH * kPW;         // 648
-constexpr int kWlPieces = 5;              // 1 KiB DMA pieces (the image is padded to 1280 floats in HBM and in LDS)
+constexpr int kBM = 16;            // output channels per block
+constexpr int kKC = 8;             // input channels per chunk (two k-steps of the 16x16x4 MFMA)
+constexpr int kWlPieces = 5;       // weight image [9][8][16] = 1152 floats, padded to five 1 KiB DMA pieces in HBM and in LDS
 constexpr int kWlRegion = kWlPieces * 256;
-constexpr int kPlFloats = kKC * kPlane;   // 5184
-constexpr int kPlF4 = kPlFloats / 4;      // 1296
-constexpr int kPlPieces = 21;             // the last one a quarter full
-constexpr int kPieces = kWlPieces + kPlPieces;        // 26
-constexpr int kPiecesPerWave = (kPieces + 3) / 4;     // 7
-constexpr int kSlot = kWlRegion + kPlFloats;          // 6464 floats
-constexpr int kTW = 132;                              // T window row: T columns 2X0-1 .. 2X0+129 (+ pad)
 constexpr int kCarryRows = 3;
-constexpr int kCarryFloats = kBM * kCarryRows * kTW;  // 6336
-constexpr int kPassCh = 4;                            // channels per epilogue pass
-constexpr int kPassRows = kTH;                        // T rows per pass: four position rows
-constexpr int kStageFloats = kPassCh * kPassRows * kTW;  // 4224
-static_assert(kStageFloats <= kSlot, "the T window of a pass lies over the idle ring slot");
+constexpr int kPassCh = 4;         // channels per epilogue pass
+constexpr int kPassRows = 8;       // T rows per pass: four position rows
 constexpr float kSqrt2f = 1.4142135623730951f;
+
+template <int CT_, int RW_>
+struct Geo16 {
+    static constexpr int CT = CT_, RW = RW_;
+    static constexpr int kSW = 16 * CT;           // position columns per strip
+    static constexpr int kTH = 4 * RW;            // position rows per step
+    static constexpr int kTiles = CT * RW;        // accumulator tiles per wave and class: 8, 8, 4
+    static constexpr int kGroups = kTiles / 4;    // MFMA groups (4 tiles x 9 taps) per k-step
+    static constexpr int kPH = kTH + 1;           // patch rows: input rows y0-1 .. y0+kTH-1
+    static constexpr int kPW = kSW + 8;           // patch columns: input columns X0-4 .. X0+kSW+3
+    static constexpr int kPlane = kPH * kPW;
+    static constexpr int kPlFloats = kKC * kPlane;
+    static constexpr int kPlF4 = kPlFloats / 4;
+    static constexpr int kPlPieces = (kPlF4 + 63) / 64;   // 21 / 22 / 13 (the last one partial)
+    static constexpr int kPieces = kWlPieces + kPlPieces;  // 26 / 27 / 18
+    static constexpr int kPiecesPerWave = (kPieces + 3) / 4;  // 7 / 7 / 5
+    static constexpr int kSlot = kWlRegion + kPlFloats;
+    static constexpr int kTW = 2 * kSW + 4;       // T window row: T columns 2X0-1 .. 2X0+2kSW+1 (+ pad)
+    static constexpr int kCarryFloats = kBM * kCarryRows * kTW;
+    static constexpr int kStageFloats = kPassCh * kPassRows * kTW;
+    static constexpr int kHaloTiles = (2 * kTH + 15) / 16;  // halo slots: kTH rows x 2 sides
+    static constexpr int kCG = kSW / 2;           // column groups of 4 output columns
+    static constexpr int kRG = 64 / kCG;          // row groups of a wave's 64 filter threads: 2 / 4 / 8
+    static constexpr int kFR = kPassRows / kRG;   // output rows per filter thread: 4 / 2 / 1
+    static constexpr int kWin = kFR + 3;          // its window rows
+    static_assert(kTiles % 4 == 0 && kStageFloats <= kSlot && kPiecesPerWave <= 4 * 2 * kGroups, "geometry");
+    // LDS (floats): ring slot 0 | ring slot 1 = T window of a pass | carry | style [Cin] | demod [16] | bias [16] | next style [16]
+    static constexpr int kStageOff = kSlot, kCarryOff = 2 * kSlot, kConstOff = kCarryOff + kCarryFloats;
+    static constexpr size_t lds_bytes(int cin) { return sizeof(float) * ((size_t)kConstOff + cin + 3 * kBM); }
+};
 
 // transposed-conv tap tables, in the order the weights are stored (engine.hip kUpTapWeight):
 // EE (0,0) (0,-1) (-1,0) (-1,-1) | EO (0,0) (-1,0) | OE (0,0) (0,-1) | OO (0,0); class = 2*py + px
@@ -105,20 +126,17 @@ __device__ __forceinline__ int fresh_lane() {
 
 }  // namespace
 
-// LDS (floats): ring slot 0 | ring slot 1 = T window of a pass | carry | style [Cin] | demod [16] | bias [16] | next style [16]
-constexpr int kStageOff16 = kSlot;
-constexpr int kCarryOff16 = 2 * kSlot;
-constexpr int kConstOff16 = kCarryOff16 + kCarryFloats;
-size_t upfir16_lds_bytes(int cin) { return sizeof(float) * ((size_t)kConstOff16 + cin + 3 * kBM); }
-
 // kNoise: the layer adds noise (a compile-time form: as a run-time flag the four selects per output row stayed in the no-noise path)
-template <bool kPre, bool kNoise>
+template <typename G, bool kPre, bool kNoise>
 __device__ __forceinline__ void upfir16_body(const UpFirArgs& p) {
+    constexpr int CT = G::CT, RW = G::RW, kSW = G::kSW, kTH = G::kTH, kPH = G::kPH, kPW = G::kPW, kPlane = G::kPlane, kPlF4 = G::kPlF4;
+    constexpr int kPieces = G::kPieces, kPiecesPerWave = G::kPiecesPerWave, kSlot = G::kSlot, kTW = G::kTW, kCarryFloats = G::kCarryFloats;
+    constexpr int kGroups = G::kGroups, kTiles = G::kTiles, kHaloTiles = G::kHaloTiles, kCG = G::kCG, kFR = G::kFR, kWin = G::kWin;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* const ring0 = smem;
-    float* const stage = smem + kStageOff16;    // [4 ch][8 rows][132], over ring slot 1
-    float* const carry = smem + kCarryOff16;    // [16 ch][3 rows][132]
-    float* const s_lds = smem + kConstOff16;    // style [Cin]
+    float* const stage = smem + G::kStageOff;   // [4 ch][8 rows][kTW], over ring slot 1
+    float* const carry = smem + G::kCarryOff;   // [16 ch][3 rows][kTW]
+    float* const s_lds = smem + G::kConstOff;   // style [Cin]
     float* const d_lds = s_lds + (kPre ? 0 : p.Cin);  // demod [16] (the pre-scaled form keeps no style vector)
     float* const b_lds = d_lds + kBM;           // bias [16]
     float* const sn_lds = b_lds + kBM;          // the next layer's style of these 16 channels (or 1): rides on the leaky ReLU
@@ -164,7 +182,7 @@ __device__ __forceinline__ void upfir16_body(const UpFirArgs& p) {
     const __amdgpu_buffer_rsrc_t x_rsrc =
         __builtin_amdgcn_make_buffer_rsrc((void*)(p.x + (size_t)b * p.x_b_stride), 0, p.Cin * Hp * Wp * 4, 0x00020000);
 
-    // ---- LDS-DMA staging: pieces 0..4 = weight image, 5..25 = patch; wave w issues pieces w, w+4, ... ----
+    // ---- LDS-DMA staging: pieces 0..4 = weight image, 5.. = patch; wave w issues pieces w, w+4, ... ----
     // Per-lane source byte offsets of this wave's patch pieces at patch row 0 = buffer row 0 (-1: none): constants of the
     // kernel. The step being staged only moves the SCALAR offset (y_stage buffer rows): recomputing the offsets per step put
     // their integer divisions -- hoisted by hipcc to the top of every chunk, operands reloaded from scratch -- into the K loop.
@@ -183,9 +201,9 @@ __device__ __forceinline__ void upfir16_body(const UpFirArgs& p) {
     }
     int y_stage = 0;  // first patch row of the step being staged, as a buffer row (= image row y0 - 1, + 1 for the border)
     auto stage_setup = [&](int y0) { y_stage = y0; };
-    // one DMA piece (r = 0..6 of this wave: piece g = wave + 4 r) of `chunk` into ring slot `buf`. Which kind a piece is is
-    // known at compile time except for r = 1 (g = 4 is the last weight piece, 5..7 are patch pieces) and r = 6 (g = 24, 25
-    // exist, 26, 27 do not); only piece 25 is partial (16 of its 64 lanes).
+    // one DMA piece (r of this wave: piece g = wave + 4 r) of `chunk` into ring slot `buf`. Which kind a piece is is known at
+    // compile time except for r = 1 (g = 4 is the last weight piece, 5..7 are patch pieces) and the last r (pieces that do not
+    // exist, and the partial last piece: poff = -1 masks its idle lanes)
     auto stage_piece = [&](auto rtag, int chunk, float* buf) {
         constexpr int r = decltype(rtag)::value;
         const int g = wave + 4 * r;
@@ -193,8 +211,8 @@ __device__ __forceinline__ void upfir16_body(const UpFirArgs& p) {
         if (weights) {
             __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, (lds_ptr_t)(buf + g * 256), 16, (g * 256 + lane * 4) * 4,
                                                      chunk * kWlRegion * 4, 0, 0);
-        } else if (r < 6 || wave < 2) {
-            if (r < 6 || poff[r] >= 0)
+        } else if (r < kPiecesPerWave - 1 || g < kPieces) {
+            if (r < kPiecesPerWave - 1 || poff[r] >= 0)
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(x_rsrc, (lds_ptr_t)(buf + kWlRegion + (g - kWlPieces) * 256), 16, poff[r],
                                                          (chunk * kKC * Hp + y_stage) * Wp * 4, 0, 0);
         }
@@ -206,9 +224,9 @@ __device__ __forceinline__ void upfir16_body(const UpFirArgs& p) {
             case 1: stage_piece(std::integral_constant<int, 1>{}, chunk, buf); break;
             case 2: stage_piece(std::integral_constant<int, 2>{}, chunk, buf); break;
             case 3: stage_piece(std::integral_constant<int, 3>{}, chunk, buf); break;
-            case 4: stage_piece(std::integral_constant<int, 4>{}, chunk, buf); break;
-            case 5: stage_piece(std::integral_constant<int, 5>{}, chunk, buf); break;
-            default: stage_piece(std::integral_constant<int, 6>{}, chunk, buf); break;
+            case 4: stage_piece(std::integral_constant<int, (4 < kPiecesPerWave ? 4 : kPiecesPerWave - 1)>{}, chunk, buf); break;
+            case 5: stage_piece(std::integral_constant<int, (5 < kPiecesPerWave ? 5 : kPiecesPerWave - 1)>{}, chunk, buf); break;
+            default: stage_piece(std::integral_constant<int, kPiecesPerWave - 1>{}, chunk, buf); break;
         }
     };
     auto stage_chunk = [&](int chunk, float* buf) {
@@ -233,18 +251,25 @@ __device__ __forceinline__ void upfir16_body(const UpFirArgs& p) {
     // row and column so that every tap shift is a non-negative immediate) ----
     // A (weights): [tap][ci 0..7][channel slot 0..15]; lane (m = n16, k = q4) reads slot m of input channel 4 j + k
     const int aoff = q4 * kBM + n16;
-    // B (patch) of main tile (half h, column tile ct): position row w + 4 h, columns 16 ct + n; interior at column + 4
-    const int boff = q4 * kPlane + (wave + 1) * kPW + n16 + 4;  // + 4 j kPlane + 4 h kPW - dy kPW + 16 ct - dx
-    // halo tile: slot n16: position row slot & 7, column -1 (slot < 8) or 64
-    const int boffh = q4 * kPlane + ((n16 & 7) + 1) * kPW + ((n16 >> 3) ? 64 : -1) + 4;
+    // B (patch) of main tile (row rw, column tile ct): position row w + 4 rw, columns 16 ct + n; interior at column + 4
+    const int boff = q4 * kPlane + (wave + 1) * kPW + n16 + 4;  // + 4 j kPlane + 4 rw kPW - dy kPW + 16 ct - dx
+    // halo tile ht, slot n16: halo slot 16 ht + n16 = (side, position row): slot % kTH, column -1 (side 0) or kSW
+    int boffh[kHaloTiles];
+#pragma unroll
+    for (int ht = 0; ht < kHaloTiles; ++ht) {
+        const int slot = 16 * ht + n16;
+        boffh[ht] = q4 * kPlane + (slot % kTH + 1) * kPW + ((slot / kTH) ? kSW : -1) + 4;
+    }
     const unsigned lds_0 = (unsigned)(unsigned long long)(__attribute__((address_space(3))) float*)smem;
     const unsigned lds_a = lds_0 + aoff * 4;
     const unsigned lds_b = lds_0 + (kWlRegion + boff - kPW - 1) * 4;
-    const unsigned lds_h = lds_0 + (kWlRegion + boffh - kPW - 1) * 4;
+    unsigned lds_h[kHaloTiles];
+#pragma unroll
+    for (int ht = 0; ht < kHaloTiles; ++ht) lds_h[ht] = lds_0 + (kWlRegion + boffh[ht] - kPW - 1) * 4;
 
     const int OW = 2 * W, OWp = OW + 8;
     const long long oplane = (long long)(2 * H + 2) * OWp;
-    // (the resource starts TWO ROWS ABOVE the block's first channel plane: a half's first window row lies two rows above the image
+    // (the resource starts TWO ROWS ABOVE the block's first channel plane: a pass's first window row lies two rows above the image
     // in the image's first step, and both parts of a store's offset -- per-lane rows in the vector offset, the row of the unrolled
     // loop in the scalar one -- must stay non-negative: a negative offset is a 4 GB jump, not a subtraction. Rows above the
     // image are never stored.)
@@ -263,12 +288,14 @@ __device__ __forceinline__ void upfir16_body(const UpFirArgs& p) {
     auto run_step = [&](auto flush_tag, const int si) {
         constexpr bool kFlush = decltype(flush_tag)::value;
         const int y0 = y_begin + kTH * si;
-        f32x4 acc[4][8];  // [class][tile: half h * 4 + column tile ct]
-        f32x4 acch = f32x4{0.f, 0.f, 0.f, 0.f};
+        f32x4 acc[4][kTiles];  // [class][tile: row rw * CT + column tile ct]
+        f32x4 acch[kHaloTiles];
+#pragma unroll
+        for (int ht = 0; ht < kHaloTiles; ++ht) acch[ht] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int c = 0; c < 4; ++c)
 #pragma unroll
-            for (int tl = 0; tl < 8; ++tl) acc[c][tl] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int tl = 0; tl < kTiles; ++tl) acc[c][tl] = f32x4{0.f, 0.f, 0.f, 0.f};
 
         for (int k = 0; k < nchunks; ++k) {
             if (!(k == 0 && landed)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -277,7 +304,7 @@ __device__ __forceinline__ void upfir16_body(const UpFirArgs& p) {
             float* const cur_buf = ring0 + ring * kSlot;
             float* const nxt_buf = ring0 + (ring ^ 1) * kSlot;
             const unsigned ring_bytes = ring * (kSlot * 4);
-            // the next chunk of the stream (this step's k+1, or the first one of the next step): its seven DMA pieces
+            // the next chunk of the stream (this step's k+1, or the first one of the next step): its DMA pieces
             // are issued one at a time BETWEEN the MFMA groups below
             int next_chunk = -1;
             if (UPFIR16_DBG & 8) {
@@ -296,42 +323,47 @@ __device__ __forceinline__ void upfir16_body(const UpFirArgs& p) {
                 continue;
             }
             if constexpr (!kFlush) {
-                // A chunk = two k-steps (input channels 4 j .. 4 j + 3) x two halves (tiles of the wave's position row w + 4 h): four
-                // groups of 36 MFMAs. The operands of group i + 1 -- the half's patch fragments at the four tap shifts (dx = 0 / -1 are
-                // neighbours in LDS: one ds_read2 per pair) and, per k-step, the nine weight fragments and the halo tile's
-                // fragments -- are read from LDS BEFORE the MFMAs of group i are issued: a wave issues in order, so the reads'
-                // latency passes under its own 1 152 matrix cycles (the other block's wave fills what is left; alone on the SIMD,
-                // while that one filters, this wave must not stall at every group).
-                // The reads are single ds_read_b32 from THREE base registers per chunk (weights, patch, halo slot) with the
+                // A chunk = two k-steps (input channels 4 j .. 4 j + 3) x kGroups groups of four tiles = 36 MFMAs each. The operands
+                // of group i + 1 -- its tiles' patch fragments at the four tap shifts and, per k-step, the nine weight fragments and
+                // the halo tiles' fragments -- are read from LDS BEFORE the MFMAs of group i are issued: a wave issues in order, so
+                // the reads' latency passes under its own 1 152 matrix cycles (the other block's wave fills what is left; alone on
+                // the SIMD, while that one filters, this wave must not stall at every group).
+                // The reads are single ds_read_b32 from a few base registers per chunk (weights, patch, halo slots) with the
                 // fragment's place as the instruction's 16-bit immediate, in inline assembly: left to hipcc, every pair of
-                // neighbouring patch values became one ds_read2_b32 (8-bit offsets) behind its own v_add_u32 for the base -- 18
-                // vector-ALU instructions per group, and a vector instruction is what an fp32 MFMA stream cannot hide. The
+                // neighbouring patch values became one ds_read2_b32 (8-bit offsets) behind its own v_add_u32 for the base. The
                 // compiler does not know these loads are in flight: every group ends in an explicit wait that ties the registers.
-                float a[2][9], bf[2][4][4], bh[4];
-                const unsigned a_lb = lds_a + ring_bytes, b_lb = lds_b + ring_bytes, h_lb = lds_h + ring_bytes;
+                constexpr int kNG = 2 * kGroups;  // groups per chunk
+                float a[2][9], bf[2][4][4], bh[kHaloTiles][4];
+                const unsigned a_lb = lds_a + ring_bytes, b_lb = lds_b + ring_bytes;
                 auto load_a = [&](int jj, float(&dst)[9]) {
                     if (UPFIR16_DBG & 128) return;
 #pragma unroll
                     for (int t = 0; t < 9; ++t) asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(dst[t]) : "v"(a_lb), "i"((t * kKC + 4 * jj) * kBM * 4));
                 };
-                auto load_b = [&](int jj, int h, float(&dst)[4][4]) {
+                auto load_b = [&](int grp, float(&dst)[4][4]) {  // group grp = (k-step grp / kGroups, tiles 4 (grp % kGroups) .. + 3)
                     if (UPFIR16_DBG & 128) return;
 #pragma unroll
                     for (int dy = 0; dy < 2; ++dy)
 #pragma unroll
-                        for (int ct = 0; ct < 4; ++ct)
+                        for (int i = 0; i < 4; ++i)
 #pragma unroll
-                            for (int dx = 0; dx < 2; ++dx)
+                            for (int dx = 0; dx < 2; ++dx) {
+                                const int tl = 4 * (grp % kGroups) + i;
                                 asm volatile("ds_read_b32 %0, %1 offset:%2"
-                                             : "=v"(dst[2 * dy + dx][ct])
-                                             : "v"(b_lb), "i"((4 * jj * kPlane + (4 * h - dy + 1) * kPW + 16 * ct + 1 - dx) * 4));
+                                             : "=v"(dst[2 * dy + dx][i])
+                                             : "v"(b_lb), "i"((4 * (grp / kGroups) * kPlane + (4 * (tl / CT) - dy + 1) * kPW + 16 * (tl % CT) + 1 - dx) * 4));
+                            }
                 };
                 auto load_halo = [&](int jj) {
 #pragma unroll
-                    for (int dy = 0; dy < 2; ++dy)
+                    for (int ht = 0; ht < kHaloTiles; ++ht) {
+                        const unsigned h_lb = lds_h[ht] + ring_bytes;
 #pragma unroll
-                        for (int dx = 0; dx < 2; ++dx)
-                            asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(bh[2 * dy + dx]) : "v"(h_lb), "i"((4 * jj * kPlane + (1 - dy) * kPW + 1 - dx) * 4));
+                        for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+                            for (int dx = 0; dx < 2; ++dx)
+                                asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(bh[ht][2 * dy + dx]) : "v"(h_lb), "i"((4 * jj * kPlane + (1 - dy) * kPW + 1 - dx) * 4));
+                    }
                 };
                 // wait for every LDS read in flight and tie the registers they fill to this point
                 auto land_b = [&](float(&x)[4][4]) {
@@ -347,43 +379,49 @@ __device__ __forceinline__ void upfir16_body(const UpFirArgs& p) {
                         for (int t = 0; t < 9; ++t) x[t] *= sv;
                     }
                 };
-                auto land_halo = [&]() { asm volatile("" : "+v"(bh[0]), "+v"(bh[1]), "+v"(bh[2]), "+v"(bh[3])); };
+                auto land_halo = [&]() {
+#pragma unroll
+                    for (int ht = 0; ht < kHaloTiles; ++ht) asm volatile("" : "+v"(bh[ht][0]), "+v"(bh[ht][1]), "+v"(bh[ht][2]), "+v"(bh[ht][3]));
+                };
                 load_a(0, a[0]);
-                load_b(0, 0, bf[0]);
+                load_b(0, bf[0]);
                 load_halo(0);
                 land_b(bf[0]);
                 land_a(0, a[0]);
                 land_halo();
 #pragma unroll
-                for (int grp = 0; grp < 4; ++grp) {
-                    const int jj = grp >> 1, h = grp & 1;
+                for (int grp = 0; grp < kNG; ++grp) {
+                    const int jj = grp / kGroups, gi = grp % kGroups;
                     // the next group's operands go out before this group's MFMAs
-                    if (grp == 0) load_b(0, 1, bf[1]);
-                    if (grp == 1) {
-                        load_a(1, a[1]);
-                        load_b(1, 0, bf[0]);
+                    if (grp + 1 < kNG) {
+                        if ((grp + 1) % kGroups == 0) load_a(1, a[1]);
+                        load_b(grp + 1, bf[(grp + 1) & 1]);
                     }
-                    if (grp == 2) load_b(1, 1, bf[1]);
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                     for (int t = 0; t < 9; ++t) {
 #pragma unroll
-                        for (int ct = 0; ct < 4; ++ct)
-                            acc[tap_cls(t)][4 * h + ct] =
-                                __builtin_amdgcn_mfma_f32_16x16x4f32(a[jj][t], bf[grp & 1][tap_shift(t)][ct], acc[tap_cls(t)][4 * h + ct], 0, 0, 0);
-                        // the halo tile: one class per wave, with the k-step's first half
-                        if (h == 0 && wave == tap_cls(t)) acch = __builtin_amdgcn_mfma_f32_16x16x4f32(a[jj][t], bh[tap_shift(t)], acch, 0, 0, 0);
+                        for (int i = 0; i < 4; ++i)
+                            acc[tap_cls(t)][4 * gi + i] =
+                                __builtin_amdgcn_mfma_f32_16x16x4f32(a[jj][t], bf[grp & 1][tap_shift(t)][i], acc[tap_cls(t)][4 * gi + i], 0, 0, 0);
+                        // the halo tiles: one class per wave, with the k-step's first group
+                        if (gi == 0 && wave == tap_cls(t)) {
+#pragma unroll
+                            for (int ht = 0; ht < kHaloTiles; ++ht)
+                                acch[ht] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[jj][t], bh[ht][tap_shift(t)], acch[ht], 0, 0, 0);
+                        }
                         __builtin_amdgcn_sched_barrier(0);
-                        // one DMA piece of the next chunk behind every other tap of the chunk's first two groups (7 pieces)
-                        if (grp < 2 && (t & 1) == 1 && grp * 4 + (t >> 1) < kPiecesPerWave) {
+                        // one DMA piece of the next chunk behind every other tap of the chunk's first groups
+                        if ((t & 1) == 1 && grp * 4 + (t >> 1) < kPiecesPerWave) {
                             if (next_chunk >= 0) stage_piece_n(grp * 4 + (t >> 1), next_chunk, nxt_buf);
                             __builtin_amdgcn_sched_barrier(0);
                         }
                     }
-                    if (grp == 1) load_halo(1);  // (the halo fragments of the second k-step: the first one's were consumed with group 0)
-                    if (grp < 3) {
+                    // (the halo fragments of the second k-step: the first one's were consumed with group 0)
+                    if (grp + 1 < kNG && (grp + 1) % kGroups == 0) load_halo(1);
+                    if (grp + 1 < kNG) {
                         land_b(bf[(grp + 1) & 1]);
-                        if (grp == 1) {
+                        if ((grp + 1) % kGroups == 0) {
                             land_a(1, a[1]);
                             land_halo();
                         }
@@ -394,7 +432,7 @@ __device__ __forceinline__ void upfir16_body(const UpFirArgs& p) {
                 if (next_chunk >= 0) stage_chunk(next_chunk, nxt_buf);
                 // flush step (si == step_main): only T row 2H exists below the image = position row y' = H (local row 0: wave
                 // 0's first tile row), even row parity, and only its taps on input row H-1 are non-zero: EE taps 2, 3 and EO
-                // tap 5 (wave 0: its four tiles of that row and the halo tile's EE class; wave 1: the halo tile's EO class)
+                // tap 5 (wave 0: its tiles of that row and the halo tiles' EE class; wave 1: the halo tiles' EO class)
                 if (wave < 2) {
 #pragma unroll
                     for (int j = 0; j < kKC / 4; ++j) {
@@ -406,11 +444,15 @@ __device__ __forceinline__ void upfir16_body(const UpFirArgs& p) {
                             const int dx = tap_shift(t) & 1;
                             if (wave == 0) {
 #pragma unroll
-                                for (int ct = 0; ct < 4; ++ct)
+                                for (int ct = 0; ct < CT; ++ct)
                                     acc[tap_cls(t)][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(
                                         a, Pl[boff + 4 * j * kPlane - kPW + 16 * ct - dx], acc[tap_cls(t)][ct], 0, 0, 0);
                             }
-                            if (wave == tap_cls(t)) acch = __builtin_amdgcn_mfma_f32_16x16x4f32(a, Pl[boffh + 4 * j * kPlane - kPW - dx], acch, 0, 0, 0);
+                            if (wave == tap_cls(t)) {
+#pragma unroll
+                                for (int ht = 0; ht < kHaloTiles; ++ht)
+                                    acch[ht] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, Pl[boffh[ht] + 4 * j * kPlane - kPW - dx], acch[ht], 0, 0, 0);
+                            }
                         }
                     }
                 }
@@ -419,89 +461,94 @@ __device__ __forceinline__ void upfir16_body(const UpFirArgs& p) {
         // (the T window lies over ring slot 1, which the last chunk was read from)
         lds_barrier();
 
-        // ---- epilogue: eight passes (half of the step x channel group) ----
+        // ---- epilogue: 4 RW passes (four position rows of the step x channel group) ----
         if (UPFIR16_DBG & 2) return;
         // per-lane roles (re-derived here: see fresh_lane)
         const int elane = fresh_lane();
         const int en16 = elane & 15, eq4 = elane >> 4;
-        // dump: register g of accumulator tile (class, h, ct) = channel 4 g + q4 of the block at position (w + 4 h, 16 ct + n16):
+        // dump: register g of accumulator tile (class, rw, ct) = channel 4 g + q4 of the block at position (w + 4 rw, 16 ct + n16):
         // T window [q4][2 w + py][2 (16 ct + n16) + px + 1]
         const int dump_base = eq4 * (kPassRows * kTW) + (2 * wave) * kTW + 2 * en16 + 1;
-        const int hpy = wave >> 1, hpx = wave & 1;  // the halo tile's class held by this wave
-        const bool halo_writes = (en16 >> 3) == 1 || hpx == 1;
-        const int halo_half = (en16 & 7) >> 2;      // the half of the step the lane's halo slot lies in
-        const int dump_halo = eq4 * (kPassRows * kTW) + (2 * (en16 & 3) + hpy) * kTW + ((en16 >> 3) ? 129 + hpx : 0);
-        // filter: thread = (channel fc of the pass, column group cg: output columns 2 X0 + 4 cg .. + 3, row group rg: output rows 4 rg .. + 3 of the half)
+        const int hpy = wave >> 1, hpx = wave & 1;  // the halo tiles' class held by this wave
+        // filter: thread = (channel fc of the pass, column group cg: output columns 2 X0 + 4 cg .. + 3, row group rg: output rows kFR rg .. + kFR - 1 of the pass)
         const int fc = wave;
-        const int cg = elane & 31;
-        const int rg = elane >> 5;
+        const int cg = elane % kCG;
+        const int rg = elane / kCG;
         // (per lane: channel plane, the row group's first row, column group)
-        const int o_voff = (int)((fc * oplane + (long long)(4 * rg) * OWp + 4 * cg) * 4);
+        const int o_voff = (int)((fc * oplane + (long long)(kFR * rg) * OWp + 4 * cg) * 4);
         const bool emit = si >= 0 && !(UPFIR16_DBG & 32);
         // the next step's first chunk must have landed before the first store is issued
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         landed = true;
 
-        // noise rows of a pass's four output rows, loaded one pass ahead (see the header)
-        f32x4 nz_next[4];
-        auto load_noise = [&](int h) {
-            const int oy = 2 * (y0 + 4 * h) - 2 + 4 * rg;
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-                nz_next[r] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(nz_rsrc, ((oy + r) * OW + 2 * X0 + 4 * cg) * 4, 0, 0));
+        // Noise rows of a thread's output rows (the same for the four channel groups of a row pass), loaded ahead: row r of the
+        // NEXT row pass goes out in the last channel group's pass, right after row r of this one was taken and BEFORE its store
+        // (see the header: a load behind a store waits for it).
+        f32x4 nz_rows[kFR];
+        auto load_noise_row = [&](int rw, int r) {
+            const int oy = 2 * (y0 + 4 * rw) - 2 + kFR * rg + r;
+            nz_rows[r] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(nz_rsrc, (oy * OW + 2 * X0 + 4 * cg) * 4, 0, 0));
         };
-        if (has_noise && emit) load_noise(0);
-
+        if (has_noise && emit) {
 #pragma unroll
-        for (int h = 0; h < (kFlush ? 1 : 2); ++h) {
-            const int oy0 = 2 * (y0 + 4 * h) - 2;       // output row of the half's window row r = 0
-            const int r_lo = max(0, -oy0);               // first image step: rows -2, -1 do not exist
+            for (int r = 0; r < kFR; ++r) load_noise_row(0, r);
+        }
+
+        constexpr int kRowPasses = kFlush ? 1 : RW;
+#pragma unroll
+        for (int rw = 0; rw < kRowPasses; ++rw) {
+            const int oy0 = 2 * (y0 + 4 * rw) - 2;       // output row of the pass's window row r = 0
+            const int r_lo = max(0, -oy0);                // first image step: rows -2, -1 do not exist
             const int r_hi = min(kPassRows, 2 * H - oy0);  // flush step: only rows 2H-2, 2H-1
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                // -- dump: accumulator register g = channel 4 g + q4 (g, h are unrolled: register indices are static) --
+                // -- dump: accumulator register g = channel 4 g + q4 (g, rw are unrolled: register indices are static) --
                 if (!(UPFIR16_DBG & 16))
 #pragma unroll
                 for (int c = 0; c < 4; ++c)
 #pragma unroll
-                    for (int ct = 0; ct < 4; ++ct)
-                        stage[dump_base + (c >> 1) * kTW + 32 * ct + (c & 1)] = acc[c][4 * h + ct][g];
-                if (halo_writes && halo_half == h) stage[dump_halo] = acch[g];
+                    for (int ct = 0; ct < CT; ++ct)
+                        stage[dump_base + (c >> 1) * kTW + 32 * ct + (c & 1)] = acc[c][rw * CT + ct][g];
+#pragma unroll
+                for (int ht = 0; ht < kHaloTiles; ++ht) {
+                    const int slot = 16 * ht + en16, row = slot % kTH, side = slot / kTH;
+                    if ((side == 1 || hpx == 1) && row / 4 == rw)
+                        stage[eq4 * (kPassRows * kTW) + (2 * (row % 4) + hpy) * kTW + (side ? 2 * kSW + 1 + hpx : 0)] = acch[ht][g];
+                }
                 lds_barrier();
 
-                // -- filter: window row i of row group rg = T row 4 rg - 3 + i of the half; rows 0..2 of rg = 0 from the carry --
+                // -- filter: window row i of row group rg = row R = kFR rg + i of (the channel's three carried T rows, the pass's eight):
+                // rows R < 3 come from the carry, the others from the T window (a select per lane for the first three rows only) --
                 const int ch = 4 * g + fc;
                 const float dsc = d_lds[ch] * kSqrt2f;
                 const float kh0 = 0.25f * dsc, kh1 = 0.75f * dsc;
                 const float bias2 = b_lds[ch] * kSqrt2f;
                 const float lr6 = 0.6f * sn_lds[ch], lr4 = 0.4f * sn_lds[ch];  // leaky ReLU x the next layer's style
-                const float* const stage_c = stage + fc * (kPassRows * kTW) + 4 * cg;
-                const float* const carry_c = carry + ch * (kCarryRows * kTW) + 4 * cg;
-                const float* const base_a = rg ? stage_c + kTW : carry_c;          // window rows 0..2
-                const float* const base_b = rg ? stage_c + 4 * kTW : stage_c;      // window rows 3..6
-                f32x4 ta[7], tb[7];
+                const float* const win_lo = carry + ch * (kCarryRows * kTW) + (kFR * rg) * kTW + 4 * cg;
+                const float* const win_hi = stage + fc * (kPassRows * kTW) + (kFR * rg - kCarryRows) * kTW + 4 * cg;
+                f32x4 ta[kWin], tb[kWin];
 #pragma unroll
-                for (int i = 0; i < 7; ++i) {
-                    const float* const rowp = i < 3 ? base_a + i * kTW : base_b + (i - 3) * kTW;
+                for (int i = 0; i < kWin; ++i) {
+                    const float* const rowp = (i < kCarryRows && kFR * rg + i < kCarryRows ? win_lo : win_hi) + i * kTW;
                     ta[i] = *reinterpret_cast<const f32x4*>(rowp);
                     tb[i] = *reinterpret_cast<const f32x4*>(rowp + 4);
                 }
-                f32x4 nz[4];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) nz[r] = nz_next[r];
-                // the next pass's noise rows go out before this pass's stores
-                if (has_noise && emit && g == 3 && h + 1 < (kFlush ? 1 : 2)) load_noise(h + 1);
                 if (emit) {
                     // Vertical taps FIRST, on the raw window: an output row's seven columns are four aligned register pairs of
                     // its rows' two 16-byte reads, so the pass is 16 PACKED operations per output row (v_pk_mul / v_pk_fma_f32:
                     // the fp32 vector instructions are what this epilogue costs -- they do not run beside another wave's fp32
                     // MFMAs, SQ_VALU_MFMA_COEXEC_CYCLES = 0 --, and filtering seven rows horizontally for four output rows
                     // was 28 per row); then the horizontal taps, which carry demod * sqrt 2 and the bias: 16 per row.
-                    // (row oy0 + 4 rg + r of the image = row oy0 + 3 + 4 rg + r of the resource: oy0 >= -2)
+                    // (row oy0 + kFR rg + r of the image = row oy0 + 3 + kFR rg + r of the resource: oy0 >= -2)
                     const int o_soff = (int)((4 * g * oplane + (long long)(oy0 + 3) * OWp + 2 * X0 + 4) * 4);
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int rr = 4 * rg + r;
+                    for (int r = 0; r < kFR; ++r) {
+                        const int rr = kFR * rg + r;
+                        f32x4 nzr;
+                        if (has_noise) {
+                            nzr = nz_rows[r];
+                            if (g == 3 && rw + 1 < kRowPasses) load_noise_row(rw + 1, r);
+                        }
                         if (rr >= r_lo && rr < r_hi) {
                             f32x2 tv[4];
 #pragma unroll
@@ -513,7 +560,7 @@ __device__ __forceinline__ void upfir16_body(const UpFirArgs& p) {
                             f32x4 v;
 #pragma unroll
                             for (int o = 0; o < 4; ++o) v[o] = fmaf(kh0, t[o + 3], fmaf(kh1, t[o + 2], fmaf(kh1, t[o + 1], fmaf(kh0, t[o], bias2))));
-                            if (has_noise) v += ns2 * nz[r];
+                            if (has_noise) v += ns2 * nzr;
 #pragma unroll
                             for (int o = 0; o < 4; ++o) v[o] = fmaf(lr6, v[o], lr4 * __builtin_fabsf(v[o]));
                             if (!(UPFIR16_DBG & 1) || v[0] == 12345.f)
@@ -522,14 +569,14 @@ __device__ __forceinline__ void upfir16_body(const UpFirArgs& p) {
                     }
                 }
                 lds_barrier();
-                // -- the last three T rows of this half become the carry of these 4 channels (row group 1 read them as its
-                // window rows 4..6) --
-                if (rg == 1) {
+                // -- the last three T rows of the window become the carry of these 4 channels (the last row group read them as
+                // the last three rows of its window) --
+                if (rg == G::kRG - 1) {
                     float* const carry_w = carry + ch * (kCarryRows * kTW) + 4 * cg;
 #pragma unroll
                     for (int i = 0; i < 3; ++i) {
-                        *reinterpret_cast<f32x4*>(carry_w + i * kTW) = ta[4 + i];
-                        if (cg == 31) *reinterpret_cast<f32x4*>(carry_w + i * kTW + 4) = tb[4 + i];
+                        *reinterpret_cast<f32x4*>(carry_w + i * kTW) = ta[kWin - 3 + i];
+                        if (cg == kCG - 1) *reinterpret_cast<f32x4*>(carry_w + i * kTW + 4) = tb[kWin - 3 + i];
                     }
                 }
             }
@@ -540,9 +587,13 @@ __device__ __forceinline__ void upfir16_body(const UpFirArgs& p) {
     if (step_last > step_main) run_step(std::true_type{}, step_main);
 }
 
+// the strip geometry of an input W wide: 64-column strips where they tile it, else 32 / 16 columns (the 32- and 16-wide layers)
+static int upfir16_strip(int W) { return W % 64 == 0 ? 64 : (W == 32 ? 32 : (W == 16 ? 16 : 0)); }
+static int upfir16_step_rows(int W) { return W % 64 == 0 ? 8 : 16; }
+
 bool upfir16_supported(int cin, int cout, int H, int W) {
     // (an even number of chunks per step: the T window lies over the ring slot that is idle after an even count)
-    return H == W && W % kSW == 0 && H % kTH == 0 && cin % (2 * kKC) == 0 && cout % kBM == 0 && cin <= 512;
+    return H == W && upfir16_strip(W) != 0 && H % upfir16_step_rows(W) == 0 && cin % (2 * kKC) == 0 && cout % kBM == 0 && cin <= 512;
 }
 
 size_t upfir16_weight_floats(int cin, int cout) { return (size_t)(cout / kBM) * (cin / kKC) * kWlRegion; }
@@ -565,10 +616,12 @@ void upfir16_arrange_weights(const float* w_in, int cin, int cout, const int* up
 
 // Row segments: as few as give every CU TWO blocks (a segment costs one extra priming step).
 void upfir16_plan(int B, int cout, int H, int W, int num_cus, UpFirArgs* a) {
+    const int strip = upfir16_strip(W), step_rows = upfir16_step_rows(W);
     a->m_tiles = cout / kBM;
-    a->strips = W / kSW;
+    a->strips = W / strip;
+    a->step_rows = step_rows;
     const int base = B * a->m_tiles * a->strips;
-    const int steps = H / kTH;
+    const int steps = H / step_rows;
     int segs = 1;
     while (base * segs < 2 * num_cus && segs * 2 <= steps && steps % (segs * 2) == 0) segs *= 2;
     a->segs = segs;
@@ -581,33 +634,48 @@ void upfir16_plan(int B, int cout, int H, int W, int num_cus, UpFirArgs* a) {
 }
 
 // (plain kernels around the templated body: see winograd64_conv.hip on kernel templates and the host pass)
-__global__ __launch_bounds__(256, 2) void upfir16_fused_kernel(const UpFirArgs p) { upfir16_body<false, false>(p); }
-__global__ __launch_bounds__(256, 2) void upfir16_fused_pre_kernel(const UpFirArgs p) { upfir16_body<true, false>(p); }
-__global__ __launch_bounds__(256, 2) void upfir16_fused_noise_kernel(const UpFirArgs p) { upfir16_body<false, true>(p); }
-__global__ __launch_bounds__(256, 2) void upfir16_fused_pre_noise_kernel(const UpFirArgs p) { upfir16_body<true, true>(p); }
+#define GANCE_UPFIR16_KERNELS(SUFFIX, CT, RW)                                                                                              \
+    __global__ __launch_bounds__(256, 2) void upfir16_fused##SUFFIX##_kernel(const UpFirArgs p) { upfir16_body<Geo16<CT, RW>, false, false>(p); }        \
+    __global__ __launch_bounds__(256, 2) void upfir16_fused##SUFFIX##_pre_kernel(const UpFirArgs p) { upfir16_body<Geo16<CT, RW>, true, false>(p); }     \
+    __global__ __launch_bounds__(256, 2) void upfir16_fused##SUFFIX##_noise_kernel(const UpFirArgs p) { upfir16_body<Geo16<CT, RW>, false, true>(p); }   \
+    __global__ __launch_bounds__(256, 2) void upfir16_fused##SUFFIX##_pre_noise_kernel(const UpFirArgs p) { upfir16_body<Geo16<CT, RW>, true, true>(p); }
+GANCE_UPFIR16_KERNELS(, 4, 2)
+GANCE_UPFIR16_KERNELS(_w32, 2, 4)
+GANCE_UPFIR16_KERNELS(_w16, 1, 4)
+#undef GANCE_UPFIR16_KERNELS
 
 hipError_t launch_upfir16_fused(const UpFirArgs& args, hipStream_t stream) {
+    using Kernel = void (*)(const UpFirArgs);
+    struct Variant {
+        Kernel kernel[4];  // [pre * 2 + noise]
+        size_t lds_plain, lds_pre;
+    };
+    static const Variant variants[3] = {
+        {{upfir16_fused_kernel, upfir16_fused_noise_kernel, upfir16_fused_pre_kernel, upfir16_fused_pre_noise_kernel}, Geo16<4, 2>::lds_bytes(512), Geo16<4, 2>::lds_bytes(0)},
+        {{upfir16_fused_w32_kernel, upfir16_fused_w32_noise_kernel, upfir16_fused_w32_pre_kernel, upfir16_fused_w32_pre_noise_kernel}, Geo16<2, 4>::lds_bytes(512), Geo16<2, 4>::lds_bytes(0)},
+        {{upfir16_fused_w16_kernel, upfir16_fused_w16_noise_kernel, upfir16_fused_w16_pre_kernel, upfir16_fused_w16_pre_noise_kernel}, Geo16<1, 4>::lds_bytes(512), Geo16<1, 4>::lds_bytes(0)},
+    };
     static PerDeviceInt ready;  // the dynamic-LDS opt-in is per device
     int unused = 0;
     const hipError_t e = ready.get(
         [&](int, int* value) {
             *value = 1;
-            for (const void* kernel : {reinterpret_cast<const void*>(upfir16_fused_kernel), reinterpret_cast<const void*>(upfir16_fused_noise_kernel)}) {
-                const hipError_t err = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)upfir16_lds_bytes(512));
-                if (err != hipSuccess) return err;
-            }
-            for (const void* kernel : {reinterpret_cast<const void*>(upfir16_fused_pre_kernel), reinterpret_cast<const void*>(upfir16_fused_pre_noise_kernel)}) {
-                const hipError_t err = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)upfir16_lds_bytes(0));
-                if (err != hipSuccess) return err;
-            }
+            for (const Variant& v : variants)
+                for (int i = 0; i < 4; ++i) {
+                    const hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(v.kernel[i]), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                               (int)(i >= 2 ? v.lds_pre : v.lds_plain));
+                    if (err != hipSuccess) return err;
+                }
             return hipSuccess;
         },
         &unused);
     if (e != hipSuccess) return e;
-    const bool noise = args.noise != nullptr;
-    auto* const kernel = args.input_prescaled ? (noise ? upfir16_fused_pre_noise_kernel : upfir16_fused_pre_kernel)
-                                              : (noise ? upfir16_fused_noise_kernel : upfir16_fused_kernel);
-    hipLaunchKernelGGL(kernel, dim3(args.total_blocks), dim3(256), upfir16_lds_bytes(args.input_prescaled ? 0 : args.Cin), stream, args);
+    const int strip = upfir16_strip(args.W);
+    if (strip == 0) return hipErrorInvalidValue;
+    const Variant& v = variants[strip == 64 ? 0 : (strip == 32 ? 1 : 2)];
+    const int pre = args.input_prescaled ? 1 : 0, noise = args.noise != nullptr ? 1 : 0;
+    const size_t lds = strip == 64 ? Geo16<4, 2>::lds_bytes(pre ? 0 : args.Cin) : (strip == 32 ? Geo16<2, 4>::lds_bytes(pre ? 0 : args.Cin) : Geo16<1, 4>::lds_bytes(pre ? 0 : args.Cin));
+    hipLaunchKernelGGL(v.kernel[2 * pre + noise], dim3(args.total_blocks), dim3(256), lds, stream, args);
     return hipGetLastError();
 }
 

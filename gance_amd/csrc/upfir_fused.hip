@@ -588,6 +588,7 @@ void upfir_plan(int B, int cout, int H, int W, int num_cus, UpFirArgs* a) {
     while (base * segs < num_cus && segs * 2 <= steps && steps % (segs * 2) == 0) segs *= 2;
     a->segs = segs;
     a->rows_per_seg = H / segs;
+    a->step_rows = kTH;
     a->total_blocks = base * segs;
     // Staggered starts (see the kernel): a step's K loop takes about 5.5 us per chunk of 8 input channels, its
     // stores (32 channels x 16 rows x 128 columns per block) take blocks x 256 KB / ~5 TB/s when every block

@@ -31,3 +31,15 @@ def test_winograd43_kernels_do_not_spill_and_run_two_waves_per_simd() -> None:
     result = subprocess.run([sys.executable, str(REPO_ROOT / "tools" / "check_w43_isa.py")], capture_output=True, text=True, timeout=900)
     assert result.returncode == 0, result.stdout + result.stderr
     assert "winograd43_rgb_kernel" in result.stdout
+
+
+@pytest.mark.skipif(shutil.which("hipcc") is None and not Path("/opt/rocm/bin/hipcc").exists(), reason="needs hipcc")
+def test_upfir16_kernels_fit_two_blocks_per_cu_without_scratch() -> None:
+    """
+    The 16-channel fused up kernel (upfir16_fused.hip) is built for two blocks per CU: 128 accumulators + two sets of operand
+    fragments in at most 256 registers, and no scratch (its first version reloaded seventeen spilled values at the top of
+    every chunk of its K loop). tools/check_upfir16_isa.py cross-compiles and checks.
+    """
+    result = subprocess.run([sys.executable, str(REPO_ROOT / "tools" / "check_upfir16_isa.py")], capture_output=True, text=True, timeout=900)
+    assert result.returncode == 0, result.stdout + result.stderr
+    assert "upfir16_fused_pre_kernel" in result.stdout

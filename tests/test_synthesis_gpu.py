@@ -163,12 +163,13 @@ def test_full_size_properties_batch_of_8(library) -> None:
     assert frames.std() > 10  # not a constant image
 
 
-@pytest.mark.parametrize("resolution,batch", [(128, 3), (256, 2)])
+@pytest.mark.parametrize("resolution,batch", [(64, 5), (128, 3), (256, 2)])
 def test_fused_upsampling_layer_matches_oracle_layerwise(library, resolution: int, batch: int) -> None:
     """
-    Conv0_up as ONE kernel (upfir_fused.hip: transposed conv + FIR + noise + bias + leaky ReLU), forced
-    at a small batch: the planner then cuts the image into row segments (priming steps), 256^2 has
-    two 64-column strips (recomputed halo columns) and 8 channel tiles; every term is switched on.
+    Conv0_up as ONE kernel (upfir16_fused.hip / upfir_fused.hip: transposed conv + FIR + noise + bias + leaky ReLU),
+    forced at a small batch: the planner then cuts the image into row segments (priming steps), 256^2 has
+    two 64-column strips (recomputed halo columns) and 8 channel tiles; every term is switched on. The 16 -> 32 and
+    32 -> 64 layers run in the kernel's 16- and 32-column strip geometries (steps of 16 position rows, two halo tiles).
     """
     spec = sg2_spec.make_spec(resolution)
     variables = sg2_spec.make_random_variables(resolution, seed=3, perturb=True)
@@ -179,7 +180,7 @@ def test_fused_upsampling_layer_matches_oracle_layerwise(library, resolution: in
         ref.g_synthesis(torch.from_numpy(dlatents).double(), variables, resolution, collect=wants)
     try:
         for n, conv in enumerate(spec.convs, start=1):
-            if not (conv.up and 2 ** conv.res_log2 >= 128):
+            if not (conv.up and 2 ** conv.res_log2 >= 32):
                 continue
             got = engine.debug_activation_after(dlatents, n)
             want = wants[n - 1].numpy()

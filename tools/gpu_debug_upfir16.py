@@ -21,7 +21,7 @@ wants = []
 with torch.no_grad():
     ref.g_synthesis(torch.from_numpy(dlatents).double(), variables, resolution, collect=wants)
 for n, conv in enumerate(spec.convs, start=1):
-    if not (conv.up and 2 ** conv.res_log2 >= 128):
+    if not (conv.up and 2 ** conv.res_log2 >= 32):
         continue
     got = engine.debug_activation_after(dlatents, n)
     want = wants[n - 1].numpy()
