@@ -61,7 +61,12 @@ def usable_cores() -> int:
 def kernel_of_step(step_name: str) -> str:
     """The HIP kernel behind a conv launch of the engine's step table (names: engine.hip)."""
     if step_name.startswith("convTF"):  # ("p": input pre-scaled by the Winograd launch before it; "/16": the 16-channel geometry)
-        return ("upfir16_fused" if step_name.endswith("/16") else "upfir_fused") + ("_pre_kernel" if step_name.startswith("convTFp") else "_kernel")
+        pre = "_pre" if step_name.startswith("convTFp") else ""
+        if not step_name.endswith("/16"):
+            return f"upfir_fused{pre}_kernel"
+        side = int(re.search(r"_(\d+)x\1_", step_name).group(1)) // 2  # the layer's INPUT width picks the strip geometry
+        geometry = "" if side % 64 == 0 else ("_w32" if side == 32 else "_w16")
+        return f"upfir16_fused{geometry}{pre}_kernel"  # (the launches of a network with noise: ..._noise_kernel)
     if step_name.startswith("convV"):
         narrow = "_32x32_" in step_name  # the 32 x 32 pixel geometry
         return ("winograd43_w32" if narrow else "winograd43") + ("_rgb_kernel" if "+rgb" in step_name else "_kernel")
@@ -481,6 +486,11 @@ def main() -> int:
         help="blend workload with --gpus N > 1: rank0 = RCCL gather of every chunk to rank 0, drained over its PCIe link; per-rank = every rank "
         "drains the pieces it synthesised over its own link (no gather; not with --overlay)",
     )
+    parser.add_argument(
+        "--rccl-channels", type=int, default=0,
+        help="N > 1 GPUs: cap RCCL at this many channels (NCCL_MAX_NCHANNELS = NCCL_MIN_NCHANNELS = N, set before the process group exists): "
+        "fewer copy kernels holding CUs while a gather overlaps the synthesis, for longer; 0 = RCCL's default (the first A/B on a node)",
+    )
     parser.add_argument("--batch-sweep", default="1,4,8,16,32,64", help="batch sizes of extras.batch_sweep (SURVEY.md section 8(d) config 2); empty: skip")
     args = parser.parse_args()
 
@@ -500,6 +510,8 @@ def main() -> int:
     device = torch.device("cuda", local_rank)
     if world_size > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if args.rccl_channels > 0:
+            os.environ["NCCL_MAX_NCHANNELS"] = os.environ["NCCL_MIN_NCHANNELS"] = str(args.rccl_channels)
         if rehearsal:
             dist.init_process_group(backend="gloo", timeout=PROCESS_GROUP_TIMEOUT)
         else:
@@ -613,7 +625,8 @@ def main() -> int:
             "config": {
                 "workload": "BASELINE.json configs[1]: FFHQ config-f %dx%d random-init, batched random-z synthesis (mapping + truncation psi=1.2 + synthesis + uint8 NHWC), frames resident in HBM" % (resolution, resolution),
                 "frames_per_step_per_gpu": batch,
-                "parallelism": f"frame-sharded x{world_size}" + (" + RCCL gather to rank 0" if world_size > 1 else ""),
+                "parallelism": f"frame-sharded x{world_size}" + (" + RCCL gather to rank 0" if world_size > 1 else "")
+                + (f" (RCCL capped at {args.rccl_channels} channels)" if world_size > 1 and args.rccl_channels > 0 else ""),
             },
             "roofline": {
                 "bound": "mfma",

@@ -614,7 +614,8 @@ void upfir16_arrange_weights(const float* w_in, int cin, int cout, const int* up
                     }
 }
 
-// Row segments: as few as give every CU TWO blocks (a segment costs one extra priming step).
+// Row segments: as few as give every CU a block (a segment costs one extra priming step; the second block per CU comes
+// with the batch: 64 frames are two to four rounds of 512 resident blocks on every layer).
 void upfir16_plan(int B, int cout, int H, int W, int num_cus, UpFirArgs* a) {
     const int strip = upfir16_strip(W), step_rows = upfir16_step_rows(W);
     a->m_tiles = cout / kBM;
@@ -623,7 +624,7 @@ void upfir16_plan(int B, int cout, int H, int W, int num_cus, UpFirArgs* a) {
     const int base = B * a->m_tiles * a->strips;
     const int steps = H / step_rows;
     int segs = 1;
-    while (base * segs < 2 * num_cus && segs * 2 <= steps && steps % (segs * 2) == 0) segs *= 2;
+    while (base * segs < num_cus && segs * 2 <= steps && steps % (segs * 2) == 0) segs *= 2;
     a->segs = segs;
     a->rows_per_seg = H / segs;
     a->total_blocks = base * segs;

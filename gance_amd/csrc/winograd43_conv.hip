@@ -80,7 +80,10 @@ struct Geo43 {
     static constexpr int kSlot = kPieces * 256;                   // 39 / 40 KB
     static constexpr int kNoiseRowsPerPiece = 256 / kTW;          // noise rows one 1 KB piece covers: 4 / 8
 };
-constexpr int kNBUF = 3;                       // ring slots: chunk G + 2 is issued during k-step G (a fourth slot measured no faster)
+#ifndef GANCE_W43_NBUF
+#define GANCE_W43_NBUF 3  // (Makefile target ../libgance_hip_w43nbuf<N>.so builds the ring-depth variants)
+#endif
+constexpr int kNBUF = GANCE_W43_NBUF;          // ring slots: chunk G + 2 is issued during k-step G (a fourth slot measured no faster)
 // constants of a tile, fetched by LDS-DMA with its first chunk (a global load in the epilogue costs its whole latency once
 // per tile, and the wait behind it would drain the ring): demod | bias | next layer's style (32 each, padded to 64) |
 // noise [16][64] | (RGB) A operands of the ToRGB product [2 channel tiles][4 steps][64 lanes]

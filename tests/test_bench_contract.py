@@ -21,6 +21,8 @@ def test_step_names_map_to_kernels_and_executed_flops() -> None:
     assert bench.kernel_of_step("convTF15_1024x1024_64->32") == "upfir_fused_kernel"
     assert bench.kernel_of_step("convTFp15_1024x1024_64->32") == "upfir_fused_pre_kernel"
     assert bench.kernel_of_step("convTFp15_1024x1024_64->32/16") == "upfir16_fused_pre_kernel"
+    assert bench.kernel_of_step("convTFp7_64x64_512->512/16") == "upfir16_fused_w32_pre_kernel"
+    assert bench.kernel_of_step("convTF5_32x32_512->512/16") == "upfir16_fused_w16_kernel"
     assert bench.kernel_of_step("convW16+rgb_1024x1024_32->32") == "winograd64_c32_rgb_kernel"
     assert bench.kernel_of_step("convW8+rgb_64x64_512->512") == "winograd64_rgb_kernel"
     assert bench.kernel_of_step("convW14_512x512_64->64") == "winograd64_kernel"
@@ -55,7 +57,9 @@ def test_traffic_record_covers_the_dominant_launches_of_the_default_workload() -
         # the 512^2 / 1024^2 launches -- where HBM traffic is a third of the roof -- move little more than the algorithmic bytes;
         # the deep-K F(4x4,3x3) launches re-stream their transformed weights (36/9 x the 3x3 ones) once per pixel tile and every
         # patch once per 32-channel tile: x5.7 at 64^2, 1.7 TB/s, far from binding
-        assert 1.0 <= ratio < (1.5 if key.endswith(("512x512", "1024x1024")) else 8.0), (key, ratio)  # (x1.38 at 1024^2: 18 x 72 patches per 16 x 64 tile, two partial images)
+        # (the 16 -> 32 up layer in one launch since round 4: 2 048 blocks of 16 channels re-stream the layer's 9.4 MB of weights once per
+        # group of samples and every sample's whole input once per channel tile: x8.2 of its 177 MB, 1.5 TB/s for 0.96 ms)
+        assert 1.0 <= ratio < (1.5 if key.endswith(("512x512", "1024x1024")) else 10.0), (key, ratio)  # (x1.38 at 1024^2: 18 x 72 patches per 16 x 64 tile, two partial images)
         assert 0.3 < entry["mfma_busy_fraction"] < 1.0
     # another workload: no figure rather than a wrong one
     assert bench.measured_traffic("convV16+rgb_1024x1024_32->32", 512, workload["frames_per_step_per_gpu"])[0] is None
