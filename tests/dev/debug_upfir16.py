@@ -1,12 +1,12 @@
 """Dev check of the fused up kernel's 16-channel geometry: where does it differ from the fp64 oracle?
-    python tools/gpu_debug_upfir16.py [resolution] [batch]   (GANCE_TUNE_UPFIR16=0 for the 32-channel geometry)"""
+    python tests/dev/debug_upfir16.py [resolution] [batch]   (GANCE_TUNE_UPFIR16=0 for the 32-channel geometry)"""
 import sys
 from pathlib import Path
 
 import numpy as np
 import torch
 
-sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent.parent))
 from gance_amd import hip_lib  # noqa: E402
 from gance_amd.stylegan2 import spec as sg2_spec  # noqa: E402
 from oracle import stylegan2_ref as ref  # noqa: E402
