@@ -158,7 +158,9 @@ LayerPlan plan_layer(const ConvLayerHost& c, int B) {
     const int res = 1 << c.res_log2;
     // strips pay once the position grid has several tiles per side; below that the launch is
     // latency-bound and extra blocks only hurt
-    const bool strips = c.up && layer_bm(c.cout) == 128 && res / 2 >= 16;
+    // (GANCE_TUNE_STRIPS_MIN, read once: smallest input side that takes the strips; default 16)
+    static const int strips_min = [] { const char* v = std::getenv("GANCE_TUNE_STRIPS_MIN"); return v ? std::atoi(v) : 16; }();
+    const bool strips = c.up && layer_bm(c.cout) == 128 && res / 2 >= strips_min;
     const int grid = c.up ? (strips ? res / 2 : res / 2 + 1) : res;  // the tiled grid
     p.OH = p.OW = c.up ? res / 2 + 1 : res;
     p.tile_id = choose_tile(c.cout, c.up, grid, grid, B);
