@@ -551,3 +551,35 @@ def test_stress_network_1024_batch_64_frame_on_the_default_kernels(library) -> N
         want_u8 = ref.convert_images_to_uint8(want)
         diff = np.abs(frames[i : i + 1].astype(np.int16) - want_u8.astype(np.int16))
         assert int(diff.max()) <= 1 and float((diff > 0).mean()) < 1e-3
+
+
+def test_repeated_calls_are_bit_identical(library) -> None:
+    """
+    The fused up kernel reads its operands with inline-assembly LDS loads behind explicit waits, the Winograd kernels pair
+    waves by SIMD, partial ToRGB images are summed in a fixed order: nothing may depend on timing. The same 48-frame call
+    twenty-five times at 1024^2 (every term on) must give the same bytes every time; so must a scattered sequence of sizes.
+    """
+    resolution = 1024
+    variables = sg2_spec.make_random_variables(resolution, seed=5, perturb=True)
+    z = np.random.RandomState(8).randn(48, 512).astype(np.float32)
+    engine = hip_lib.Engine(variables, resolution, max_batch=48)
+    try:
+        d_z = torch.from_numpy(z).cuda()
+        stream = torch.cuda.current_stream().cuda_stream
+        outs = [torch.empty((48, resolution, resolution, 3), dtype=torch.uint8, device="cuda") for _ in range(2)]
+        engine.synthesize_z_device(d_z.data_ptr(), 48, 1.2, outs[0].data_ptr(), 0, stream)
+        for trip in range(25):
+            engine.synthesize_z_device(d_z.data_ptr(), 48, 1.2, outs[1].data_ptr(), 0, stream)
+            assert torch.equal(outs[0], outs[1]), f"trip {trip}: {int((outs[0] != outs[1]).sum())} bytes differ"
+        first = {}
+        for trip in range(3):
+            for batch in (5, 17, 48, 2, 33):
+                engine.synthesize_z_device(d_z.data_ptr(), batch, 1.2, outs[1].data_ptr(), 0, stream)
+                torch.cuda.synchronize()
+                got = outs[1][:batch].clone()
+                if trip == 0:
+                    first[batch] = got
+                else:
+                    assert torch.equal(first[batch], got), f"trip {trip}, batch {batch}"
+    finally:
+        engine.close()
