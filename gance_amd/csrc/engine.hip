@@ -456,6 +456,10 @@ int run_conv(gance_engine* e, const ConvLayerHost& c, int li, const LayerPlan& p
     // job -- then delays a quarter of its share instead of the tail of the launch. GANCE_TUNE_W43_ROUNDS=1: one block per CU.
     static const int env_rounds = [] { const char* v = std::getenv("GANCE_TUNE_W43_ROUNDS"); return v ? std::atoi(v) : 0; }();
     a.grid_rounds = env_rounds > 0 ? env_rounds : 4;
+    // GANCE_TUNE_W43_XCD=0: the channel tile fastest in the F(4x4,3x3) launches' tile order (round 3's); default: 4 x 8 blocking per XCD
+    // where the layer has 16 channel tiles
+    static const int env_xcd = [] { const char* v = std::getenv("GANCE_TUNE_W43_XCD"); return v ? std::atoi(v) : 1; }();
+    a.xcd_blocking = env_xcd != 0 ? 1 : 0;  // (the launcher drops it where the launch's pixel tiles are not a multiple of four)
     a.fault_flag = e->ws->fault_flag;
     static unsigned long long* stamps = nullptr;
     if (debug_flags & 16) {

@@ -129,6 +129,7 @@ struct ConvArgs {
     // the tiles, handed to the CUs by the hardware dispatcher as they come free -- the hardware is the tile queue: a CU that
     // something else holds for a while (a copy kernel of a collective) delays 1/k of its share, not the launch's tail)
     int grid_rounds;
+    int xcd_blocking;  // winograd43 kernels, layers with 16 channel tiles: 1 = an XCD's 32 concurrent tiles are 4 pixel tiles x 8 channel tiles (else 2 x 16)
     // winograd43 kernels: host-visible word a block sets (to 43) when its SIMDs did not each get exactly two of its waves
     // (the pairing the kernel's roles rest on); the launch's output is then invalid and the engine says so on its next call
     int* fault_flag;

@@ -194,8 +194,18 @@ __device__ __forceinline__ void winograd43_body(const ConvArgs& p) {
         const int q = nwg >> 3, r = nwg & 7, xcd = v & 7;
         int id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (v >> 3);
         Tile43 t;
-        t.m_tile = id % p.m_tiles;
-        id /= p.m_tiles;
+        if (p.m_tiles == 16 && p.xcd_blocking) {
+            // An XCD's 32 CUs work on 32 consecutive ids at a time: with the channel tile fastest that is 2 pixel tiles x 16
+            // channel tiles -- every XCD streams the layer's whole 37.7 MB of transformed weights per 5.2 MB of patches (x5.6 of the
+            // algorithmic bytes at 32^2 / 64^2). 4 pixel tiles x 8 channel tiles move 29 MB per round instead of 43: blocks walk K in
+            // step, so the sharing is by timing, not by L2 capacity.
+            const int j = id & 63, sg = id >> 6;  // (64 ids = 4 pixel tiles x 16 channel tiles)
+            t.m_tile = 8 * (j >> 5) + (j & 7);
+            id = 4 * sg + ((j & 31) >> 3);
+        } else {
+            t.m_tile = id % p.m_tiles;
+            id /= p.m_tiles;
+        }
         t.x0 = (id % p.tiles_x) * kTW;
         id /= p.tiles_x;
         t.y0 = (id % p.tiles_y) * kTH;
@@ -658,6 +668,7 @@ hipError_t launch_winograd43_conv(const ConvArgs& args, hipStream_t stream) {
     a.m_tiles = a.Cout / kBM;
     a.total_chunks = a.Cin / kKC;
     a.total_tiles = a.m_tiles * a.tiles_x * a.tiles_y * a.B;
+    if ((a.tiles_x * a.tiles_y * a.B) % 4 != 0) a.xcd_blocking = 0;  // (the 4 x 8 blocking walks pixel tiles four at a time)
     // blocks per CU (ConvArgs::grid_rounds), as long as a block's stream stays long beside its ring prologue (about two k-steps):
     // at least 64 k-steps per block, else fewer, larger blocks (one frame per call: one block per CU as before)
     int rounds = std::max(1, a.grid_rounds);
