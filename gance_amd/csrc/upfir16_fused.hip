@@ -44,7 +44,8 @@
 #include "kernels.h"
 
 // Timing ablations (GANCE_DEBUG_UPFIR: 1 no stores, 2 no epilogue, 4 no MFMA, 8 no DMA after the first chunk, 16 no
-// accumulator dump into the T window, 32 no FIR rows, 64 no barrier per chunk, 128 no operand reads in the K loop) exist only in a -DGANCE_UPFIR16_DEBUG=1 build (Makefile target
+// accumulator dump into the T window, 32 no FIR rows, 64 no barrier per chunk, 128 no operand reads in the K loop, 256 non-temporal
+// output stores) exist only in a -DGANCE_UPFIR16_DEBUG=1 build (Makefile target
 // upfir16dbg): wrong results, and their uniform branches cost scalar registers.
 #ifndef GANCE_UPFIR16_DEBUG
 #define GANCE_UPFIR16_DEBUG 0
@@ -563,7 +564,9 @@ __device__ __forceinline__ void upfir16_body(const UpFirArgs& p) {
                             if (has_noise) v += ns2 * nzr;
 #pragma unroll
                             for (int o = 0; o < 4; ++o) v[o] = fmaf(lr6, v[o], lr4 * __builtin_fabsf(v[o]));
-                            if (!(UPFIR16_DBG & 1) || v[0] == 12345.f)
+                            if (UPFIR16_DBG & 256)  // (experiment: non-temporal stores)
+                                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), o_rsrc, o_voff, o_soff + r * OWp * 4, 2);
+                            else if (!(UPFIR16_DBG & 1) || v[0] == 12345.f)
                                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), o_rsrc, o_voff, o_soff + r * OWp * 4, 0);
                         }
                     }

@@ -339,8 +339,8 @@ def _prepare_blend_inputs(  # pylint: disable=too-many-arguments,too-many-locals
 
 # Pieces per network in a window of the multi-network stream: a window of w * networks pieces ends in up to `networks` short
 # engine calls, so the loss against full batches shrinks as 1 / w; the window's frames wait in HBM (uint8, 3 MiB each at
-# 1024^2: 768 frames = 2.4 GB with three networks)
-STREAM_WINDOW_PIECES_PER_NETWORK = 4
+# 1024^2: 768 frames = 2.4 GB with three networks at 4 pieces per network). GANCE_STREAM_WINDOW_PIECES overrides.
+STREAM_WINDOW_PIECES_PER_NETWORK = int(os.environ.get("GANCE_STREAM_WINDOW_PIECES", "4"))
 
 
 class _WindowSynthesizer:  # pylint: disable=too-few-public-methods
