@@ -235,6 +235,13 @@ __device__ __forceinline__ void upfir16_body(const UpFirArgs& p) {
         for (int r = 0; r < kPiecesPerWave; ++r) stage_piece_n(r, chunk, buf);
     };
 
+    // Staggered start (experiment, off by default: GANCE_TUNE_UPFIR16_STAGGER_US): the two blocks of a CU start together and do
+    // the same work, so they reach their epilogues -- and their flush steps, which are bound by DMA latency -- together. Every
+    // second wave of 256 blocks (the second resident block of each CU in the launch's first round) waits `stagger_ticks` x 10 ns.
+    if (p.stagger_ticks > 0 && ((blockIdx.x >> 8) & 1)) {
+        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+        while (__builtin_amdgcn_s_memrealtime() - t0 < (unsigned long long)p.stagger_ticks) __builtin_amdgcn_s_sleep(32);
+    }
     stage_setup(y_begin + kTH * step_first);
     stage_chunk(0, ring0);
 
@@ -631,8 +638,9 @@ void upfir16_plan(int B, int cout, int H, int W, int num_cus, UpFirArgs* a) {
     a->segs = segs;
     a->rows_per_seg = H / segs;
     a->total_blocks = base * segs;
+    static const int env_stagger_us = [] { const char* v = std::getenv("GANCE_TUNE_UPFIR16_STAGGER_US"); return v ? std::atoi(v) : 0; }();
     a->stagger_phases = 1;
-    a->stagger_ticks = 0;
+    a->stagger_ticks = env_stagger_us * 100;  // (s_memrealtime ticks of 10 ns)
     static const int env_debug = [] { const char* v = std::getenv("GANCE_DEBUG_UPFIR"); return v ? std::atoi(v) : 0; }();
     a->debug_flags = env_debug;
 }
