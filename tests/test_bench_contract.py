@@ -63,3 +63,13 @@ def test_traffic_record_covers_the_dominant_launches_of_the_default_workload() -
         assert 0.3 < entry["mfma_busy_fraction"] < 1.0
     # another workload: no figure rather than a wrong one
     assert bench.measured_traffic("convV16+rgb_1024x1024_32->32", 512, workload["frames_per_step_per_gpu"])[0] is None
+
+
+def test_metric_labels_of_the_sharded_product_stream_measurements() -> None:
+    """`bench.sharded`: the N-GPU forms of the configs[2] / [3] / [4] labels name the GPU count and drop the one-GPU wording."""
+    bench = _bench_module()
+    assert bench.sharded(bench.METRIC_CONFIG_3, 1) == bench.METRIC_CONFIG_3
+    for label in (bench.METRIC_CONFIG_2, bench.METRIC_CONFIG_3, bench.METRIC_CONFIG_4, bench.METRIC_CONFIG_4_OVERLAY):
+        text = bench.sharded(label, 8)
+        assert text.endswith("frame-sharded over 8 GPUs") and "ONE GPU" not in text and "on one GPU" not in text
+    assert "2160" in bench.sharded(bench.METRIC_CONFIG_3, 8)
