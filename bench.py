@@ -62,6 +62,8 @@ def kernel_of_step(step_name: str) -> str:
     """The HIP kernel behind a conv launch of the engine's step table (names: engine.hip)."""
     if step_name.startswith("convTF"):  # ("p": input pre-scaled by the Winograd launch before it; "/16": the 16-channel geometry)
         pre = "_pre" if step_name.startswith("convTFp") else ""
+        if step_name.endswith("/16x"):
+            return "upfir16x_fused_pre_kernel"  # the pair form (F(2,2) along x)
         if not step_name.endswith("/16"):
             return f"upfir_fused{pre}_kernel"
         side = int(re.search(r"_(\d+)x\1_", step_name).group(1)) // 2  # the layer's INPUT width picks the strip geometry
@@ -402,7 +404,7 @@ def batch_sweep(resolution: int, variables, device, batches, steps: int = 20, wa
             for info in launches:
                 if info.name.startswith("conv") and info.flops > 0:
                     kind, _, rest = info.name.partition("_")
-                    forms[rest.split("_")[0] + ("_up" if kind.startswith("convT") else "")] = kind + ("/16" if info.name.endswith("/16") else "")
+                    forms[rest.split("_")[0] + ("_up" if kind.startswith("convT") else "")] = kind + ("/16" + info.name.rsplit("/16", 1)[1] if "/16" in info.name else "")
             row = {
                 "frames_per_s": round(batch / (ms_per_call * 1e-3), 2), "ms_per_frame": round(ms_per_call / batch, 4), "ms_per_call": round(ms_per_call, 4),
                 "direct_form_frac_of_fp32_mfma_peak": round(

@@ -279,6 +279,7 @@ struct gance_engine {
     std::vector<size_t> wino43_w;  // F(4x4, 3x3) weights (winograd43_conv.hip), SIZE_MAX where the layer does not take that form
     std::vector<size_t> upfir_w;  // fused transposed-conv + FIR kernel's weight image of the up layers that support it (else SIZE_MAX)
     std::vector<size_t> upfir16_w;  // the same for its 16-channel, two-blocks-per-CU geometry (upfir16_fused.hip)
+    std::vector<size_t> upfir16x_w;  // ... and for that geometry's pair form (F(2,2) along x: 15 MFMAs per pair of columns instead of 18)
     int num_cus = 256;
     std::vector<float> conv_ns;
     std::vector<int> conv_s_off, conv_d_off;
@@ -363,6 +364,16 @@ struct FusedRgb {
 static int upfir16_mode() {
     static const int mode = [] {
         const char* v = std::getenv("GANCE_TUNE_UPFIR16");
+        return v ? std::atoi(v) : 1;
+    }();
+    return mode;
+}
+
+// GANCE_TUNE_UPFIR16X (read once per process) = 0: the fused up layers whose input the 64-column strips tile stay in direct form; 1
+// (default): they run in the pair form (F(2,2) along x) when their input arrives pre-scaled and the layer adds no noise.
+static int upfir16x_mode() {
+    static const int mode = [] {
+        const char* v = std::getenv("GANCE_TUNE_UPFIR16X");
         return v ? std::atoi(v) : 1;
     }();
     return mode;
@@ -706,8 +717,10 @@ int synthesize_from_dlat(gance_engine* e, const float* d_dlat, int B, uint8_t* d
                 gance::UpFirArgs u{};
                 if (up_runs_fused(li, &u)) {
                     const bool geometry16 = e->upfir16_w[li] != SIZE_MAX;
+                    const bool pair_form = geometry16 && e->upfir16x_w[li] != SIZE_MAX && input_prescaled && noise == nullptr;
+                    u.pair_form = pair_form ? 1 : 0;
                     u.x = x_in;
-                    u.w = e->pool + (geometry16 ? e->upfir16_w[li] : e->upfir_w[li]);
+                    u.w = e->pool + (pair_form ? e->upfir16x_w[li] : (geometry16 ? e->upfir16_w[li] : e->upfir_w[li]));
                     u.s = e->ws->styles + e->conv_s_off[li];
                     u.d = e->ws->demod + e->conv_d_off[li];
                     u.noise = noise;
@@ -726,9 +739,9 @@ int synthesize_from_dlat(gance_engine* e, const float* d_dlat, int B, uint8_t* d
                     u.s_next = s_next;
                     u.input_prescaled = input_prescaled ? 1 : 0;
                     // ("convTFp": upfir_fused_pre_kernel, the input arrives multiplied by this layer's style)
-                    // (a trailing "/16": the 16-channel, two-blocks-per-CU geometry, upfir16_fused*_kernel)
+                    // (a trailing "/16": the 16-channel, two-blocks-per-CU geometry, upfir16_fused*_kernel; "/16x": its pair form)
                     std::snprintf(name, sizeof(name), input_prescaled ? "convTFp%d_%dx%d_%d->%d%s" : "convTF%d_%dx%d_%d->%d%s", c.layer_idx, res, res, c.cin,
-                                  c.cout, geometry16 ? "/16" : "");
+                                  c.cout, pair_form ? "/16x" : (geometry16 ? "/16" : ""));
                     {
                         const double flops = 2.0 * 9 * (double)c.cin * c.cout * H * W * B;
                         const double bytes = 4.0 * ((double)B * c.cin * H * W + (double)B * c.cout * res * res + 9.0 * c.cin * c.cout);
@@ -1087,6 +1100,13 @@ int gance_engine_create(const gance_engine_config* config, const float* host_wei
             for (size_t j = 0; j < wn; ++j) scaled[j] = src[j] * coef;
             e->upfir16_w[i] = reserve(gance::upfir16_weight_floats(c.cin, c.cout));
             gance::upfir16_arrange_weights(scaled.data(), c.cin, c.cout, kUpTapWeight, &pool[e->upfir16_w[i]]);
+        }
+        e->upfir16x_w.push_back(SIZE_MAX);
+        if (c.up && upfir16_mode() != 0 && upfir16x_mode() != 0 && gance::upfir16x_supported(c.cin, c.cout, (1 << c.res_log2) / 2, (1 << c.res_log2) / 2)) {
+            std::vector<float> scaled(wn);
+            for (size_t j = 0; j < wn; ++j) scaled[j] = src[j] * coef;
+            e->upfir16x_w[i] = reserve(gance::upfir16x_weight_floats(c.cin, c.cout));
+            gance::upfir16x_arrange_weights(scaled.data(), c.cin, c.cout, kUpTapWeight, &pool[e->upfir16x_w[i]]);
         }
         src += wn;
         demod_layers[i] = {(long long)w2_cursor, e->conv_s_off[i], e->conv_d_off[i], c.cin, c.cout};

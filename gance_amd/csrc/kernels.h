@@ -198,6 +198,7 @@ struct UpFirArgs {
     // activation is multiplied by it (the Winograd kernel on 16x16x4 MFMAs takes its input pre-scaled)
     const float* s_next;
     int input_prescaled;  // x arrives multiplied by this layer's own style (its producer was given s_next): no style scale in the K loop
+    int pair_form;        // upfir16 only: w is the pair-form image (upfir16x_arrange_weights): F(2,2) along x, 15 MFMAs per pair of columns instead of 18
 };
 bool upfir_supported(int cin, int cout, int H, int W);
 size_t upfir_weight_floats(int cin, int cout);
@@ -212,6 +213,9 @@ size_t upfir16_weight_floats(int cin, int cout);
 void upfir16_arrange_weights(const float* w_in /*[9][cin][cout] scaled*/, int cin, int cout, const int* up_tap_weight, float* w_out);
 void upfir16_plan(int B, int cout, int H, int W, int num_cus, UpFirArgs* args);
 hipError_t launch_upfir16_fused(const UpFirArgs& args, hipStream_t stream);
+bool upfir16x_supported(int cin, int cout, int H, int W);
+size_t upfir16x_weight_floats(int cin, int cout);
+void upfir16x_arrange_weights(const float* w_in /*[9][cin][cout] scaled*/, int cin, int cout, const int* up_tap_weight, float* w_out);
 
 // ---- aux_kernels.hip ----
 

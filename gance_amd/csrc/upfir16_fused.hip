@@ -63,16 +63,21 @@ typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
 constexpr int kBM = 16;            // output channels per block
 constexpr int kKC = 8;             // input channels per chunk (two k-steps of the 16x16x4 MFMA)
-constexpr int kWlPieces = 5;       // weight image [9][8][16] = 1152 floats, padded to five 1 KiB DMA pieces in HBM and in LDS
-constexpr int kWlRegion = kWlPieces * 256;
 constexpr int kCarryRows = 3;
 constexpr int kPassCh = 4;         // channels per epilogue pass
 constexpr int kPassRows = 8;       // T rows per pass: four position rows
 constexpr float kSqrt2f = 1.4142135623730951f;
 
-template <int CT_, int RW_>
+// WX: the two-tap classes along x (EE, OE) in Winograd F(2,2) form over PAIRS of position columns (see the header): an N tile of
+// the MFMA is 16 pairs = 32 columns, 15 MFMAs per pair tile and k-step instead of 18, 10 accumulator tiles per pair tile instead of 8.
+template <int CT_, int RW_, bool WX_ = false>
 struct Geo16 {
     static constexpr int CT = CT_, RW = RW_;
+    static constexpr bool WX = WX_;
+    static constexpr int kWlSlots = WX ? 12 : 9;   // weight fragments per (input channel, channel): the nine taps, or EE (h0, h0+h1, h1) x 2 row taps, EO x 2, OE (h0, h0+h1, h1), OO
+    static constexpr int kWlPieces = WX ? 6 : 5;   // weight image [slots][8][16] = 1152 / 1536 floats in 1 KiB DMA pieces (1152 padded to 1280 in HBM and in LDS)
+    static constexpr int kWlRegion = kWlPieces * 256;
+    static constexpr int kAcc = WX ? 10 * (CT / 2) * RW : 4 * CT * RW;  // accumulator tiles per wave: 40 / 32 / 32 / 16
     static constexpr int kSW = 16 * CT;           // position columns per strip
     static constexpr int kTH = 4 * RW;            // position rows per step
     static constexpr int kTiles = CT * RW;        // accumulator tiles per wave and class: 8, 8, 4
@@ -94,7 +99,7 @@ struct Geo16 {
     static constexpr int kRG = 64 / kCG;          // row groups of a wave's 64 filter threads: 2 / 4 / 8
     static constexpr int kFR = kPassRows / kRG;   // output rows per filter thread: 4 / 2 / 1
     static constexpr int kWin = kFR + 3;          // its window rows
-    static_assert(kTiles % 4 == 0 && kStageFloats <= kSlot && kPiecesPerWave <= 4 * 2 * kGroups, "geometry");
+    static_assert(kTiles % 4 == 0 && kStageFloats <= kSlot && kPiecesPerWave <= 4 * 2 * kGroups && (!WX || CT == 4), "geometry");
     // LDS (floats): ring slot 0 | ring slot 1 = T window of a pass | carry | style [Cin] | demod [16] | bias [16] | next style [16]
     static constexpr int kStageOff = kSlot, kCarryOff = 2 * kSlot, kConstOff = kCarryOff + kCarryFloats;
     static constexpr size_t lds_bytes(int cin) { return sizeof(float) * ((size_t)kConstOff + cin + 3 * kBM); }
@@ -133,6 +138,9 @@ __device__ __forceinline__ void upfir16_body(const UpFirArgs& p) {
     constexpr int CT = G::CT, RW = G::RW, kSW = G::kSW, kTH = G::kTH, kPH = G::kPH, kPW = G::kPW, kPlane = G::kPlane, kPlF4 = G::kPlF4;
     constexpr int kPieces = G::kPieces, kPiecesPerWave = G::kPiecesPerWave, kSlot = G::kSlot, kTW = G::kTW, kCarryFloats = G::kCarryFloats;
     constexpr int kGroups = G::kGroups, kTiles = G::kTiles, kHaloTiles = G::kHaloTiles, kCG = G::kCG, kFR = G::kFR, kWin = G::kWin;
+    constexpr int kWlPieces = G::kWlPieces, kWlRegion = G::kWlRegion;
+    constexpr bool WX = G::WX;
+    static_assert(!WX || kPre, "the pair form takes its input pre-scaled (no room for the style vector beside two blocks' LDS)");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* const ring0 = smem;
     float* const stage = smem + G::kStageOff;   // [4 ch][8 rows][kTW], over ring slot 1
@@ -208,7 +216,7 @@ __device__ __forceinline__ void upfir16_body(const UpFirArgs& p) {
     auto stage_piece = [&](auto rtag, int chunk, float* buf) {
         constexpr int r = decltype(rtag)::value;
         const int g = wave + 4 * r;
-        const bool weights = r < 1 || (r == 1 && wave == 0);
+        const bool weights = g < kWlPieces;  // (r = 0: every wave; r = 1: wave 0, and wave 1 too in the pair form's six pieces)
         if (weights) {
             __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, (lds_ptr_t)(buf + g * 256), 16, (g * 256 + lane * 4) * 4,
                                                      chunk * kWlRegion * 4, 0, 0);
@@ -270,7 +278,8 @@ __device__ __forceinline__ void upfir16_body(const UpFirArgs& p) {
     }
     const unsigned lds_0 = (unsigned)(unsigned long long)(__attribute__((address_space(3))) float*)smem;
     const unsigned lds_a = lds_0 + aoff * 4;
-    const unsigned lds_b = lds_0 + (kWlRegion + boff - kPW - 1) * 4;
+    // (pair form: lane n16 is PAIR n16 of its pair tile: its three columns are 2 n16 - 1, 2 n16, 2 n16 + 1 = immediates 0, 1, 2 from here)
+    const unsigned lds_b = lds_0 + (kWlRegion + boff + (WX ? n16 : 0) - kPW - 1) * 4;
     unsigned lds_h[kHaloTiles];
 #pragma unroll
     for (int ht = 0; ht < kHaloTiles; ++ht) lds_h[ht] = lds_0 + (kWlRegion + boffh[ht] - kPW - 1) * 4;
@@ -296,14 +305,25 @@ __device__ __forceinline__ void upfir16_body(const UpFirArgs& p) {
     auto run_step = [&](auto flush_tag, const int si) {
         constexpr bool kFlush = decltype(flush_tag)::value;
         const int y0 = y_begin + kTH * si;
-        f32x4 acc[4][kTiles];  // [class][tile: row rw * CT + column tile ct]
+        // direct form: [class][tile: row rw * CT + column tile ct]. Pair form: accw[pair tile: row rw * 2 + pt][product]: 0..2 = EE (m1, m2,
+        // m3), 3, 4 = EO at x = 2 n, 2 n + 1, 5..7 = OE (m1, m2, m3), 8, 9 = OO at 2 n, 2 n + 1 (acc is then unused and folds away)
+        f32x4 acc[4][kTiles];
+        f32x4 accw[WX ? 2 * RW : 1][10];
+        if constexpr (WX) {
+#pragma unroll
+            for (int t4 = 0; t4 < 2 * RW; ++t4)
+#pragma unroll
+                for (int c = 0; c < 10; ++c) accw[t4][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
         f32x4 acch[kHaloTiles];
 #pragma unroll
         for (int ht = 0; ht < kHaloTiles; ++ht) acch[ht] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if constexpr (!WX) {
 #pragma unroll
-        for (int c = 0; c < 4; ++c)
+            for (int c = 0; c < 4; ++c)
 #pragma unroll
-            for (int tl = 0; tl < kTiles; ++tl) acc[c][tl] = f32x4{0.f, 0.f, 0.f, 0.f};
+                for (int tl = 0; tl < kTiles; ++tl) acc[c][tl] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
 
         for (int k = 0; k < nchunks; ++k) {
             if (!(k == 0 && landed)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -323,14 +343,135 @@ __device__ __forceinline__ void upfir16_body(const UpFirArgs& p) {
                 next_chunk = 0;
             }
             ring ^= 1;
-            const float* const Wl = cur_buf + aoff;
-            const float* const Pl = cur_buf + kWlRegion;
 
             if (UPFIR16_DBG & 4) {
                 if (next_chunk >= 0) stage_chunk(next_chunk, nxt_buf);
                 continue;
             }
-            if constexpr (!kFlush) {
+            if constexpr (!kFlush && WX) {
+                // Pair form. A chunk = two k-steps x two groups of two pair tiles (position row w + 4 rw, pair tiles pt = 0, 1: 64 columns)
+                // = 30 MFMAs each. Fragments of a pair tile and row tap dy: e0 - e1, e1, e1 - e2, e2 with (e0, e1, e2) = input columns
+                // (2 n - 1, 2 n, 2 n + 1): three reads and two subtractions; weights: twelve fragments per k-step (slot order: Geo16).
+                // Products per pair tile: EE m1..m3 += (h0, h0 + h1, h1)[dy] x (e0 - e1, e1, e1 - e2)[dy] for both row taps, EO += t[dy] x
+                // (e1, e2)[dy], OE m1..m3 += (h0, h0 + h1, h1) x (...)[0], OO += t8 x (e1, e2)[0]: 15 MFMAs instead of 18.
+                constexpr int kNG = 2 * RW;  // groups per chunk: (k-step, row of the wave)
+                // (one set of weight fragments: 160 accumulators leave no room for two -- the second k-step's twelve are read behind the
+                // first one's last MFMAs and waited for there; the other block's wave covers the gap)
+                float a[1][12], raw[2][2][2][3], bh[kHaloTiles][4];
+                const unsigned a_lb = lds_a + ring_bytes, b_lb = lds_b + ring_bytes;
+                auto load_a = [&](int jj, float(&dst)[12]) {
+#pragma unroll
+                    for (int t = 0; t < 12; ++t) asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(dst[t]) : "v"(a_lb), "i"((t * kKC + 4 * jj) * kBM * 4));
+                };
+                auto load_raw = [&](int grp, float(&dst)[2][2][3]) {  // group grp = (k-step grp / RW, row grp % RW): [pair tile][dy][column]
+#pragma unroll
+                    for (int pt = 0; pt < 2; ++pt)
+#pragma unroll
+                        for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+                            for (int e = 0; e < 3; ++e)
+                                asm volatile("ds_read_b32 %0, %1 offset:%2"
+                                             : "=v"(dst[pt][dy][e])
+                                             : "v"(b_lb), "i"((4 * (grp / RW) * kPlane + (4 * (grp % RW) - dy + 1) * kPW + 32 * pt + e) * 4));
+                };
+                auto load_halo = [&](int jj) {
+#pragma unroll
+                    for (int ht = 0; ht < kHaloTiles; ++ht) {
+                        const unsigned h_lb = lds_h[ht] + ring_bytes;
+#pragma unroll
+                        for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+                            for (int dx = 0; dx < 2; ++dx)
+                                asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(bh[ht][2 * dy + dx]) : "v"(h_lb), "i"((4 * jj * kPlane + (1 - dy) * kPW + 1 - dx) * 4));
+                    }
+                };
+                auto land_raw = [&](float(&x)[2][2][3]) {
+                    asm volatile("s_waitcnt lgkmcnt(0)"
+                                 : "+v"(x[0][0][0]), "+v"(x[0][0][1]), "+v"(x[0][0][2]), "+v"(x[0][1][0]), "+v"(x[0][1][1]), "+v"(x[0][1][2]),
+                                   "+v"(x[1][0][0]), "+v"(x[1][0][1]), "+v"(x[1][0][2]), "+v"(x[1][1][0]), "+v"(x[1][1][1]), "+v"(x[1][1][2]));
+                };
+                auto land_a = [&](float(&x)[12]) {
+                    asm volatile("" : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(x[4]), "+v"(x[5]), "+v"(x[6]), "+v"(x[7]), "+v"(x[8]), "+v"(x[9]), "+v"(x[10]), "+v"(x[11]));
+                };
+                auto land_halo = [&]() {
+#pragma unroll
+                    for (int ht = 0; ht < kHaloTiles; ++ht) asm volatile("" : "+v"(bh[ht][0]), "+v"(bh[ht][1]), "+v"(bh[ht][2]), "+v"(bh[ht][3]));
+                };
+                // direct tap t of the halo tile from the slot order (t0 = s2, t1 = s0, t2 = s5, t3 = s3, t4 = s6, t5 = s7, t6 = s10, t7 = s8, t8 = s11)
+                constexpr int kTapSlot[9] = {2, 0, 5, 3, 6, 7, 10, 8, 11};
+                load_a(0, a[0]);
+                load_raw(0, raw[0]);
+                load_halo(0);
+                land_raw(raw[0]);
+                land_a(a[0]);
+                land_halo();
+#pragma unroll
+                for (int grp = 0; grp < kNG; ++grp) {
+                    const int jj = grp / RW, rw = grp % RW;
+                    if (grp + 1 < kNG) load_raw(grp + 1, raw[(grp + 1) & 1]);
+                    __builtin_amdgcn_sched_barrier(0);
+                    // the group's fragments: two subtractions per pair tile and row tap
+                    float bw[2][2][4];
+#pragma unroll
+                    for (int pt = 0; pt < 2; ++pt)
+#pragma unroll
+                        for (int dy = 0; dy < 2; ++dy) {
+                            const float e0 = raw[grp & 1][pt][dy][0], e1 = raw[grp & 1][pt][dy][1], e2 = raw[grp & 1][pt][dy][2];
+                            bw[pt][dy][0] = e0 - e1;
+                            bw[pt][dy][1] = e1;
+                            bw[pt][dy][2] = e1 - e2;
+                            bw[pt][dy][3] = e2;
+                        }
+                    // (the MFMAs below are inline assembly: hipcc knows no hazard of theirs. The eight differences are tied to a two-cycle
+                    // wait here -- a vector write needs two wait states before an MFMA reads it -- and every MFMA reads them after it.)
+                    asm volatile("s_nop 1"
+                                 : "+v"(bw[0][0][0]), "+v"(bw[0][0][2]), "+v"(bw[0][1][0]), "+v"(bw[0][1][2]), "+v"(bw[1][0][0]), "+v"(bw[1][0][2]),
+                                   "+v"(bw[1][1][0]), "+v"(bw[1][1][2]));
+                    // 15 MFMAs per pair tile as (weight slot, fragment, product): ordered so that the two row taps of a product are far apart
+                    constexpr int kOps[15][4] = {  // {slot, dy, fragment, product}
+                        {0, 0, 0, 0}, {1, 0, 1, 1}, {2, 0, 2, 2}, {6, 0, 1, 3}, {6, 0, 3, 4}, {8, 0, 0, 5}, {9, 0, 1, 6}, {10, 0, 2, 7},
+                        {11, 0, 1, 8}, {11, 0, 3, 9}, {3, 1, 0, 0}, {4, 1, 1, 1}, {5, 1, 2, 2}, {7, 1, 1, 3}, {7, 1, 3, 4}};
+#pragma unroll
+                    for (int op = 0; op < 15; ++op) {
+#pragma unroll
+                        // (in the accumulate-in-place form by hand: with 160 accumulators hipcc's builtin took the form whose result is
+                        // another register tuple than its addend and rotated the accumulators through spare tuples it did not have: spills.
+                        // Products of one accumulator are ten MFMAs apart: no dependent pair back to back.)
+                        for (int pt = 0; pt < 2; ++pt)
+                            asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0"
+                                         : "+v"(accw[2 * rw + pt][kOps[op][3]])
+                                         : "v"(a[0][kOps[op][0]]), "v"(bw[pt][kOps[op][1]][kOps[op][2]]));
+                        // the halo tiles (direct form, one class per wave) with the k-step's first group: nine taps beside the first nine products
+                        if (rw == 0 && op < 9 && wave == tap_cls(op)) {
+#pragma unroll
+                            for (int ht = 0; ht < kHaloTiles; ++ht)
+                                asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(acch[ht]) : "v"(a[0][kTapSlot[op]]), "v"(bh[ht][tap_shift(op)]));
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                        // one DMA piece of the next chunk behind every other product of the chunk's first groups
+                        if ((op & 1) == 1 && grp * 7 + (op >> 1) < kPiecesPerWave) {
+                            if (next_chunk >= 0) stage_piece_n(grp * 7 + (op >> 1), next_chunk, nxt_buf);
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                    }
+                    if (grp + 1 < kNG && (grp + 1) % RW == 0) {
+                        load_a(1, a[0]);
+                        load_halo(1);
+                    }
+                    if (grp + 1 < kNG) {
+                        land_raw(raw[(grp + 1) & 1]);
+                        if ((grp + 1) % RW == 0) {
+                            land_a(a[0]);
+                            land_halo();
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    (void)jj;
+                }
+                // (the last MFMAs' results are read by vector instructions in the epilogue, or by the next chunk's MFMAs: a 16x16x4 MFMA
+                // takes 8 passes; the chunk loop's wait + barrier are far longer, the epilogue's first barrier is not guaranteed to be)
+                if (k + 1 == nchunks) asm volatile("s_nop 15\n\ts_nop 15");
+            } else if constexpr (!kFlush) {
                 // A chunk = two k-steps (input channels 4 j .. 4 j + 3) x kGroups groups of four tiles = 36 MFMAs each. The operands
                 // of group i + 1 -- its tiles' patch fragments at the four tap shifts and, per k-step, the nine weight fragments and
                 // the halo tiles' fragments -- are read from LDS BEFORE the MFMAs of group i are issued: a wave issues in order, so
@@ -438,10 +579,53 @@ __device__ __forceinline__ void upfir16_body(const UpFirArgs& p) {
                 }
             } else {
                 if (next_chunk >= 0) stage_chunk(next_chunk, nxt_buf);
+                // (the flush step's per-lane offsets are derived here, from a fresh lane id: kept from the prologue they would be live
+                // across the main K loop, where every register is taken)
+                const int fl = fresh_lane();
+                const int n16 = fl & 15, q4 = fl >> 4;
+                const int boff = q4 * kPlane + (wave + 1) * kPW + n16 + 4;
+                int boffh[kHaloTiles];
+#pragma unroll
+                for (int ht = 0; ht < kHaloTiles; ++ht) {
+                    const int slot = 16 * ht + n16;
+                    boffh[ht] = q4 * kPlane + (slot % kTH + 1) * kPW + ((slot / kTH) ? kSW : -1) + 4;
+                }
+                const float* const Wl = cur_buf + q4 * kBM + n16;
+                const float* const Pl = cur_buf + kWlRegion;
                 // flush step (si == step_main): only T row 2H exists below the image = position row y' = H (local row 0: wave
                 // 0's first tile row), even row parity, and only its taps on input row H-1 are non-zero: EE taps 2, 3 and EO
                 // tap 5 (wave 0: its tiles of that row and the halo tiles' EE class; wave 1: the halo tiles' EO class)
-                if (wave < 2) {
+                if constexpr (WX) {
+                    // (pair form: row tap dy = -1 only: EE products with slots 3..5, EO with slot 7; halo: direct taps 2, 3 = slots 5, 3, tap 5 = slot 7)
+                    if (wave < 2) {
+#pragma unroll
+                        for (int j = 0; j < kKC / 4; ++j) {
+                            if (wave == 0) {
+#pragma unroll
+                                for (int pt = 0; pt < 2; ++pt) {
+                                    const float* const src = Pl + boff + n16 + 4 * j * kPlane - kPW + 32 * pt;
+                                    const float e0 = src[-1], e1 = src[0], e2 = src[1];
+                                    accw[pt][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(Wl[(3 * kKC + 4 * j) * kBM], e0 - e1, accw[pt][0], 0, 0, 0);
+                                    accw[pt][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(Wl[(4 * kKC + 4 * j) * kBM], e1, accw[pt][1], 0, 0, 0);
+                                    accw[pt][2] = __builtin_amdgcn_mfma_f32_16x16x4f32(Wl[(5 * kKC + 4 * j) * kBM], e1 - e2, accw[pt][2], 0, 0, 0);
+                                    accw[pt][3] = __builtin_amdgcn_mfma_f32_16x16x4f32(Wl[(7 * kKC + 4 * j) * kBM], e1, accw[pt][3], 0, 0, 0);
+                                    accw[pt][4] = __builtin_amdgcn_mfma_f32_16x16x4f32(Wl[(7 * kKC + 4 * j) * kBM], e2, accw[pt][4], 0, 0, 0);
+                                }
+                            }
+#pragma unroll
+                            for (int t = 2; t <= 5; ++t) {
+                                if (t == 4) continue;
+                                const int slot = t == 2 ? 5 : (t == 3 ? 3 : 7);
+                                if (wave == tap_cls(t)) {
+#pragma unroll
+                                    for (int ht = 0; ht < kHaloTiles; ++ht)
+                                        acch[ht] = __builtin_amdgcn_mfma_f32_16x16x4f32(Wl[(slot * kKC + 4 * j) * kBM],
+                                                                                        Pl[boffh[ht] + 4 * j * kPlane - kPW - (tap_shift(t) & 1)], acch[ht], 0, 0, 0);
+                                }
+                            }
+                        }
+                    }
+                } else if (wave < 2) {
 #pragma unroll
                     for (int j = 0; j < kKC / 4; ++j) {
                         const float sv = kPre ? 1.0f : s_lds[k * kKC + 4 * j + q4];
@@ -511,12 +695,29 @@ __device__ __forceinline__ void upfir16_body(const UpFirArgs& p) {
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 // -- dump: accumulator register g = channel 4 g + q4 (g, rw are unrolled: register indices are static) --
-                if (!(UPFIR16_DBG & 16))
+                if constexpr (WX) {
+                    // pair form: the output transform (y0 = m1 + m2, y1 = m2 - m3) on the way out; a lane holds the FOUR consecutive T
+                    // columns of its pair per row parity: T columns 4 n .. 4 n + 3 of the pair tile = (EE y0, EO x0, EE y1, EO x1) / (OE y0, OO x0, OE y1, OO x1)
 #pragma unroll
-                for (int c = 0; c < 4; ++c)
+                    for (int pt = 0; pt < 2; ++pt) {
+                        const f32x4 (&m)[10] = accw[2 * rw + pt];
+                        float* const dst = stage + dump_base + 2 * en16 + 64 * pt;  // (dump_base holds 2 n16 + 1: pairs are 4 T columns apart)
+                        dst[0] = m[0][g] + m[1][g];
+                        dst[1] = m[3][g];
+                        dst[2] = m[1][g] - m[2][g];
+                        dst[3] = m[4][g];
+                        dst[kTW + 0] = m[5][g] + m[6][g];
+                        dst[kTW + 1] = m[8][g];
+                        dst[kTW + 2] = m[6][g] - m[7][g];
+                        dst[kTW + 3] = m[9][g];
+                    }
+                } else if (!(UPFIR16_DBG & 16)) {
 #pragma unroll
-                    for (int ct = 0; ct < CT; ++ct)
-                        stage[dump_base + (c >> 1) * kTW + 32 * ct + (c & 1)] = acc[c][rw * CT + ct][g];
+                    for (int c = 0; c < 4; ++c)
+#pragma unroll
+                        for (int ct = 0; ct < CT; ++ct)
+                            stage[dump_base + (c >> 1) * kTW + 32 * ct + (c & 1)] = acc[c][rw * CT + ct][g];
+                }
 #pragma unroll
                 for (int ht = 0; ht < kHaloTiles; ++ht) {
                     const int slot = 16 * ht + en16, row = slot % kTH, side = slot / kTH;
@@ -606,7 +807,7 @@ bool upfir16_supported(int cin, int cout, int H, int W) {
     return H == W && upfir16_strip(W) != 0 && H % upfir16_step_rows(W) == 0 && cin % (2 * kKC) == 0 && cout % kBM == 0 && cin <= 512;
 }
 
-size_t upfir16_weight_floats(int cin, int cout) { return (size_t)(cout / kBM) * (cin / kKC) * kWlRegion; }
+size_t upfir16_weight_floats(int cin, int cout) { return (size_t)(cout / kBM) * (cin / kKC) * Geo16<4, 2>::kWlRegion; }
 
 // w_in: scaled filter [tap = wy*3+wx][cin][cout]; w_out: [m tile of 16][chunk of 8][1280]: [slot][ci 0..7][row m 0..15] + padding, slot t =
 // filter tap up_tap_weight[t], MFMA row m = 4 q + r holds channel 4 r + q of the tile (see the header)
@@ -619,9 +820,32 @@ void upfir16_arrange_weights(const float* w_in, int cin, int cout, const int* up
                 for (int kc = 0; kc < kKC; ++kc)
                     for (int m = 0; m < kBM; ++m) {
                         const int channel = 4 * (m & 3) + (m >> 2);
-                        w_out[((size_t)mt * chunks + ch) * kWlRegion + (t * kKC + kc) * kBM + m] =
+                        w_out[((size_t)mt * chunks + ch) * Geo16<4, 2>::kWlRegion + (t * kKC + kc) * kBM + m] =
                             w_in[((size_t)up_tap_weight[t] * cin + ch * kKC + kc) * cout + mt * kBM + channel];
                     }
+}
+
+// The pair form (Geo16<4, 2, true>: F(2,2) along x on the classes with two taps there): inputs whose width the 64-column strips tile.
+bool upfir16x_supported(int cin, int cout, int H, int W) { return upfir16_supported(cin, cout, H, W) && W % 64 == 0; }
+size_t upfir16x_weight_floats(int cin, int cout) { return (size_t)(cout / kBM) * (cin / kKC) * Geo16<4, 2, true>::kWlRegion; }
+
+// w_out: [m tile of 16][chunk of 8][12 slots][ci 0..7][row m 0..15]; with filter taps in the slot order of the direct image (t0..t8 =
+// up_tap_weight[0..8]: EE (0,0) (0,-1) (-1,0) (-1,-1) | EO (0,0) (-1,0) | OE (0,0) (0,-1) | OO) the slots are
+// EE row tap 0: t1, t0 + t1, t0 | EE row tap -1: t3, t2 + t3, t2 | EO: t4, t5 | OE: t7, t6 + t7, t6 | OO: t8   (h0 = the tap on column x - 1)
+void upfir16x_arrange_weights(const float* w_in, int cin, int cout, const int* up_tap_weight, float* w_out) {
+    const int m_tiles = cout / kBM, chunks = cin / kKC;
+    constexpr int kRegion = Geo16<4, 2, true>::kWlRegion;
+    for (int mt = 0; mt < m_tiles; ++mt)
+        for (int ch = 0; ch < chunks; ++ch)
+            for (int kc = 0; kc < kKC; ++kc)
+                for (int m = 0; m < kBM; ++m) {
+                    const int channel = 4 * (m & 3) + (m >> 2);
+                    float t[9];
+                    for (int i = 0; i < 9; ++i) t[i] = w_in[((size_t)up_tap_weight[i] * cin + ch * kKC + kc) * cout + mt * kBM + channel];
+                    const float slots[12] = {t[1], (float)((double)t[0] + (double)t[1]), t[0], t[3], (float)((double)t[2] + (double)t[3]), t[2],
+                                             t[4], t[5], t[7], (float)((double)t[6] + (double)t[7]), t[6], t[8]};
+                    for (int sl = 0; sl < 12; ++sl) w_out[((size_t)mt * chunks + ch) * kRegion + (sl * kKC + kc) * kBM + m] = slots[sl];
+                }
 }
 
 // Row segments: as few as give every CU a block (a segment costs one extra priming step; the second block per CU comes
@@ -655,6 +879,9 @@ GANCE_UPFIR16_KERNELS(, 4, 2)
 GANCE_UPFIR16_KERNELS(_w32, 2, 4)
 GANCE_UPFIR16_KERNELS(_w16, 1, 4)
 #undef GANCE_UPFIR16_KERNELS
+// the pair form: input pre-scaled only
+__global__ __launch_bounds__(256, 2) void upfir16x_fused_pre_kernel(const UpFirArgs p) { upfir16_body<Geo16<4, 2, true>, true, false>(p); }
+// (no noise form: with 160 accumulators the filter threads' noise rows spill; a layer with noise takes the direct form)
 
 hipError_t launch_upfir16_fused(const UpFirArgs& args, hipStream_t stream) {
     using Kernel = void (*)(const UpFirArgs);
@@ -672,6 +899,11 @@ hipError_t launch_upfir16_fused(const UpFirArgs& args, hipStream_t stream) {
     const hipError_t e = ready.get(
         [&](int, int* value) {
             *value = 1;
+            {
+                const hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(upfir16x_fused_pre_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                           (int)Geo16<4, 2, true>::lds_bytes(0));
+                if (err != hipSuccess) return err;
+            }
             for (const Variant& v : variants)
                 for (int i = 0; i < 4; ++i) {
                     const hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(v.kernel[i]), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -684,6 +916,12 @@ hipError_t launch_upfir16_fused(const UpFirArgs& args, hipStream_t stream) {
     if (e != hipSuccess) return e;
     const int strip = upfir16_strip(args.W);
     if (strip == 0) return hipErrorInvalidValue;
+    if (args.pair_form) {  // (args.w is upfir16x_arrange_weights' image)
+        if (strip != 64 || !args.input_prescaled || args.noise != nullptr) return hipErrorInvalidValue;
+        const size_t lds_x = Geo16<4, 2, true>::lds_bytes(0);
+        hipLaunchKernelGGL(upfir16x_fused_pre_kernel, dim3(args.total_blocks), dim3(256), lds_x, stream, args);
+        return hipGetLastError();
+    }
     const Variant& v = variants[strip == 64 ? 0 : (strip == 32 ? 1 : 2)];
     const int pre = args.input_prescaled ? 1 : 0, noise = args.noise != nullptr ? 1 : 0;
     const size_t lds = strip == 64 ? Geo16<4, 2>::lds_bytes(pre ? 0 : args.Cin) : (strip == 32 ? Geo16<2, 4>::lds_bytes(pre ? 0 : args.Cin) : Geo16<1, 4>::lds_bytes(pre ? 0 : args.Cin));

@@ -9,6 +9,8 @@ required to be within 1 LSB, on at most 0.1 % of the pixels (a float within 1e-5
 boundary can truncate either way).
 """
 
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -163,18 +165,23 @@ def test_full_size_properties_batch_of_8(library) -> None:
     assert frames.std() > 10  # not a constant image
 
 
-@pytest.mark.parametrize("resolution,batch", [(64, 5), (128, 3), (256, 2)])
-def test_fused_upsampling_layer_matches_oracle_layerwise(library, resolution: int, batch: int) -> None:
+@pytest.mark.parametrize("resolution,batch,noise", [(64, 5, True), (128, 3, True), (256, 2, True), (128, 3, False), (256, 5, False)])
+def test_fused_upsampling_layer_matches_oracle_layerwise(library, resolution: int, batch: int, noise: bool) -> None:
     """
     Conv0_up as ONE kernel (upfir16_fused.hip / upfir_fused.hip: transposed conv + FIR + noise + bias + leaky ReLU),
     forced at a small batch: the planner then cuts the image into row segments (priming steps), 256^2 has
     two 64-column strips (recomputed halo columns) and 8 channel tiles; every term is switched on. The 16 -> 32 and
     32 -> 64 layers run in the kernel's 16- and 32-column strip geometries (steps of 16 position rows, two halo tiles).
+    `noise=False` zeroes the noise strengths (StyleGAN2's own init, the network bench.py times): the layers from 64 -> 128
+    up then run in the kernel's pair form (F(2,2) along x, launch names ending in "/16x"), biases still on.
     """
     spec = sg2_spec.make_spec(resolution)
     variables = sg2_spec.make_random_variables(resolution, seed=3, perturb=True)
+    if not noise:
+        variables = {name: (np.zeros_like(value) if name.endswith("/noise_strength") else value) for name, value in variables.items()}
     dlatents = np.random.RandomState(5).randn(batch, spec.num_layers, 512).astype(np.float32)
-    engine = hip_lib.Engine(variables, resolution, max_batch=batch, up_form="fused")
+    # (the pair form reads input the layer before has scaled by this layer's style: the F(4x4,3x3) kernels do that)
+    engine = hip_lib.Engine(variables, resolution, max_batch=batch, up_form="fused", conv_form="auto" if noise else "winograd43", profile=True)
     wants: list = []
     with torch.no_grad():
         ref.g_synthesis(torch.from_numpy(dlatents).double(), variables, resolution, collect=wants)
@@ -186,6 +193,10 @@ def test_fused_upsampling_layer_matches_oracle_layerwise(library, resolution: in
             want = wants[n - 1].numpy()
             rel = np.abs(got - want).max() / np.abs(want).max()
             assert rel < 2e-5, f"conv layer {n} ({conv.scope}): rel err {rel}"
+        if not noise and os.environ.get("GANCE_TUNE_UPFIR16X", "1") != "0" and os.environ.get("GANCE_TUNE_UPFIR16", "1") != "0":
+            engine.synthesize_w(dlatents)
+            pair = [step.name for step in engine.steps() if step.name.endswith("/16x")]
+            assert len(pair) == int(np.log2(resolution)) - 6, pair  # every up layer whose input is >= 64 wide
     finally:
         engine.close()
 
