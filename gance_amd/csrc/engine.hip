@@ -370,7 +370,7 @@ static int upfir16_mode() {
 }
 
 // GANCE_TUNE_UPFIR16X (read once per process) = 0: the fused up layers whose input the 64-column strips tile stay in direct form; 1
-// (default): they run in the pair form (F(2,2) along x) when their input arrives pre-scaled and the layer adds no noise.
+// (default): they run in the pair form (F(2,2) along x) when their input arrives pre-scaled.
 static int upfir16x_mode() {
     static const int mode = [] {
         const char* v = std::getenv("GANCE_TUNE_UPFIR16X");
@@ -717,7 +717,7 @@ int synthesize_from_dlat(gance_engine* e, const float* d_dlat, int B, uint8_t* d
                 gance::UpFirArgs u{};
                 if (up_runs_fused(li, &u)) {
                     const bool geometry16 = e->upfir16_w[li] != SIZE_MAX;
-                    const bool pair_form = geometry16 && e->upfir16x_w[li] != SIZE_MAX && input_prescaled && noise == nullptr;
+                    const bool pair_form = geometry16 && e->upfir16x_w[li] != SIZE_MAX && input_prescaled;
                     u.pair_form = pair_form ? 1 : 0;
                     u.x = x_in;
                     u.w = e->pool + (pair_form ? e->upfir16x_w[li] : (geometry16 ? e->upfir16_w[li] : e->upfir_w[li]));

@@ -99,6 +99,8 @@ struct Geo16 {
     static constexpr int kRG = 64 / kCG;          // row groups of a wave's 64 filter threads: 2 / 4 / 8
     static constexpr int kFR = kPassRows / kRG;   // output rows per filter thread: 4 / 2 / 1
     static constexpr int kWin = kFR + 3;          // its window rows
+    static constexpr int kNzPieces = RW * kPassRows * 2 * kSW / 256;  // noise of a step's output rows in 1 KiB DMA pieces: 8 / 8 / 4
+    static_assert(kNzPieces % 4 == 0 && kStageFloats + kNzPieces * 256 <= kSlot, "the step's noise lies behind the T window in ring slot 1");
     static_assert(kTiles % 4 == 0 && kStageFloats <= kSlot && kPiecesPerWave <= 4 * 2 * kGroups && (!WX || CT == 4), "geometry");
     // LDS (floats): ring slot 0 | ring slot 1 = T window of a pass | carry | style [Cin] | demod [16] | bias [16] | next style [16]
     static constexpr int kStageOff = kSlot, kCarryOff = 2 * kSlot, kConstOff = kCarryOff + kCarryFloats;
@@ -144,6 +146,8 @@ __device__ __forceinline__ void upfir16_body(const UpFirArgs& p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* const ring0 = smem;
     float* const stage = smem + G::kStageOff;   // [4 ch][8 rows][kTW], over ring slot 1
+    float* const nz_lds = stage + G::kStageFloats;  // [8 RW output rows][2 kSW]: the step's noise, behind the T window in ring slot 1
+    constexpr int kNzPieces = G::kNzPieces;
     float* const carry = smem + G::kCarryOff;   // [16 ch][3 rows][kTW]
     float* const s_lds = smem + G::kConstOff;   // style [Cin]
     float* const d_lds = s_lds + (kPre ? 0 : p.Cin);  // demod [16] (the pre-scaled form keeps no style vector)
@@ -669,22 +673,23 @@ __device__ __forceinline__ void upfir16_body(const UpFirArgs& p) {
         // (per lane: channel plane, the row group's first row, column group)
         const int o_voff = (int)((fc * oplane + (long long)(kFR * rg) * OWp + 4 * cg) * 4);
         const bool emit = si >= 0 && !(UPFIR16_DBG & 32);
-        // the next step's first chunk must have landed before the first store is issued
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        landed = true;
-
-        // Noise rows of a thread's output rows (the same for the four channel groups of a row pass), loaded ahead: row r of the
-        // NEXT row pass goes out in the last channel group's pass, right after row r of this one was taken and BEFORE its store
-        // (see the header: a load behind a store waits for it).
-        f32x4 nz_rows[kFR];
-        auto load_noise_row = [&](int rw, int r) {
-            const int oy = 2 * (y0 + 4 * rw) - 2 + kFR * rg + r;
-            nz_rows[r] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(nz_rsrc, (oy * OW + 2 * X0 + 4 * cg) * 4, 0, 0));
-        };
+        // Noise of the step's output rows [8 RW][2 kSW] (the same for every channel): by DMA into the part of ring slot 1 the T
+        // window leaves free, so that it costs no registers and no vector load sits behind the stores (the single vmcnt counter: a
+        // load behind a store waits for it). A lane's 16 bytes: float f = 256 piece + 4 lane of the region; rows above / below the
+        // plane are outside the bounded resource and arrive as zeros (they are never stored). The whole offset is in the VECTOR
+        // part: the range check does not see the scalar one.
         if (has_noise && emit) {
 #pragma unroll
-            for (int r = 0; r < kFR; ++r) load_noise_row(0, r);
+            for (int i = 0; i < kNzPieces / 4; ++i) {
+                const int f = (wave + 4 * i) * 256 + 4 * elane;
+                const int row = f / (2 * kSW), col = f % (2 * kSW);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(nz_rsrc, (lds_ptr_t)(nz_lds + (wave + 4 * i) * 256), 16,
+                                                         ((2 * y0 - 2 + row) * OW + 2 * X0 + col) * 4, 0, 0, 0);
+            }
         }
+        // the next step's first chunk (and the noise) must have landed before the first store is issued
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        landed = true;
 
         constexpr int kRowPasses = kFlush ? 1 : RW;
 #pragma unroll
@@ -753,11 +758,6 @@ __device__ __forceinline__ void upfir16_body(const UpFirArgs& p) {
 #pragma unroll
                     for (int r = 0; r < kFR; ++r) {
                         const int rr = kFR * rg + r;
-                        f32x4 nzr;
-                        if (has_noise) {
-                            nzr = nz_rows[r];
-                            if (g == 3 && rw + 1 < kRowPasses) load_noise_row(rw + 1, r);
-                        }
                         if (rr >= r_lo && rr < r_hi) {
                             f32x2 tv[4];
 #pragma unroll
@@ -769,7 +769,7 @@ __device__ __forceinline__ void upfir16_body(const UpFirArgs& p) {
                             f32x4 v;
 #pragma unroll
                             for (int o = 0; o < 4; ++o) v[o] = fmaf(kh0, t[o + 3], fmaf(kh1, t[o + 2], fmaf(kh1, t[o + 1], fmaf(kh0, t[o], bias2))));
-                            if (has_noise) v += ns2 * nzr;
+                            if (has_noise) v += ns2 * *reinterpret_cast<const f32x4*>(nz_lds + (kPassRows * rw + rr) * (2 * kSW) + 4 * cg);
 #pragma unroll
                             for (int o = 0; o < 4; ++o) v[o] = fmaf(lr6, v[o], lr4 * __builtin_fabsf(v[o]));
                             if (UPFIR16_DBG & 256)  // (experiment: non-temporal stores)
@@ -881,7 +881,7 @@ GANCE_UPFIR16_KERNELS(_w16, 1, 4)
 #undef GANCE_UPFIR16_KERNELS
 // the pair form: input pre-scaled only
 __global__ __launch_bounds__(256, 2) void upfir16x_fused_pre_kernel(const UpFirArgs p) { upfir16_body<Geo16<4, 2, true>, true, false>(p); }
-// (no noise form: with 160 accumulators the filter threads' noise rows spill; a layer with noise takes the direct form)
+__global__ __launch_bounds__(256, 2) void upfir16x_fused_pre_noise_kernel(const UpFirArgs p) { upfir16_body<Geo16<4, 2, true>, true, true>(p); }
 
 hipError_t launch_upfir16_fused(const UpFirArgs& args, hipStream_t stream) {
     using Kernel = void (*)(const UpFirArgs);
@@ -899,8 +899,8 @@ hipError_t launch_upfir16_fused(const UpFirArgs& args, hipStream_t stream) {
     const hipError_t e = ready.get(
         [&](int, int* value) {
             *value = 1;
-            {
-                const hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(upfir16x_fused_pre_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+            for (const auto kernel : {upfir16x_fused_pre_kernel, upfir16x_fused_pre_noise_kernel}) {
+                const hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                                            (int)Geo16<4, 2, true>::lds_bytes(0));
                 if (err != hipSuccess) return err;
             }
@@ -917,9 +917,10 @@ hipError_t launch_upfir16_fused(const UpFirArgs& args, hipStream_t stream) {
     const int strip = upfir16_strip(args.W);
     if (strip == 0) return hipErrorInvalidValue;
     if (args.pair_form) {  // (args.w is upfir16x_arrange_weights' image)
-        if (strip != 64 || !args.input_prescaled || args.noise != nullptr) return hipErrorInvalidValue;
+        if (strip != 64 || !args.input_prescaled) return hipErrorInvalidValue;
         const size_t lds_x = Geo16<4, 2, true>::lds_bytes(0);
-        hipLaunchKernelGGL(upfir16x_fused_pre_kernel, dim3(args.total_blocks), dim3(256), lds_x, stream, args);
+        const Kernel kernel_x = args.noise != nullptr ? upfir16x_fused_pre_noise_kernel : upfir16x_fused_pre_kernel;
+        hipLaunchKernelGGL(kernel_x, dim3(args.total_blocks), dim3(256), lds_x, stream, args);
         return hipGetLastError();
     }
     const Variant& v = variants[strip == 64 ? 0 : (strip == 32 ? 1 : 2)];

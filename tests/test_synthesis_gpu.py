@@ -165,23 +165,26 @@ def test_full_size_properties_batch_of_8(library) -> None:
     assert frames.std() > 10  # not a constant image
 
 
-@pytest.mark.parametrize("resolution,batch,noise", [(64, 5, True), (128, 3, True), (256, 2, True), (128, 3, False), (256, 5, False)])
-def test_fused_upsampling_layer_matches_oracle_layerwise(library, resolution: int, batch: int, noise: bool) -> None:
+@pytest.mark.parametrize(
+    "resolution,batch,noise,conv_form",
+    [(64, 5, True, "auto"), (128, 3, True, "auto"), (256, 2, True, "auto"), (128, 3, False, "winograd43"), (256, 5, False, "winograd43"), (256, 3, True, "winograd43")],
+)
+def test_fused_upsampling_layer_matches_oracle_layerwise(library, resolution: int, batch: int, noise: bool, conv_form: str) -> None:
     """
     Conv0_up as ONE kernel (upfir16_fused.hip / upfir_fused.hip: transposed conv + FIR + noise + bias + leaky ReLU),
     forced at a small batch: the planner then cuts the image into row segments (priming steps), 256^2 has
     two 64-column strips (recomputed halo columns) and 8 channel tiles; every term is switched on. The 16 -> 32 and
     32 -> 64 layers run in the kernel's 16- and 32-column strip geometries (steps of 16 position rows, two halo tiles).
-    `noise=False` zeroes the noise strengths (StyleGAN2's own init, the network bench.py times): the layers from 64 -> 128
-    up then run in the kernel's pair form (F(2,2) along x, launch names ending in "/16x"), biases still on.
+    `noise=False` zeroes the noise strengths (StyleGAN2's own init, the network bench.py times), biases still on. With the
+    F(4x4,3x3) kernels on the layers before them ("winograd43": those scale their stores by the up layer's style) the
+    layers from 64 -> 128 up run in the kernel's pair form (F(2,2) along x, launch names ending in "/16x").
     """
     spec = sg2_spec.make_spec(resolution)
     variables = sg2_spec.make_random_variables(resolution, seed=3, perturb=True)
     if not noise:
         variables = {name: (np.zeros_like(value) if name.endswith("/noise_strength") else value) for name, value in variables.items()}
     dlatents = np.random.RandomState(5).randn(batch, spec.num_layers, 512).astype(np.float32)
-    # (the pair form reads input the layer before has scaled by this layer's style: the F(4x4,3x3) kernels do that)
-    engine = hip_lib.Engine(variables, resolution, max_batch=batch, up_form="fused", conv_form="auto" if noise else "winograd43", profile=True)
+    engine = hip_lib.Engine(variables, resolution, max_batch=batch, up_form="fused", conv_form=conv_form, profile=True)
     wants: list = []
     with torch.no_grad():
         ref.g_synthesis(torch.from_numpy(dlatents).double(), variables, resolution, collect=wants)
@@ -193,7 +196,7 @@ def test_fused_upsampling_layer_matches_oracle_layerwise(library, resolution: in
             want = wants[n - 1].numpy()
             rel = np.abs(got - want).max() / np.abs(want).max()
             assert rel < 2e-5, f"conv layer {n} ({conv.scope}): rel err {rel}"
-        if not noise and os.environ.get("GANCE_TUNE_UPFIR16X", "1") != "0" and os.environ.get("GANCE_TUNE_UPFIR16", "1") != "0":
+        if conv_form == "winograd43" and os.environ.get("GANCE_TUNE_UPFIR16X", "1") != "0" and os.environ.get("GANCE_TUNE_UPFIR16", "1") != "0":
             engine.synthesize_w(dlatents)
             pair = [step.name for step in engine.steps() if step.name.endswith("/16x")]
             assert len(pair) == int(np.log2(resolution)) - 6, pair  # every up layer whose input is >= 64 wide
