@@ -62,12 +62,12 @@ def kernel_of_step(step_name: str) -> str:
     """The HIP kernel behind a conv launch of the engine's step table (names: engine.hip)."""
     if step_name.startswith("convTF"):  # ("p": input pre-scaled by the Winograd launch before it; "/16": the 16-channel geometry)
         pre = "_pre" if step_name.startswith("convTFp") else ""
-        if step_name.endswith("/16x"):
-            return "upfir16x_fused_pre_kernel"  # the pair form (F(2,2) along x)
-        if not step_name.endswith("/16"):
+        if not step_name.endswith(("/16", "/16x")):
             return f"upfir_fused{pre}_kernel"
         side = int(re.search(r"_(\d+)x\1_", step_name).group(1)) // 2  # the layer's INPUT width picks the strip geometry
         geometry = "" if side % 64 == 0 else ("_w32" if side == 32 else "_w16")
+        if step_name.endswith("/16x"):
+            return f"upfir16x_fused{geometry}_pre_kernel"  # the pair form (F(2,2) along x)
         return f"upfir16_fused{geometry}{pre}_kernel"  # (the launches of a network with noise: ..._noise_kernel)
     if step_name.startswith("convV"):
         narrow = "_32x32_" in step_name  # the 32 x 32 pixel geometry

@@ -101,7 +101,7 @@ struct Geo16 {
     static constexpr int kWin = kFR + 3;          // its window rows
     static constexpr int kNzPieces = RW * kPassRows * 2 * kSW / 256;  // noise of a step's output rows in 1 KiB DMA pieces: 8 / 8 / 4
     static_assert(kNzPieces % 4 == 0 && kStageFloats + kNzPieces * 256 <= kSlot, "the step's noise lies behind the T window in ring slot 1");
-    static_assert(kTiles % 4 == 0 && kStageFloats <= kSlot && kPiecesPerWave <= 4 * 2 * kGroups && (!WX || CT == 4), "geometry");
+    static_assert(kTiles % 4 == 0 && kStageFloats <= kSlot && kPiecesPerWave <= 4 * 2 * kGroups && (!WX || CT % 2 == 0), "geometry");
     // LDS (floats): ring slot 0 | ring slot 1 = T window of a pass | carry | style [Cin] | demod [16] | bias [16] | next style [16]
     static constexpr int kStageOff = kSlot, kCarryOff = 2 * kSlot, kConstOff = kCarryOff + kCarryFloats;
     static constexpr size_t lds_bytes(int cin) { return sizeof(float) * ((size_t)kConstOff + cin + 3 * kBM); }
@@ -142,6 +142,7 @@ __device__ __forceinline__ void upfir16_body(const UpFirArgs& p) {
     constexpr int kGroups = G::kGroups, kTiles = G::kTiles, kHaloTiles = G::kHaloTiles, kCG = G::kCG, kFR = G::kFR, kWin = G::kWin;
     constexpr int kWlPieces = G::kWlPieces, kWlRegion = G::kWlRegion;
     constexpr bool WX = G::WX;
+    constexpr int kPT = CT / 2 > 0 ? CT / 2 : 1;  // pair tiles (16 pairs = 32 position columns) per row of the strip
     static_assert(!WX || kPre, "the pair form takes its input pre-scaled (no room for the style vector beside two blocks' LDS)");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* const ring0 = smem;
@@ -312,10 +313,10 @@ __device__ __forceinline__ void upfir16_body(const UpFirArgs& p) {
         // direct form: [class][tile: row rw * CT + column tile ct]. Pair form: accw[pair tile: row rw * 2 + pt][product]: 0..2 = EE (m1, m2,
         // m3), 3, 4 = EO at x = 2 n, 2 n + 1, 5..7 = OE (m1, m2, m3), 8, 9 = OO at 2 n, 2 n + 1 (acc is then unused and folds away)
         f32x4 acc[4][kTiles];
-        f32x4 accw[WX ? 2 * RW : 1][10];
+        f32x4 accw[WX ? kPT * RW : 1][10];
         if constexpr (WX) {
 #pragma unroll
-            for (int t4 = 0; t4 < 2 * RW; ++t4)
+            for (int t4 = 0; t4 < kPT * RW; ++t4)
 #pragma unroll
                 for (int c = 0; c < 10; ++c) accw[t4][c] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
@@ -361,15 +362,15 @@ __device__ __forceinline__ void upfir16_body(const UpFirArgs& p) {
                 constexpr int kNG = 2 * RW;  // groups per chunk: (k-step, row of the wave)
                 // (one set of weight fragments: 160 accumulators leave no room for two -- the second k-step's twelve are read behind the
                 // first one's last MFMAs and waited for there; the other block's wave covers the gap)
-                float a[1][12], raw[2][2][2][3], bh[kHaloTiles][4];
+                float a[1][12], raw[2][kPT][2][3], bh[kHaloTiles][4];
                 const unsigned a_lb = lds_a + ring_bytes, b_lb = lds_b + ring_bytes;
                 auto load_a = [&](int jj, float(&dst)[12]) {
 #pragma unroll
                     for (int t = 0; t < 12; ++t) asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(dst[t]) : "v"(a_lb), "i"((t * kKC + 4 * jj) * kBM * 4));
                 };
-                auto load_raw = [&](int grp, float(&dst)[2][2][3]) {  // group grp = (k-step grp / RW, row grp % RW): [pair tile][dy][column]
+                auto load_raw = [&](int grp, float(&dst)[kPT][2][3]) {  // group grp = (k-step grp / RW, row grp % RW): [pair tile][dy][column]
 #pragma unroll
-                    for (int pt = 0; pt < 2; ++pt)
+                    for (int pt = 0; pt < kPT; ++pt)
 #pragma unroll
                         for (int dy = 0; dy < 2; ++dy)
 #pragma unroll
@@ -389,10 +390,14 @@ __device__ __forceinline__ void upfir16_body(const UpFirArgs& p) {
                                 asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(bh[ht][2 * dy + dx]) : "v"(h_lb), "i"((4 * jj * kPlane + (1 - dy) * kPW + 1 - dx) * 4));
                     }
                 };
-                auto land_raw = [&](float(&x)[2][2][3]) {
-                    asm volatile("s_waitcnt lgkmcnt(0)"
-                                 : "+v"(x[0][0][0]), "+v"(x[0][0][1]), "+v"(x[0][0][2]), "+v"(x[0][1][0]), "+v"(x[0][1][1]), "+v"(x[0][1][2]),
-                                   "+v"(x[1][0][0]), "+v"(x[1][0][1]), "+v"(x[1][0][2]), "+v"(x[1][1][0]), "+v"(x[1][1][1]), "+v"(x[1][1][2]));
+                auto land_raw = [&](float(&x)[kPT][2][3]) {
+                    if constexpr (kPT == 2)
+                        asm volatile("s_waitcnt lgkmcnt(0)"
+                                     : "+v"(x[0][0][0]), "+v"(x[0][0][1]), "+v"(x[0][0][2]), "+v"(x[0][1][0]), "+v"(x[0][1][1]), "+v"(x[0][1][2]),
+                                       "+v"(x[kPT - 1][0][0]), "+v"(x[kPT - 1][0][1]), "+v"(x[kPT - 1][0][2]), "+v"(x[kPT - 1][1][0]), "+v"(x[kPT - 1][1][1]),
+                                       "+v"(x[kPT - 1][1][2]));
+                    else
+                        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(x[0][0][0]), "+v"(x[0][0][1]), "+v"(x[0][0][2]), "+v"(x[0][1][0]), "+v"(x[0][1][1]), "+v"(x[0][1][2]));
                 };
                 auto land_a = [&](float(&x)[12]) {
                     asm volatile("" : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(x[4]), "+v"(x[5]), "+v"(x[6]), "+v"(x[7]), "+v"(x[8]), "+v"(x[9]), "+v"(x[10]), "+v"(x[11]));
@@ -415,9 +420,9 @@ __device__ __forceinline__ void upfir16_body(const UpFirArgs& p) {
                     if (grp + 1 < kNG) load_raw(grp + 1, raw[(grp + 1) & 1]);
                     __builtin_amdgcn_sched_barrier(0);
                     // the group's fragments: two subtractions per pair tile and row tap
-                    float bw[2][2][4];
+                    float bw[kPT][2][4];
 #pragma unroll
-                    for (int pt = 0; pt < 2; ++pt)
+                    for (int pt = 0; pt < kPT; ++pt)
 #pragma unroll
                         for (int dy = 0; dy < 2; ++dy) {
                             const float e0 = raw[grp & 1][pt][dy][0], e1 = raw[grp & 1][pt][dy][1], e2 = raw[grp & 1][pt][dy][2];
@@ -428,9 +433,12 @@ __device__ __forceinline__ void upfir16_body(const UpFirArgs& p) {
                         }
                     // (the MFMAs below are inline assembly: hipcc knows no hazard of theirs. The eight differences are tied to a two-cycle
                     // wait here -- a vector write needs two wait states before an MFMA reads it -- and every MFMA reads them after it.)
-                    asm volatile("s_nop 1"
-                                 : "+v"(bw[0][0][0]), "+v"(bw[0][0][2]), "+v"(bw[0][1][0]), "+v"(bw[0][1][2]), "+v"(bw[1][0][0]), "+v"(bw[1][0][2]),
-                                   "+v"(bw[1][1][0]), "+v"(bw[1][1][2]));
+                    if constexpr (kPT == 2)
+                        asm volatile("s_nop 1"
+                                     : "+v"(bw[0][0][0]), "+v"(bw[0][0][2]), "+v"(bw[0][1][0]), "+v"(bw[0][1][2]), "+v"(bw[kPT - 1][0][0]), "+v"(bw[kPT - 1][0][2]),
+                                       "+v"(bw[kPT - 1][1][0]), "+v"(bw[kPT - 1][1][2]));
+                    else
+                        asm volatile("s_nop 1" : "+v"(bw[0][0][0]), "+v"(bw[0][0][2]), "+v"(bw[0][1][0]), "+v"(bw[0][1][2]));
                     // 15 MFMAs per pair tile as (weight slot, fragment, product): ordered so that the two row taps of a product are far apart
                     constexpr int kOps[15][4] = {  // {slot, dy, fragment, product}
                         {0, 0, 0, 0}, {1, 0, 1, 1}, {2, 0, 2, 2}, {6, 0, 1, 3}, {6, 0, 3, 4}, {8, 0, 0, 5}, {9, 0, 1, 6}, {10, 0, 2, 7},
@@ -441,9 +449,9 @@ __device__ __forceinline__ void upfir16_body(const UpFirArgs& p) {
                         // (in the accumulate-in-place form by hand: with 160 accumulators hipcc's builtin took the form whose result is
                         // another register tuple than its addend and rotated the accumulators through spare tuples it did not have: spills.
                         // Products of one accumulator are ten MFMAs apart: no dependent pair back to back.)
-                        for (int pt = 0; pt < 2; ++pt)
+                        for (int pt = 0; pt < kPT; ++pt)
                             asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0"
-                                         : "+v"(accw[2 * rw + pt][kOps[op][3]])
+                                         : "+v"(accw[kPT * rw + pt][kOps[op][3]])
                                          : "v"(a[0][kOps[op][0]]), "v"(bw[pt][kOps[op][1]][kOps[op][2]]));
                         // the halo tiles (direct form, one class per wave) with the k-step's first group: nine taps beside the first nine products
                         if (rw == 0 && op < 9 && wave == tap_cls(op)) {
@@ -606,7 +614,7 @@ __device__ __forceinline__ void upfir16_body(const UpFirArgs& p) {
                         for (int j = 0; j < kKC / 4; ++j) {
                             if (wave == 0) {
 #pragma unroll
-                                for (int pt = 0; pt < 2; ++pt) {
+                                for (int pt = 0; pt < kPT; ++pt) {
                                     const float* const src = Pl + boff + n16 + 4 * j * kPlane - kPW + 32 * pt;
                                     const float e0 = src[-1], e1 = src[0], e2 = src[1];
                                     accw[pt][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(Wl[(3 * kKC + 4 * j) * kBM], e0 - e1, accw[pt][0], 0, 0, 0);
@@ -704,8 +712,8 @@ __device__ __forceinline__ void upfir16_body(const UpFirArgs& p) {
                     // pair form: the output transform (y0 = m1 + m2, y1 = m2 - m3) on the way out; a lane holds the FOUR consecutive T
                     // columns of its pair per row parity: T columns 4 n .. 4 n + 3 of the pair tile = (EE y0, EO x0, EE y1, EO x1) / (OE y0, OO x0, OE y1, OO x1)
 #pragma unroll
-                    for (int pt = 0; pt < 2; ++pt) {
-                        const f32x4 (&m)[10] = accw[2 * rw + pt];
+                    for (int pt = 0; pt < kPT; ++pt) {
+                        const f32x4 (&m)[10] = accw[kPT * rw + pt];
                         float* const dst = stage + dump_base + 2 * en16 + 64 * pt;  // (dump_base holds 2 n16 + 1: pairs are 4 T columns apart)
                         dst[0] = m[0][g] + m[1][g];
                         dst[1] = m[3][g];
@@ -826,7 +834,7 @@ void upfir16_arrange_weights(const float* w_in, int cin, int cout, const int* up
 }
 
 // The pair form (Geo16<4, 2, true>: F(2,2) along x on the classes with two taps there): inputs whose width the 64-column strips tile.
-bool upfir16x_supported(int cin, int cout, int H, int W) { return upfir16_supported(cin, cout, H, W) && W % 64 == 0; }
+bool upfir16x_supported(int cin, int cout, int H, int W) { return upfir16_supported(cin, cout, H, W) && (W % 64 == 0 || W == 32); }
 size_t upfir16x_weight_floats(int cin, int cout) { return (size_t)(cout / kBM) * (cin / kKC) * Geo16<4, 2, true>::kWlRegion; }
 
 // w_out: [m tile of 16][chunk of 8][12 slots][ci 0..7][row m 0..15]; with filter taps in the slot order of the direct image (t0..t8 =
@@ -882,6 +890,8 @@ GANCE_UPFIR16_KERNELS(_w16, 1, 4)
 // the pair form: input pre-scaled only
 __global__ __launch_bounds__(256, 2) void upfir16x_fused_pre_kernel(const UpFirArgs p) { upfir16_body<Geo16<4, 2, true>, true, false>(p); }
 __global__ __launch_bounds__(256, 2) void upfir16x_fused_pre_noise_kernel(const UpFirArgs p) { upfir16_body<Geo16<4, 2, true>, true, true>(p); }
+__global__ __launch_bounds__(256, 2) void upfir16x_fused_w32_pre_kernel(const UpFirArgs p) { upfir16_body<Geo16<2, 4, true>, true, false>(p); }
+__global__ __launch_bounds__(256, 2) void upfir16x_fused_w32_pre_noise_kernel(const UpFirArgs p) { upfir16_body<Geo16<2, 4, true>, true, true>(p); }
 
 hipError_t launch_upfir16_fused(const UpFirArgs& args, hipStream_t stream) {
     using Kernel = void (*)(const UpFirArgs);
@@ -904,6 +914,11 @@ hipError_t launch_upfir16_fused(const UpFirArgs& args, hipStream_t stream) {
                                                            (int)Geo16<4, 2, true>::lds_bytes(0));
                 if (err != hipSuccess) return err;
             }
+            for (const auto kernel : {upfir16x_fused_w32_pre_kernel, upfir16x_fused_w32_pre_noise_kernel}) {
+                const hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                           (int)Geo16<2, 4, true>::lds_bytes(0));
+                if (err != hipSuccess) return err;
+            }
             for (const Variant& v : variants)
                 for (int i = 0; i < 4; ++i) {
                     const hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(v.kernel[i]), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -917,9 +932,11 @@ hipError_t launch_upfir16_fused(const UpFirArgs& args, hipStream_t stream) {
     const int strip = upfir16_strip(args.W);
     if (strip == 0) return hipErrorInvalidValue;
     if (args.pair_form) {  // (args.w is upfir16x_arrange_weights' image)
-        if (strip != 64 || !args.input_prescaled) return hipErrorInvalidValue;
-        const size_t lds_x = Geo16<4, 2, true>::lds_bytes(0);
-        const Kernel kernel_x = args.noise != nullptr ? upfir16x_fused_pre_noise_kernel : upfir16x_fused_pre_kernel;
+        if (strip < 32 || !args.input_prescaled) return hipErrorInvalidValue;
+        const size_t lds_64 = Geo16<4, 2, true>::lds_bytes(0), lds_32 = Geo16<2, 4, true>::lds_bytes(0);
+        const size_t lds_x = strip == 64 ? lds_64 : lds_32;
+        const Kernel kernel_x = strip == 64 ? (args.noise != nullptr ? upfir16x_fused_pre_noise_kernel : upfir16x_fused_pre_kernel)
+                                            : (args.noise != nullptr ? upfir16x_fused_w32_pre_noise_kernel : upfir16x_fused_w32_pre_kernel);
         hipLaunchKernelGGL(kernel_x, dim3(args.total_blocks), dim3(256), lds_x, stream, args);
         return hipGetLastError();
     }

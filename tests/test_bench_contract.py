@@ -22,6 +22,7 @@ def test_step_names_map_to_kernels_and_executed_flops() -> None:
     assert bench.kernel_of_step("convTFp15_1024x1024_64->32") == "upfir_fused_pre_kernel"
     assert bench.kernel_of_step("convTFp15_1024x1024_64->32/16") == "upfir16_fused_pre_kernel"
     assert bench.kernel_of_step("convTFp15_1024x1024_64->32/16x") == "upfir16x_fused_pre_kernel"
+    assert bench.kernel_of_step("convTFp7_64x64_512->512/16x") == "upfir16x_fused_w32_pre_kernel"
     assert bench.kernel_of_step("convTFp7_64x64_512->512/16") == "upfir16_fused_w32_pre_kernel"
     assert bench.kernel_of_step("convTF5_32x32_512->512/16") == "upfir16_fused_w16_kernel"
     assert bench.kernel_of_step("convW16+rgb_1024x1024_32->32") == "winograd64_c32_rgb_kernel"

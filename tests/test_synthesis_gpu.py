@@ -167,7 +167,7 @@ def test_full_size_properties_batch_of_8(library) -> None:
 
 @pytest.mark.parametrize(
     "resolution,batch,noise,conv_form",
-    [(64, 5, True, "auto"), (128, 3, True, "auto"), (256, 2, True, "auto"), (128, 3, False, "winograd43"), (256, 5, False, "winograd43"), (256, 3, True, "winograd43")],
+    [(64, 5, True, "auto"), (128, 3, True, "auto"), (256, 2, True, "auto"), (128, 3, False, "winograd43"), (256, 5, False, "winograd43"), (256, 3, True, "winograd43"), (64, 5, True, "winograd43")],
 )
 def test_fused_upsampling_layer_matches_oracle_layerwise(library, resolution: int, batch: int, noise: bool, conv_form: str) -> None:
     """
@@ -177,7 +177,7 @@ def test_fused_upsampling_layer_matches_oracle_layerwise(library, resolution: in
     32 -> 64 layers run in the kernel's 16- and 32-column strip geometries (steps of 16 position rows, two halo tiles).
     `noise=False` zeroes the noise strengths (StyleGAN2's own init, the network bench.py times), biases still on. With the
     F(4x4,3x3) kernels on the layers before them ("winograd43": those scale their stores by the up layer's style) the
-    layers from 64 -> 128 up run in the kernel's pair form (F(2,2) along x, launch names ending in "/16x").
+    layers from 32 -> 64 up run in the kernel's pair form (F(2,2) along x, launch names ending in "/16x").
     """
     spec = sg2_spec.make_spec(resolution)
     variables = sg2_spec.make_random_variables(resolution, seed=3, perturb=True)
@@ -199,7 +199,7 @@ def test_fused_upsampling_layer_matches_oracle_layerwise(library, resolution: in
         if conv_form == "winograd43" and os.environ.get("GANCE_TUNE_UPFIR16X", "1") != "0" and os.environ.get("GANCE_TUNE_UPFIR16", "1") != "0":
             engine.synthesize_w(dlatents)
             pair = [step.name for step in engine.steps() if step.name.endswith("/16x")]
-            assert len(pair) == int(np.log2(resolution)) - 6, pair  # every up layer whose input is >= 64 wide
+            assert len(pair) == int(np.log2(resolution)) - 5, pair  # every up layer whose input is >= 32 wide
     finally:
         engine.close()
 

@@ -10,7 +10,7 @@ with tempfile.NamedTemporaryFile(suffix=".s") as out:
                    check=True, cwd=src.parent, stderr=subprocess.DEVNULL)
     text = Path(out.name).read_text()
 bad = False
-names = [f"upfir16_fused{geo}{pre}{noise}_kernel" for geo in ("", "_w32", "_w16") for pre in ("", "_pre") for noise in ("", "_noise")] + ["upfir16x_fused_pre_kernel", "upfir16x_fused_pre_noise_kernel"]
+names = [f"upfir16_fused{geo}{pre}{noise}_kernel" for geo in ("", "_w32", "_w16") for pre in ("", "_pre") for noise in ("", "_noise")] + [f"upfir16x_fused{geo}_pre{noise}_kernel" for geo in ("", "_w32") for noise in ("", "_noise")]
 for name in names:
     start = text.index(f"_ZN5gance{len(name)}{name}ENS_9UpFirArgsE:")
     end = text.index(".Lfunc_end", start)
