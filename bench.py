@@ -69,6 +69,8 @@ def kernel_of_step(step_name: str) -> str:
         if step_name.endswith("/16x"):
             return f"upfir16x_fused{geometry}_pre_kernel"  # the pair form (F(2,2) along x)
         return f"upfir16_fused{geometry}{pre}_kernel"  # (the launches of a network with noise: ..._noise_kernel)
+    if step_name.startswith("convTG"):
+        return "upgemm_kernel"  # the scatter form of the two smallest up layers (up_gemm.hip; + its pack and gather kernels)
     if step_name.startswith("convV"):
         narrow = "_32x32_" in step_name  # the 32 x 32 pixel geometry
         return ("winograd43_w32" if narrow else "winograd43") + ("_rgb_kernel" if "+rgb" in step_name else "_kernel")
@@ -423,7 +425,7 @@ def batch_sweep(resolution: int, variables, device, batches, steps: int = 20, wa
         "workload": "BASELINE.json configs[1] at other batch sizes (SURVEY.md section 8(d) config 2): random-z synthesis, z and frames resident in HBM",
         "timing": f"HIP events on the launch stream around {steps} engine calls after {warmup} warm-up calls, per batch size",
         "forms_legend": "conv<N> direct form, convW F(2x2,3x3), convV F(4x4,3x3), +rgb ToRGB channel sum in the epilogue, +torgb fused ToRGB + uint8; "
-        "convT two-pass up layer (+ fir pass), convTF / convTFp one fused up kernel (p: input pre-scaled by its style)",
+        "convT two-pass up layer (+ fir pass), convTG its scatter form (one dense GEMM + gather, + fir pass), convTF / convTFp one fused up kernel (p: input pre-scaled by its style)",
         "by_batch": rows,
     }
 

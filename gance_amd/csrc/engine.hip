@@ -209,6 +209,7 @@ struct gance_workspace {
     std::vector<float*> act;      // per conv layer: zero-bordered output [Bmax][cout][res+2][res+8]
     std::vector<float*> tplanes;  // per up layer: [4 cls][max_units][cout][H+3][W+8] (else nullptr)
     float* slabs = nullptr;       // split-K scratch of the small stride-1 convs (dense)
+    float *up_packed = nullptr, *up_prod = nullptr;  // the scatter-form up layers' GEMM operand image and product (up_gemm.hip)
     float* ybuf[2] = {nullptr, nullptr};
     float* rgb_coef = nullptr;  // [Bmax][8 m tiles][16][64]: A operands of a ToRGB product fused into a Winograd conv epilogue
     float* rgb_part = nullptr;  // [m tiles][Bmax][3][R][R]: its partial images where a pixel's channels span several blocks
@@ -236,6 +237,8 @@ struct gance_workspace {
         for (float* ptr : act) hipFree(ptr);
         for (float* ptr : tplanes) hipFree(ptr);
         hipFree(slabs);
+        hipFree(up_packed);
+        hipFree(up_prod);
         hipFree(ybuf[0]);
         hipFree(ybuf[1]);
         hipFree(rgb_coef);
@@ -279,6 +282,8 @@ struct gance_engine {
     std::vector<size_t> wino43_w;  // F(4x4, 3x3) weights (winograd43_conv.hip), SIZE_MAX where the layer does not take that form
     std::vector<size_t> upfir_w;  // fused transposed-conv + FIR kernel's weight image of the up layers that support it (else SIZE_MAX)
     std::vector<size_t> upfir16_w;  // the same for its 16-channel, two-blocks-per-CU geometry (upfir16_fused.hip)
+    std::vector<size_t> upgemm_w;  // weight image of the scatter-form GEMM of the two smallest up layers (up_gemm.hip; else SIZE_MAX)
+    size_t up_packed_floats = 0, up_prod_floats = 0;
     std::vector<size_t> upfir16x_w;  // ... and for that geometry's pair form (F(2,2) along x: 15 MFMAs per pair of columns instead of 18)
     int num_cus = 256;
     std::vector<float> conv_ns;
@@ -377,6 +382,17 @@ static int upfir16x_mode() {
         return v ? std::atoi(v) : 1;
     }();
     return mode;
+}
+
+// GANCE_TUNE_UPGEMM (read once per process): the two smallest up layers (4x4 -> 8x8, 8x8 -> 16x16) run in scatter form (up_gemm.hip:
+// one dense GEMM, no position grid to tile) when a call has at least this many GEMM columns (samples x input positions); 0 = never.
+// Default 512: from 8 samples at 8x8, 32 at 4x4 -- below that the GEMM has too few column tiles to fill the chip.
+static int upgemm_min_columns() {
+    static const int columns = [] {
+        const char* v = std::getenv("GANCE_TUNE_UPGEMM");
+        return v ? std::atoi(v) : 512;
+    }();
+    return columns;
 }
 
 // Largest resolution whose Conv1 runs in Winograd F(4x4, 3x3) form (winograd43_conv.hip) in an engine with these
@@ -759,12 +775,41 @@ int synthesize_from_dlat(gance_engine* e, const float* d_dlat, int B, uint8_t* d
             const long long tc = (long long)t_plane(H);
             const long long unit = tc * c.cout;
             const long long cls_stride = unit * e->t_units[li];
-            std::snprintf(name, sizeof(name), "convT%d_%dx%d_%d->%d", c.layer_idx, res, res, c.cin,
-                          c.cout);
-            int rc = run_conv(e, c, li, p, x_in, x_b_stride, H, W, e->ws->tplanes[li],
-                              gance::kEpilogueRaw, W + 8, 1, 4, unit, tc, unit * B, cls_stride, B,
-                              stream, name);
-            if (rc) return rc;
+            const bool scatter = e->upgemm_w[li] != SIZE_MAX && B * H * W >= upgemm_min_columns();
+            if (scatter) {
+                // ("convTG": pack + GEMM + gather, up_gemm.hip)
+                std::snprintf(name, sizeof(name), "convTG%d_%dx%d_%d->%d", c.layer_idx, res, res, c.cin, c.cout);
+                gance::UpGemmArgs g{};
+                g.x = x_in;
+                g.w = e->pool + e->upgemm_w[li];
+                g.s = e->ws->styles + e->conv_s_off[li];
+                g.d = e->ws->demod + e->conv_d_off[li];
+                g.packed = e->ws->up_packed;
+                g.prod = e->ws->up_prod;
+                g.t = e->ws->tplanes[li];
+                g.x_b_stride = x_b_stride;
+                g.cls_stride = cls_stride;
+                g.unit_stride = unit;
+                g.B = B;
+                g.Cin = c.cin;
+                g.Cout = c.cout;
+                g.H = H;
+                g.W = W;
+                g.s_stride = e->ctot;
+                g.d_stride = e->dtot;
+                g.n_tiles = gance::upgemm_n_tiles(B, H, W);
+                const double n = (double)g.n_tiles * 128;
+                StepScope scope(e, stream, name, 2.0 * 9 * c.cin * c.cout * (double)B * H * W,
+                                4.0 * (9.0 * c.cin * c.cout + 2.0 * c.cin * n + 2.0 * 9 * c.cout * n + 4.0 * unit * B));
+                GANCE_HIP_CHECK(gance::launch_upgemm(g, stream));
+            } else {
+                std::snprintf(name, sizeof(name), "convT%d_%dx%d_%d->%d", c.layer_idx, res, res, c.cin,
+                              c.cout);
+                int rc = run_conv(e, c, li, p, x_in, x_b_stride, H, W, e->ws->tplanes[li],
+                                  gance::kEpilogueRaw, W + 8, 1, 4, unit, tc, unit * B, cls_stride, B,
+                                  stream, name);
+                if (rc) return rc;
+            }
             gance::FirArgs f{};
             f.t = e->ws->tplanes[li];
             f.cls_stride = cls_stride;
@@ -778,7 +823,7 @@ int synthesize_from_dlat(gance_engine* e, const float* d_dlat, int B, uint8_t* d
             f.C = c.cout;
             f.H = H;
             f.W = W;
-            f.nsplit = p.nsplit;
+            f.nsplit = scatter ? 1 : p.nsplit;
             f.s_next = s_next;
             f.s_next_stride = e->ctot;
             std::snprintf(name, sizeof(name), "fir%d_%dx%d", c.layer_idx, res, res);
@@ -879,6 +924,8 @@ int acquire_workspace(gance_engine* e) {
         if (ok && c.up)
             ok = alloc((void**)&ws->tplanes[i], (size_t)4 * e->t_units[i] * c.cout * t_plane((1 << c.res_log2) / 2) * sizeof(float), true);
     }
+    ok = ok && alloc((void**)&ws->up_packed, std::max<size_t>(1, e->up_packed_floats) * sizeof(float), false) &&
+         alloc((void**)&ws->up_prod, std::max<size_t>(1, e->up_prod_floats) * sizeof(float), false);
     ok = ok && alloc((void**)&ws->slabs, e->slab_floats * sizeof(float), false) &&
          alloc((void**)&ws->ybuf[0], e->y_floats * sizeof(float), false) && alloc((void**)&ws->ybuf[1], e->y_floats * sizeof(float), false) &&
          alloc((void**)&ws->rgb_coef, (size_t)Bmax * 8 * 16 * 64 * sizeof(float), false) &&
@@ -1101,6 +1148,13 @@ int gance_engine_create(const gance_engine_config* config, const float* host_wei
             e->upfir16_w[i] = reserve(gance::upfir16_weight_floats(c.cin, c.cout));
             gance::upfir16_arrange_weights(scaled.data(), c.cin, c.cout, kUpTapWeight, &pool[e->upfir16_w[i]]);
         }
+        e->upgemm_w.push_back(SIZE_MAX);
+        if (c.up && upgemm_min_columns() > 0 && gance::upgemm_supported(c.cin, c.cout, (1 << c.res_log2) / 2, (1 << c.res_log2) / 2)) {
+            std::vector<float> scaled(wn);
+            for (size_t j = 0; j < wn; ++j) scaled[j] = src[j] * coef;
+            e->upgemm_w[i] = reserve(gance::upgemm_weight_floats(c.cin, c.cout));
+            gance::upgemm_arrange_weights(scaled.data(), c.cin, c.cout, kUpTapWeight, &pool[e->upgemm_w[i]]);
+        }
         e->upfir16x_w.push_back(SIZE_MAX);
         if (c.up && upfir16_mode() != 0 && upfir16x_mode() != 0 && gance::upfir16x_supported(c.cin, c.cout, (1 << c.res_log2) / 2, (1 << c.res_log2) / 2)) {
             std::vector<float> scaled(wn);
@@ -1180,6 +1234,15 @@ int gance_engine_create(const gance_engine_config* config, const float* host_wei
         }
     }
     e->slab_floats = slab_max;
+    // the scatter-form up layers' GEMM buffers (whatever this engine's knobs say: the workspace is shared)
+    for (int i = 0; i < nconv; ++i) {
+        const ConvLayerHost& c = e->convs[i];
+        const int H = (1 << c.res_log2) / 2;
+        if (c.up && gance::upgemm_supported(c.cin, c.cout, H, H)) {
+            e->up_packed_floats = std::max(e->up_packed_floats, gance::upgemm_packed_floats(Bmax, c.cin, H, H));
+            e->up_prod_floats = std::max(e->up_prod_floats, gance::upgemm_prod_floats(Bmax, c.cout, H, H));
+        }
+    }
     e->y_floats = (size_t)3 * config->resolution * config->resolution * Bmax;
     // partial ToRGB images of the Winograd conv launches whose pixels span several channel tiles: [Cout / 64][Bmax][3][R][R]
     for (int i = 0; i < nconv; ++i) {

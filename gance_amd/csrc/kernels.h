@@ -217,6 +217,29 @@ bool upfir16x_supported(int cin, int cout, int H, int W);
 size_t upfir16x_weight_floats(int cin, int cout);
 void upfir16x_arrange_weights(const float* w_in /*[9][cin][cout] scaled*/, int cin, int cout, const int* up_tap_weight, float* w_out);
 
+// The two smallest up layers (4x4 -> 8x8, 8x8 -> 16x16) in scatter form (up_gemm.hip): pack (x * style -> the GEMM's B image),
+// ONE dense GEMM P[tap slot * Cout + co][b H W + position] (M = 9 Cout, K = Cin), gather (taps of a class, x demod) into the parity
+// planes the FIR pass reads. Replaces the transposed-conv launch where the position grid tiles badly (81 of 256 tile slots).
+struct UpGemmArgs {
+    const float* x;  // zero-bordered [B][Cin][H+2][W+8]
+    const float* w;  // upgemm_arrange_weights' image
+    const float* s;  // style: s[b * s_stride + ci]
+    const float* d;  // demodulation: d[b * d_stride + co]
+    float* packed;   // workspace: upgemm_packed_floats
+    float* prod;     // workspace: upgemm_prod_floats: P [9 Cout][n_tiles * 128]
+    float* t;        // parity planes: t + cls * cls_stride + b * unit_stride + co * (H+3) * (W+8) + (y'+1) * (W+8) + x'+4
+    long long x_b_stride, cls_stride, unit_stride;
+    int B, Cin, Cout, H, W, s_stride, d_stride;
+    int n_tiles;  // upgemm_n_tiles(B, H, W)
+};
+bool upgemm_supported(int cin, int cout, int H, int W);
+size_t upgemm_weight_floats(int cin, int cout);
+int upgemm_n_tiles(int B, int H, int W);
+size_t upgemm_packed_floats(int B, int cin, int H, int W);
+size_t upgemm_prod_floats(int B, int cout, int H, int W);
+void upgemm_arrange_weights(const float* w_in /*[9][cin][cout] scaled*/, int cin, int cout, const int* up_tap_weight, float* w_out);
+hipError_t launch_upgemm(const UpGemmArgs& args, hipStream_t stream);
+
 // ---- aux_kernels.hip ----
 
 // Mapping network: one dense 512->512 layer with lrelu*sqrt2 (G_mapping DenseN).

@@ -204,6 +204,35 @@ def test_fused_upsampling_layer_matches_oracle_layerwise(library, resolution: in
         engine.close()
 
 
+@pytest.mark.parametrize("resolution,batch", [(16, 33), (8, 40), (32, 9)])
+def test_smallest_up_layers_in_scatter_form_match_oracle_layerwise(library, resolution: int, batch: int) -> None:
+    """
+    The 4x4 -> 8x8 and 8x8 -> 16x16 up layers as one dense GEMM each (up_gemm.hip: pack, GEMM over tap slot x channel rows and
+    sample x position columns, gather into the parity planes, then the FIR pass), which the engine takes from 512 GEMM columns
+    (samples x input positions) up; every term on. The batches are no multiples of the 128-column tiles (padded columns), and
+    (32, 9) has the 8x8 -> 16x16 layer in scatter form (576 columns) and the 4x4 -> 8x8 layer below the threshold (144).
+    """
+    spec = sg2_spec.make_spec(resolution)
+    variables = sg2_spec.make_random_variables(resolution, seed=6, perturb=True)
+    dlatents = np.random.RandomState(8).randn(batch, spec.num_layers, 512).astype(np.float32)
+    engine = hip_lib.Engine(variables, resolution, max_batch=batch, profile=True)
+    wants: list = []
+    with torch.no_grad():
+        ref.g_synthesis(torch.from_numpy(dlatents).double(), variables, resolution, collect=wants)
+    try:
+        for n, conv in enumerate(spec.convs, start=1):
+            got = engine.debug_activation_after(dlatents, n)
+            want = wants[n - 1].numpy()
+            rel = np.abs(got - want).max() / np.abs(want).max()
+            assert rel < 2e-5, f"conv layer {n} ({conv.scope}): rel err {rel}"
+        if os.environ.get("GANCE_TUNE_UPGEMM") is None:
+            engine.synthesize_w(dlatents)
+            scatter = [step.name.split("_")[1] for step in engine.steps() if step.name.startswith("convTG")]
+            assert scatter == [f"{2 * side}x{2 * side}" for side in (4, 8) if batch * side * side >= 512 and 2 * side <= resolution], scatter
+    finally:
+        engine.close()
+
+
 @pytest.mark.parametrize("up_form", ["fused", "split"])
 def test_matrix_path_512_both_upsampling_forms(library, up_form: str) -> None:
     """512^2, every term on: the fused up kernel (4 strips at 256 -> 512) and the two-pass form against the oracle."""
