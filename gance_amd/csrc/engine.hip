@@ -209,7 +209,7 @@ struct gance_workspace {
     std::vector<float*> act;      // per conv layer: zero-bordered output [Bmax][cout][res+2][res+8]
     std::vector<float*> tplanes;  // per up layer: [4 cls][max_units][cout][H+3][W+8] (else nullptr)
     float* slabs = nullptr;       // split-K scratch of the small stride-1 convs (dense)
-    float *up_packed = nullptr, *up_prod = nullptr;  // the scatter-form up layers' GEMM operand image and product (up_gemm.hip)
+    float *up_packed = nullptr, *up_prod = nullptr;  // the GEMM forms' operand images and products (gemm_forms.hip: scatter-form up layers, Winograd at 8x8 / 16x16)
     float* ybuf[2] = {nullptr, nullptr};
     float* rgb_coef = nullptr;  // [Bmax][8 m tiles][16][64]: A operands of a ToRGB product fused into a Winograd conv epilogue
     float* rgb_part = nullptr;  // [m tiles][Bmax][3][R][R]: its partial images where a pixel's channels span several blocks
@@ -282,7 +282,8 @@ struct gance_engine {
     std::vector<size_t> wino43_w;  // F(4x4, 3x3) weights (winograd43_conv.hip), SIZE_MAX where the layer does not take that form
     std::vector<size_t> upfir_w;  // fused transposed-conv + FIR kernel's weight image of the up layers that support it (else SIZE_MAX)
     std::vector<size_t> upfir16_w;  // the same for its 16-channel, two-blocks-per-CU geometry (upfir16_fused.hip)
-    std::vector<size_t> upgemm_w;  // weight image of the scatter-form GEMM of the two smallest up layers (up_gemm.hip; else SIZE_MAX)
+    std::vector<size_t> winogemm_w;  // weight image of the Winograd F(4x4,3x3) GEMM form of the stride-1 layers at 8x8, 16x16 (gemm_forms.hip; else SIZE_MAX)
+    std::vector<size_t> upgemm_w;  // weight image of the scatter-form GEMM of the two smallest up layers (gemm_forms.hip; else SIZE_MAX)
     size_t up_packed_floats = 0, up_prod_floats = 0;
     std::vector<size_t> upfir16x_w;  // ... and for that geometry's pair form (F(2,2) along x: 15 MFMAs per pair of columns instead of 18)
     int num_cus = 256;
@@ -384,13 +385,24 @@ static int upfir16x_mode() {
     return mode;
 }
 
-// GANCE_TUNE_UPGEMM (read once per process): the two smallest up layers (4x4 -> 8x8, 8x8 -> 16x16) run in scatter form (up_gemm.hip:
+// GANCE_TUNE_UPGEMM (read once per process): the two smallest up layers (4x4 -> 8x8, 8x8 -> 16x16) run in scatter form (gemm_forms.hip:
 // one dense GEMM, no position grid to tile) when a call has at least this many GEMM columns (samples x input positions); 0 = never.
 // Default 512: from 8 samples at 8x8, 32 at 4x4 -- below that the GEMM has too few column tiles to fill the chip.
 static int upgemm_min_columns() {
     static const int columns = [] {
         const char* v = std::getenv("GANCE_TUNE_UPGEMM");
         return v ? std::atoi(v) : 512;
+    }();
+    return columns;
+}
+
+// GANCE_TUNE_WINOGEMM (read once per process): the stride-1 layers at 8x8 and 16x16 run in Winograd F(4x4,3x3) GEMM form (gemm_forms.hip)
+// when a call has at least this many GEMM columns (samples x 4x4 output tiles); 0 = never. Default 256: from 16 samples at 16x16, 64 at
+// 8x8. Like every Winograd form it is off in engines created with conv_form "direct" (or "winograd": F(2x2,3x3) only).
+static int winogemm_min_columns() {
+    static const int columns = [] {
+        const char* v = std::getenv("GANCE_TUNE_WINOGEMM");
+        return v ? std::atoi(v) : 256;
     }();
     return columns;
 }
@@ -662,9 +674,39 @@ int synthesize_from_dlat(gance_engine* e, const float* d_dlat, int B, uint8_t* d
                           c.cout);
             const ConvForm form = conv_form_of(li, have_y);
             x_prescaled = false;  // (set below where this launch scales its stores for the next layer)
-            fused_rgb = form.fused_rgb;
+            const bool gemm_form = e->winogemm_w[li] != SIZE_MAX && B * (res / 4) * (res / 4) >= winogemm_min_columns();
+            fused_rgb = form.fused_rgb && !gemm_form;
             const bool winograd = form.winograd, winograd_last = form.winograd_last;
-            if (fused_rgb) {
+            if (gemm_form) {
+                // ("convVG": input transform + 36 GEMMs + output transform, gemm_forms.hip)
+                std::snprintf(name, sizeof(name), "convVG%d_%dx%d_%d->%d", c.layer_idx, res, res, c.cin, c.cout);
+                gance::WinoGemmArgs g{};
+                g.x = x_in;
+                g.w = e->pool + e->winogemm_w[li];
+                g.s = e->ws->styles + e->conv_s_off[li];
+                g.d = e->ws->demod + e->conv_d_off[li];
+                g.noise = noise;
+                g.bias = bias;
+                g.packed = e->ws->up_packed;
+                g.prod = e->ws->up_prod;
+                g.out = x_out;
+                g.x_b_stride = x_b_stride;
+                g.out_b_stride = out_b;
+                g.noise_strength = e->conv_ns[li];
+                g.noise_b_stride = noise_b_stride;
+                g.B = B;
+                g.Cin = c.cin;
+                g.Cout = c.cout;
+                g.H = res;
+                g.W = res;
+                g.s_stride = e->ctot;
+                g.d_stride = e->dtot;
+                g.n_tiles = gance::winogemm_n_tiles(B, res, res);
+                const double n = (double)g.n_tiles * 128;
+                StepScope scope(e, stream, name, 2.0 * 9 * c.cin * c.cout * (double)B * res * res,
+                                4.0 * (36.0 * c.cin * c.cout + 2.0 * 36 * (c.cin + c.cout) * n + (double)B * (c.cin + c.cout) * res * res));
+                GANCE_HIP_CHECK(gance::launch_winogemm(g, stream));
+            } else if (fused_rgb) {
                 const int ri = c.res_log2 - 2;
                 FusedRgb rgb{e->pool + e->rgb_w[ri], e->ws->styles + e->rgb_s_off[ri], e->pool + e->rgb_bias[ri],
                              e->ws->ybuf[ycur], (d_f32 != nullptr || e->keep_skip_image) ? e->ws->ybuf[1 - ycur] : nullptr, d_u8};
@@ -777,7 +819,7 @@ int synthesize_from_dlat(gance_engine* e, const float* d_dlat, int B, uint8_t* d
             const long long cls_stride = unit * e->t_units[li];
             const bool scatter = e->upgemm_w[li] != SIZE_MAX && B * H * W >= upgemm_min_columns();
             if (scatter) {
-                // ("convTG": pack + GEMM + gather, up_gemm.hip)
+                // ("convTG": pack + GEMM + gather, gemm_forms.hip)
                 std::snprintf(name, sizeof(name), "convTG%d_%dx%d_%d->%d", c.layer_idx, res, res, c.cin, c.cout);
                 gance::UpGemmArgs g{};
                 g.x = x_in;
@@ -1148,6 +1190,14 @@ int gance_engine_create(const gance_engine_config* config, const float* host_wei
             e->upfir16_w[i] = reserve(gance::upfir16_weight_floats(c.cin, c.cout));
             gance::upfir16_arrange_weights(scaled.data(), c.cin, c.cout, kUpTapWeight, &pool[e->upfir16_w[i]]);
         }
+        e->winogemm_w.push_back(SIZE_MAX);
+        if (!c.up && i > 0 && winogemm_min_columns() > 0 && wino43_max_res(e->cfg.flags) >= 16 &&
+            gance::winogemm_supported(c.cin, c.cout, 1 << c.res_log2, 1 << c.res_log2)) {
+            std::vector<float> scaled(wn);
+            for (size_t j = 0; j < wn; ++j) scaled[j] = src[j] * coef;
+            e->winogemm_w[i] = reserve(gance::winogemm_weight_floats(c.cin, c.cout));
+            gance::winogemm_arrange_weights(scaled.data(), c.cin, c.cout, &pool[e->winogemm_w[i]]);
+        }
         e->upgemm_w.push_back(SIZE_MAX);
         if (c.up && upgemm_min_columns() > 0 && gance::upgemm_supported(c.cin, c.cout, (1 << c.res_log2) / 2, (1 << c.res_log2) / 2)) {
             std::vector<float> scaled(wn);
@@ -1241,6 +1291,10 @@ int gance_engine_create(const gance_engine_config* config, const float* host_wei
         if (c.up && gance::upgemm_supported(c.cin, c.cout, H, H)) {
             e->up_packed_floats = std::max(e->up_packed_floats, gance::upgemm_packed_floats(Bmax, c.cin, H, H));
             e->up_prod_floats = std::max(e->up_prod_floats, gance::upgemm_prod_floats(Bmax, c.cout, H, H));
+        }
+        if (!c.up && i > 0 && gance::winogemm_supported(c.cin, c.cout, 2 * H, 2 * H)) {
+            e->up_packed_floats = std::max(e->up_packed_floats, gance::winogemm_packed_floats(Bmax, c.cin, 2 * H, 2 * H));
+            e->up_prod_floats = std::max(e->up_prod_floats, gance::winogemm_prod_floats(Bmax, c.cout, 2 * H, 2 * H));
         }
     }
     e->y_floats = (size_t)3 * config->resolution * config->resolution * Bmax;

@@ -217,7 +217,7 @@ bool upfir16x_supported(int cin, int cout, int H, int W);
 size_t upfir16x_weight_floats(int cin, int cout);
 void upfir16x_arrange_weights(const float* w_in /*[9][cin][cout] scaled*/, int cin, int cout, const int* up_tap_weight, float* w_out);
 
-// The two smallest up layers (4x4 -> 8x8, 8x8 -> 16x16) in scatter form (up_gemm.hip): pack (x * style -> the GEMM's B image),
+// The two smallest up layers (4x4 -> 8x8, 8x8 -> 16x16) in scatter form (gemm_forms.hip): pack (x * style -> the GEMM's B image),
 // ONE dense GEMM P[tap slot * Cout + co][b H W + position] (M = 9 Cout, K = Cin), gather (taps of a class, x demod) into the parity
 // planes the FIR pass reads. Replaces the transposed-conv launch where the position grid tiles badly (81 of 256 tile slots).
 struct UpGemmArgs {
@@ -239,6 +239,32 @@ size_t upgemm_packed_floats(int B, int cin, int H, int W);
 size_t upgemm_prod_floats(int B, int cout, int H, int W);
 void upgemm_arrange_weights(const float* w_in /*[9][cin][cout] scaled*/, int cin, int cout, const int* up_tap_weight, float* w_out);
 hipError_t launch_upgemm(const UpGemmArgs& args, hipStream_t stream);
+
+// The stride-1 layers at 8x8 and 16x16 in Winograd F(4x4, 3x3) GEMM form (gemm_forms.hip): input transform into 36 B images, the
+// same GEMM kernel as 36 independent products, output transform + demod + noise + bias + leaky ReLU.
+struct WinoGemmArgs {
+    const float* x;      // zero-bordered [B][Cin][H+2][W+8]
+    const float* w;      // winogemm_arrange_weights' image
+    const float* s;      // style: s[b * s_stride + ci]
+    const float* d;      // demodulation: d[b * d_stride + co]
+    const float* noise;  // [H][W] or nullptr; sample b reads noise + b * noise_b_stride
+    const float* bias;   // [Cout]
+    float* packed;       // workspace: winogemm_packed_floats
+    float* prod;         // workspace: winogemm_prod_floats
+    float* out;          // zero-bordered [B][Cout][H+2][W+8]
+    long long x_b_stride, out_b_stride;
+    float noise_strength;
+    int noise_b_stride;
+    int B, Cin, Cout, H, W, s_stride, d_stride;
+    int n_tiles;  // winogemm_n_tiles(B, H, W)
+};
+bool winogemm_supported(int cin, int cout, int H, int W);
+size_t winogemm_weight_floats(int cin, int cout);
+int winogemm_n_tiles(int B, int H, int W);
+size_t winogemm_packed_floats(int B, int cin, int H, int W);
+size_t winogemm_prod_floats(int B, int cout, int H, int W);
+void winogemm_arrange_weights(const float* w_in /*[9][cin][cout] scaled*/, int cin, int cout, float* w_out);
+hipError_t launch_winogemm(const WinoGemmArgs& args, hipStream_t stream);
 
 // ---- aux_kernels.hip ----
 

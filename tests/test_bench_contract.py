@@ -25,7 +25,10 @@ def test_step_names_map_to_kernels_and_executed_flops() -> None:
     assert bench.kernel_of_step("convTFp7_64x64_512->512/16x") == "upfir16x_fused_w32_pre_kernel"
     assert bench.kernel_of_step("convTFp7_64x64_512->512/16") == "upfir16_fused_w32_pre_kernel"
     assert bench.kernel_of_step("convTF5_32x32_512->512/16") == "upfir16_fused_w16_kernel"
-    assert bench.kernel_of_step("convTG3_16x16_512->512") == "upgemm_kernel"
+    assert bench.kernel_of_step("convTG3_16x16_512->512") == "tile_gemm_kernel"
+    assert bench.kernel_of_step("convVG4_16x16_512->512") == "tile_gemm_kernel"
+    assert bench.executed_fraction("convVG4_16x16_512->512") == 0.25
+    assert abs(bench.executed_fraction("convTFp15_1024x1024_64->32/16x") - 15 / 18) < 1e-12
     assert bench.kernel_of_step("convW16+rgb_1024x1024_32->32") == "winograd64_c32_rgb_kernel"
     assert bench.kernel_of_step("convW8+rgb_64x64_512->512") == "winograd64_rgb_kernel"
     assert bench.kernel_of_step("convW14_512x512_64->64") == "winograd64_kernel"

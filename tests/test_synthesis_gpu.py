@@ -207,7 +207,7 @@ def test_fused_upsampling_layer_matches_oracle_layerwise(library, resolution: in
 @pytest.mark.parametrize("resolution,batch", [(16, 33), (8, 40), (32, 9)])
 def test_smallest_up_layers_in_scatter_form_match_oracle_layerwise(library, resolution: int, batch: int) -> None:
     """
-    The 4x4 -> 8x8 and 8x8 -> 16x16 up layers as one dense GEMM each (up_gemm.hip: pack, GEMM over tap slot x channel rows and
+    The 4x4 -> 8x8 and 8x8 -> 16x16 up layers as one dense GEMM each (gemm_forms.hip: pack, GEMM over tap slot x channel rows and
     sample x position columns, gather into the parity planes, then the FIR pass), which the engine takes from 512 GEMM columns
     (samples x input positions) up; every term on. The batches are no multiples of the 128-column tiles (padded columns), and
     (32, 9) has the 8x8 -> 16x16 layer in scatter form (576 columns) and the 4x4 -> 8x8 layer below the threshold (144).
