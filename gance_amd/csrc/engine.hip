@@ -198,7 +198,7 @@ struct StepRecord {
 }  // namespace
 
 // Per-call scratch (activations, parity planes, split-K slabs, skip images, styles ...): about 0.8 GB per frame
-// of batch capacity at 1024^2 against 135 MB of weights per network. It holds nothing between calls except its
+// of batch capacity at 1024^2 against 0.45 GB of weights per network (135 MB as trained, the rest the same weights as each kernel form's LDS image). It holds nothing between calls except its
 // zero borders, which depend only on the resolution, so every engine of one (device, resolution, max_batch)
 // shares ONE workspace: 20 resident networks cost 20 x weights + 1 x workspace. Calls that share it are ordered
 // by an event (a call waits for the previous user's last kernel, on whatever stream that ran).
@@ -1177,7 +1177,9 @@ int gance_engine_create(const gance_engine_config* config, const float* host_wei
             gance::winograd43_transform_weights(scaled.data(), c.cin, c.cout, &pool[e->wino43_w[i]]);
         }
         e->upfir_w.push_back(SIZE_MAX);
-        if (c.up && gance::upfir_supported(c.cin, c.cout, (1 << c.res_log2) / 2, (1 << c.res_log2) / 2)) {
+        // (the 32-channel kernel's image only where the 16-channel kernel will not take the layer: GANCE_TUNE_UPFIR16=0)
+        if (c.up && gance::upfir_supported(c.cin, c.cout, (1 << c.res_log2) / 2, (1 << c.res_log2) / 2) &&
+            !(upfir16_mode() != 0 && gance::upfir16_supported(c.cin, c.cout, (1 << c.res_log2) / 2, (1 << c.res_log2) / 2))) {
             std::vector<float> scaled(wn);
             for (size_t j = 0; j < wn; ++j) scaled[j] = src[j] * coef;
             e->upfir_w[i] = reserve(gance::upfir_weight_floats(c.cin, c.cout));

