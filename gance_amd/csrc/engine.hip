@@ -285,6 +285,7 @@ struct gance_engine {
     std::vector<size_t> winogemm_w;  // weight image of the Winograd F(4x4,3x3) GEMM form of the stride-1 layers at 8x8, 16x16 (gemm_forms.hip; else SIZE_MAX)
     std::vector<size_t> upgemm_w;  // weight image of the scatter-form GEMM of the two smallest up layers (gemm_forms.hip; else SIZE_MAX)
     size_t up_packed_floats = 0, up_prod_floats = 0;
+    bool gemm_bf16 = false;  // experiment (GANCE_TUNE_GEMM_BF16X6=1 when the engine is created): the GEMM forms on the bf16 matrix cores from split operands
     std::vector<size_t> upfir16x_w;  // ... and for that geometry's pair form (F(2,2) along x: 15 MFMAs per pair of columns instead of 18)
     int num_cus = 256;
     std::vector<float> conv_ns;
@@ -702,6 +703,7 @@ int synthesize_from_dlat(gance_engine* e, const float* d_dlat, int B, uint8_t* d
                 g.s_stride = e->ctot;
                 g.d_stride = e->dtot;
                 g.n_tiles = gance::winogemm_n_tiles(B, res, res);
+                g.bf16_split = e->gemm_bf16 ? 1 : 0;
                 const double n = (double)g.n_tiles * 128;
                 StepScope scope(e, stream, name, 2.0 * 9 * c.cin * c.cout * (double)B * res * res,
                                 4.0 * (36.0 * c.cin * c.cout + 2.0 * 36 * (c.cin + c.cout) * n + (double)B * (c.cin + c.cout) * res * res));
@@ -840,6 +842,7 @@ int synthesize_from_dlat(gance_engine* e, const float* d_dlat, int B, uint8_t* d
                 g.s_stride = e->ctot;
                 g.d_stride = e->dtot;
                 g.n_tiles = gance::upgemm_n_tiles(B, H, W);
+                g.bf16_split = e->gemm_bf16 ? 1 : 0;
                 const double n = (double)g.n_tiles * 128;
                 StepScope scope(e, stream, name, 2.0 * 9 * c.cin * c.cout * (double)B * H * W,
                                 4.0 * (9.0 * c.cin * c.cout + 2.0 * c.cin * n + 2.0 * 9 * c.cout * n + 4.0 * unit * B));
@@ -1061,6 +1064,10 @@ int gance_engine_create(const gance_engine_config* config, const float* host_wei
     GANCE_HIP_CHECK(hipDeviceGetAttribute(&num_cus, hipDeviceAttributeMultiprocessorCount, config->device));
 
     gance_engine* e = new gance_engine();
+    {  // (read per engine, not once per process: a test creates engines with and without it)
+        const char* v = std::getenv("GANCE_TUNE_GEMM_BF16X6");
+        e->gemm_bf16 = v != nullptr && std::atoi(v) != 0;
+    }
     e->cfg = *config;
     e->num_cus = num_cus > 0 ? num_cus : 256;
     e->res_log2 = res_log2;
@@ -1197,15 +1204,17 @@ int gance_engine_create(const gance_engine_config* config, const float* host_wei
             gance::winogemm_supported(c.cin, c.cout, 1 << c.res_log2, 1 << c.res_log2)) {
             std::vector<float> scaled(wn);
             for (size_t j = 0; j < wn; ++j) scaled[j] = src[j] * coef;
-            e->winogemm_w[i] = reserve(gance::winogemm_weight_floats(c.cin, c.cout));
-            gance::winogemm_arrange_weights(scaled.data(), c.cin, c.cout, &pool[e->winogemm_w[i]]);
+            e->winogemm_w[i] = reserve(gance::winogemm_weight_floats(c.cin, c.cout) * (e->gemm_bf16 ? 3 : 2) / 2);
+            if (e->gemm_bf16) gance::winogemm_arrange_weights_split(scaled.data(), c.cin, c.cout, &pool[e->winogemm_w[i]]);
+            else gance::winogemm_arrange_weights(scaled.data(), c.cin, c.cout, &pool[e->winogemm_w[i]]);
         }
         e->upgemm_w.push_back(SIZE_MAX);
         if (c.up && upgemm_min_columns() > 0 && gance::upgemm_supported(c.cin, c.cout, (1 << c.res_log2) / 2, (1 << c.res_log2) / 2)) {
             std::vector<float> scaled(wn);
             for (size_t j = 0; j < wn; ++j) scaled[j] = src[j] * coef;
-            e->upgemm_w[i] = reserve(gance::upgemm_weight_floats(c.cin, c.cout));
-            gance::upgemm_arrange_weights(scaled.data(), c.cin, c.cout, kUpTapWeight, &pool[e->upgemm_w[i]]);
+            e->upgemm_w[i] = reserve(gance::upgemm_weight_floats(c.cin, c.cout) * (e->gemm_bf16 ? 3 : 2) / 2);
+            if (e->gemm_bf16) gance::upgemm_arrange_weights_split(scaled.data(), c.cin, c.cout, kUpTapWeight, &pool[e->upgemm_w[i]]);
+            else gance::upgemm_arrange_weights(scaled.data(), c.cin, c.cout, kUpTapWeight, &pool[e->upgemm_w[i]]);
         }
         e->upfir16x_w.push_back(SIZE_MAX);
         if (c.up && upfir16_mode() != 0 && upfir16x_mode() != 0 && gance::upfir16x_supported(c.cin, c.cout, (1 << c.res_log2) / 2, (1 << c.res_log2) / 2)) {
@@ -1291,11 +1300,12 @@ int gance_engine_create(const gance_engine_config* config, const float* host_wei
         const ConvLayerHost& c = e->convs[i];
         const int H = (1 << c.res_log2) / 2;
         if (c.up && gance::upgemm_supported(c.cin, c.cout, H, H)) {
-            e->up_packed_floats = std::max(e->up_packed_floats, gance::upgemm_packed_floats(Bmax, c.cin, H, H));
+            // (x 3/2: room for the three bf16 parts of the experiment's operand images, whatever this engine's knobs say)
+            e->up_packed_floats = std::max(e->up_packed_floats, gance::upgemm_packed_floats(Bmax, c.cin, H, H) * 3 / 2);
             e->up_prod_floats = std::max(e->up_prod_floats, gance::upgemm_prod_floats(Bmax, c.cout, H, H));
         }
         if (!c.up && i > 0 && gance::winogemm_supported(c.cin, c.cout, 2 * H, 2 * H)) {
-            e->up_packed_floats = std::max(e->up_packed_floats, gance::winogemm_packed_floats(Bmax, c.cin, 2 * H, 2 * H));
+            e->up_packed_floats = std::max(e->up_packed_floats, gance::winogemm_packed_floats(Bmax, c.cin, 2 * H, 2 * H) * 3 / 2);
             e->up_prod_floats = std::max(e->up_prod_floats, gance::winogemm_prod_floats(Bmax, c.cout, 2 * H, 2 * H));
         }
     }

@@ -27,10 +27,21 @@
 //   2. tile_gemm_kernel: M_g[co][n] = sum_ci U_g[ci][co] V_g[ci][n], U = G w G^T (host, fp64, the matrices of winograd43_conv.hip),
 //   3. winogemm_finish_kernel: A^T M A per (tile, channel), x demod, + noise + bias, leaky ReLU x sqrt 2 -> the bordered activation.
 // A quarter of the direct form's flops, every MFMA slot useful; 36 Cin N + 36 Cout N floats through HBM (150 MB at 16x16, batch 64).
+//
+// (3) EXPERIMENT, off by default (GANCE_TUNE_GEMM_BF16X6=1 at engine creation): the same GEMMs on the bf16 matrix cores with fp32
+// accuracy. Each fp32 operand is split into three bf16 numbers that hold its 24 mantissa bits exactly (x = x0 + x1 + x2); a product is
+// the sum of the six largest of the nine bf16 x bf16 products (x0 w0, x0 w1, x1 w0, x1 w1, x0 w2, x2 w0: the three left out are below
+// 2^-25 |x w|), each exact in the fp32 accumulator of v_mfma_f32_16x16x32_bf16, which does 8192 MACs in 16 cycles where the fp32 MFMA
+// does 1024 in 32: six terms cost 0.375 of the fp32 matrix time (tools/experiments/bf16_split_error.py: the error of a K = 4608 sum
+// against fp64 is 4e-7 of the largest output, fp32 MFMAs in their order 1.2e-6). The pack kernels write the three parts of the B image,
+// the host the three of the weights; operand tile = [part][8-channel group][16][8] bf16, so a lane's fragment is one ds_read_b128; block
+// tile 256 x 128, eight waves of 64 x 64, K chunks of 32 through a two-slot ring of 72 KB each. It is the first hardware data point of the
+// lever DESIGN.md section 9 prices for the convolutions; the contract line does not use it.
 
 #include <hip/hip_runtime.h>
 
 #include <cstdlib>
+#include <vector>
 
 #include "kernels.h"
 
@@ -43,6 +54,31 @@ typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
 constexpr int kGM = 128, kGN = 128, kGK = 16;  // block tile and K chunk
 constexpr int kTileFloats = kGK * 128;         // an operand tile of a chunk: [8 tiles of 16][16 k][16] = 8 KB = 8 DMA pieces
+
+// fp32 -> three bf16 (round to nearest even each time): x = p[0] + p[1] + p[2] exactly for every finite x whose parts stay normal
+__host__ __device__ inline unsigned short bf16_rne(float x) {
+    unsigned u;
+    __builtin_memcpy(&u, &x, 4);
+    return (unsigned short)((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16);
+}
+__host__ __device__ inline float bf16_value(unsigned short h) {
+    const unsigned u = (unsigned)h << 16;
+    float x;
+    __builtin_memcpy(&x, &u, 4);
+    return x;
+}
+__host__ __device__ inline void split3(float x, unsigned short (&part)[3]) {
+    part[0] = bf16_rne(x);
+    const float r1 = x - bf16_value(part[0]);
+    part[1] = bf16_rne(r1);
+    part[2] = bf16_rne(r1 - bf16_value(part[1]));
+}
+constexpr int kSK = 32;                     // bf16 form: k per chunk = one k-step of v_mfma_f32_16x16x32_bf16
+constexpr int kSplitTile = 3 * 4 * 16 * 8;  // bf16 form: a 16-row operand tile of a chunk, [part][k group of 8][16][8] = 1536 values = 3 KB
+// index (in bf16 values) of element (row r of the operand, channel k) in an image [row tile of `rows`][chunk][16-row tile][part][k / 8][16][8]
+__host__ __device__ inline size_t split_index(int r, int k, int rows, int chunks) {
+    return ((((size_t)(r / rows) * chunks + k / kSK) * (rows / 16) + (r % rows) / 16) * kSplitTile) + ((k % kSK) / 8) * 128 + (r % 16) * 8 + k % 8;
+}
 
 __host__ __device__ constexpr int up_tap_cls(int t) { return t < 4 ? 0 : (t < 6 ? 1 : (t < 8 ? 2 : 3)); }
 
@@ -64,7 +100,16 @@ __global__ __launch_bounds__(256) void upgemm_pack_kernel(const UpGemmArgs p) {
         const int y = pos / p.W, x = pos - y * p.W;
         v = p.x[(size_t)b * p.x_b_stride + ((size_t)ci * (p.H + 2) + y + 1) * (p.W + 8) + x + 4] * p.s[(size_t)b * p.s_stride + ci];
     }
-    p.packed[i] = v;
+    if (p.bf16_split) {
+        // (the same thread -> element map; consecutive threads are consecutive columns: 2-byte stores 16 bytes apart -- small images)
+        unsigned short part[3];
+        split3(v, part);
+        unsigned short* const dst = reinterpret_cast<unsigned short*>(p.packed) + split_index(n, ci, kGN, p.Cin / kSK);
+#pragma unroll
+        for (int q = 0; q < 3; ++q) dst[q * 512] = part[q];
+    } else {
+        p.packed[i] = v;
+    }
 }
 
 // ---- the GEMM: C[m][n] = sum_k A[k][m] B[k][n]; rows in groups of m_tiles_per_group tiles, group g reads B image g ----
@@ -75,7 +120,10 @@ struct TileGemmArgs {
     int n_tiles, Cin, m_tiles_per_group;
 };
 
-__global__ __launch_bounds__(256, 3) void tile_gemm_kernel(const TileGemmArgs p) {
+#ifndef GANCE_TILE_GEMM_BLOCKS
+#define GANCE_TILE_GEMM_BLOCKS 3
+#endif
+__global__ __launch_bounds__(256, GANCE_TILE_GEMM_BLOCKS) void tile_gemm_kernel(const TileGemmArgs p) {
     __shared__ float smem[2 * 2 * kTileFloats];  // ring of two slots: A tile | B tile
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -142,6 +190,95 @@ __global__ __launch_bounds__(256, 3) void tile_gemm_kernel(const TileGemmArgs p)
     }
 }
 
+// ---- the same product from split operands on the bf16 matrix cores (experiment, see the header): 256 x 128 block tiles, eight waves ----
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+constexpr int kSM = 256;                                      // rows (channels) per block
+constexpr int kSplitSlotBytes = (kSM / 16 + kGN / 16) * 3072;  // 48 KB of weights + 24 KB of columns per chunk
+
+__global__ __launch_bounds__(512, 1) void tile_gemm_bf16x6_kernel(const TileGemmArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem_split[];  // ring of two slots
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63;
+    const int n16 = lane & 15, q4 = lane >> 4;
+    const int wm = wave >> 1, wn = wave & 1;  // the wave's 64 channels of the block's 256 / 64 positions of its 128
+    const int n_tile = blockIdx.x % p.n_tiles, m_tile = blockIdx.x / p.n_tiles;
+    const int chunks = p.Cin / kSK;
+    const int group = m_tile / p.m_tiles_per_group;
+    constexpr int kABytes = (kSM / 16) * 3072, kBBytes = (kGN / 16) * 3072;
+    const __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(reinterpret_cast<const char*>(p.w) + (size_t)m_tile * chunks * kABytes), 0, chunks * kABytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t b_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(reinterpret_cast<const char*>(p.packed) + ((size_t)group * p.n_tiles + n_tile) * chunks * kBBytes), 0, chunks * kBBytes, 0x00020000);
+    // 72 pieces of 1 KB per chunk (48 of weights, 24 of columns): wave w stages pieces w, w + 8, ...
+    auto stage = [&](int chunk, char* buf) {
+#pragma unroll
+        for (int i = 0; i < 9; ++i) {
+            const int piece = wave + 8 * i;
+            if (piece < kABytes / 1024)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rsrc, (lds_ptr_t)(buf + piece * 1024), 16, piece * 1024 + lane * 16, chunk * kABytes, 0, 0);
+            else
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(b_rsrc, (lds_ptr_t)(buf + piece * 1024), 16, (piece - kABytes / 1024) * 1024 + lane * 16,
+                                                         chunk * kBBytes, 0, 0);
+        }
+    };
+    f32x4 acc[4][4];  // [position tile][channel tile]
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    stage(0, smem_split);
+    for (int k = 0; k < chunks; ++k) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        const char* const cur = smem_split + (k & 1) * kSplitSlotBytes;
+        if (k + 1 < chunks) stage(k + 1, smem_split + ((k + 1) & 1) * kSplitSlotBytes);
+        // a lane's fragment of (tile, part): 8 consecutive channels k = 8 q4 .. + 7 of row n16 = bytes [q4][n16][8] of the part: lane x 16
+        bf16x8 a[4][3], b[4][3];
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                a[t][q] = *reinterpret_cast<const bf16x8*>(cur + (4 * wm + t) * 3072 + q * 1024 + lane * 16);
+                b[t][q] = *reinterpret_cast<const bf16x8*>(cur + kABytes + (4 * wn + t) * 3072 + q * 1024 + lane * 16);
+            }
+        // six of the nine part products, smallest first: (x2 w0) (x0 w2) (x1 w1) (x1 w0) (x0 w1) (x0 w0)
+        constexpr int kTerms[6][2] = {{2, 0}, {0, 2}, {1, 1}, {1, 0}, {0, 1}, {0, 0}};
+#pragma unroll
+        for (int term = 0; term < 6; ++term)
+#pragma unroll
+            for (int pt = 0; pt < 4; ++pt)
+#pragma unroll
+                for (int ct = 0; ct < 4; ++ct)
+                    acc[pt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[pt][kTerms[term][0]], a[ct][kTerms[term][1]], acc[pt][ct], 0, 0, 0);
+    }
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) {
+        const size_t m = (size_t)m_tile * kSM + (4 * wm + ct) * 16 + n16;
+#pragma unroll
+        for (int pt = 0; pt < 4; ++pt) {
+            const int n = n_tile * kGN + (4 * wn + pt) * 16 + 4 * q4;
+            *reinterpret_cast<f32x4*>(p.prod + m * ((size_t)p.n_tiles * kGN) + n) = acc[pt][ct];
+        }
+    }
+}
+
+hipError_t launch_tile_gemm_bf16x6(const TileGemmArgs& g, int m_rows, hipStream_t stream) {
+    static PerDeviceInt ready;
+    int unused = 0;
+    const hipError_t e = ready.get(
+        [&](int, int* value) {
+            *value = 1;
+            return hipFuncSetAttribute(reinterpret_cast<const void*>(tile_gemm_bf16x6_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * kSplitSlotBytes);
+        },
+        &unused);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(tile_gemm_bf16x6_kernel, dim3((unsigned)(g.n_tiles * (m_rows / kSM))), dim3(512), 2 * kSplitSlotBytes, stream, g);
+    return hipGetLastError();
+}
+
 // ---- 3. gather: thread = one position (y', x') of the (H+1) x (W+1) grid of one (sample, channel): its four classes ----
 __global__ __launch_bounds__(256) void upgemm_gather_kernel(const UpGemmArgs p) {
     const int PH = p.H + 1, PW = p.W + 1;
@@ -171,7 +308,10 @@ __global__ __launch_bounds__(256) void winogemm_pack_kernel(const WinoGemmArgs p
     const int N = p.n_tiles * kGN;
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= (size_t)N * p.Cin) return;
-    const int n = (int)(i % N), ci = (int)(i / N);
+    // (bf16 form: eight consecutive threads = the eight channels of one 16-byte group of the image, then consecutive columns: a wave stores 128
+    // contiguous bytes per part and position instead of 64 two-byte pieces 16 bytes apart)
+    const int n = p.bf16_split ? (int)((i >> 3) % N) : (int)(i % N);
+    const int ci = p.bf16_split ? (int)((i >> 3) / N) * 8 + (int)(i & 7) : (int)(i / N);
     const int tiles_x = p.W / 4, tiles = tiles_x * (p.H / 4);
     const int b = n / tiles, tile = n - b * tiles;
     float v[6][6];
@@ -208,6 +348,21 @@ __global__ __launch_bounds__(256) void winogemm_pack_kernel(const WinoGemmArgs p
         for (int r = 0; r < 6; ++r)
 #pragma unroll
             for (int c = 0; c < 6; ++c) v[r][c] = 0.f;
+    }
+    if (p.bf16_split) {
+        const int chunks = p.Cin / kSK;
+        const size_t image = (size_t)p.n_tiles * chunks * 8 * kSplitTile;
+        unsigned short* const dst = reinterpret_cast<unsigned short*>(p.packed) + split_index(n, ci, kGN, chunks);
+#pragma unroll
+        for (int r = 0; r < 6; ++r)
+#pragma unroll
+            for (int c = 0; c < 6; ++c) {
+                unsigned short part[3];
+                split3(v[r][c], part);
+#pragma unroll
+                for (int q = 0; q < 3; ++q) dst[(size_t)(r * 6 + c) * image + q * 512] = part[q];
+            }
+        return;
     }
     // B image g: [n tile][chunk][column tile][k][16]
     const int chunks = p.Cin / kGK;
@@ -285,13 +440,31 @@ void upgemm_arrange_weights(const float* w_in, int cin, int cout, const int* up_
                     }
 }
 
+// the same rows as three bf16 parts: [row tile of 256][chunk of 32][16-row tile][part][k / 8][16][8] (1.5 x the fp32 image's bytes)
+void upgemm_arrange_weights_split(const float* w_in, int cin, int cout, const int* up_tap_weight, void* w_out) {
+    unsigned short* const out = static_cast<unsigned short*>(w_out);
+    for (int m = 0; m < 9 * cout; ++m)
+        for (int ci = 0; ci < cin; ++ci) {
+            unsigned short part[3];
+            split3(w_in[((size_t)up_tap_weight[m / cout] * cin + ci) * cout + m % cout], part);
+            for (int q = 0; q < 3; ++q) out[split_index(m, ci, kSM, cin / kSK) + q * 512] = part[q];
+        }
+}
+
 hipError_t launch_upgemm(const UpGemmArgs& args, hipStream_t stream) {
     if (!upgemm_supported(args.Cin, args.Cout, args.H, args.W) || args.n_tiles != upgemm_n_tiles(args.B, args.H, args.W)) return hipErrorInvalidValue;
     const size_t packed = (size_t)args.n_tiles * kGN * args.Cin;
     hipLaunchKernelGGL(upgemm_pack_kernel, dim3((unsigned)((packed + 255) / 256)), dim3(256), 0, stream, args);
-    const int m_tiles = 9 * args.Cout / kGM;
-    const TileGemmArgs g{args.w, args.packed, args.prod, args.n_tiles, args.Cin, m_tiles};
-    hipLaunchKernelGGL(tile_gemm_kernel, dim3((unsigned)(args.n_tiles * m_tiles)), dim3(256), 0, stream, g);
+    if (args.bf16_split) {
+        if (args.Cin % kSK != 0 || (9 * args.Cout) % kSM != 0) return hipErrorInvalidValue;
+        const TileGemmArgs g{args.w, args.packed, args.prod, args.n_tiles, args.Cin, 9 * args.Cout / kSM};
+        const hipError_t e = launch_tile_gemm_bf16x6(g, 9 * args.Cout, stream);
+        if (e != hipSuccess) return e;
+    } else {
+        const int m_tiles = 9 * args.Cout / kGM;
+        const TileGemmArgs g{args.w, args.packed, args.prod, args.n_tiles, args.Cin, m_tiles};
+        hipLaunchKernelGGL(tile_gemm_kernel, dim3((unsigned)(args.n_tiles * m_tiles)), dim3(256), 0, stream, g);
+    }
     const size_t outs = (size_t)args.B * args.Cout * (args.H + 1) * (args.W + 1);
     hipLaunchKernelGGL(upgemm_gather_kernel, dim3((unsigned)((outs + 255) / 256)), dim3(256), 0, stream, args);
     return hipGetLastError();
@@ -325,13 +498,33 @@ void winogemm_arrange_weights(const float* w_in, int cin, int cout, float* w_out
         }
 }
 
+void winogemm_arrange_weights_split(const float* w_in, int cin, int cout, void* w_out) {
+    std::vector<float> plain(winogemm_weight_floats(cin, cout));
+    winogemm_arrange_weights(w_in, cin, cout, plain.data());
+    unsigned short* const out = static_cast<unsigned short*>(w_out);
+    const int chunks = cin / kGK;
+    for (int m = 0; m < 36 * cout; ++m)
+        for (int ci = 0; ci < cin; ++ci) {
+            unsigned short part[3];
+            split3(plain[((((size_t)(m / kGM) * chunks + ci / kGK) * 8 + (m % kGM) / 16) * kGK + ci % kGK) * 16 + m % 16], part);
+            for (int q = 0; q < 3; ++q) out[split_index(m, ci, kSM, cin / kSK) + q * 512] = part[q];
+        }
+}
+
 hipError_t launch_winogemm(const WinoGemmArgs& args, hipStream_t stream) {
     if (!winogemm_supported(args.Cin, args.Cout, args.H, args.W) || args.n_tiles != winogemm_n_tiles(args.B, args.H, args.W)) return hipErrorInvalidValue;
     const size_t columns = (size_t)args.n_tiles * kGN;
     hipLaunchKernelGGL(winogemm_pack_kernel, dim3((unsigned)((columns * args.Cin + 255) / 256)), dim3(256), 0, stream, args);
-    const int per_group = args.Cout / kGM;
-    const TileGemmArgs g{args.w, args.packed, args.prod, args.n_tiles, args.Cin, per_group};
-    hipLaunchKernelGGL(tile_gemm_kernel, dim3((unsigned)(args.n_tiles * 36 * per_group)), dim3(256), 0, stream, g);
+    if (args.bf16_split) {
+        if (args.Cin % kSK != 0 || args.Cout % kSM != 0) return hipErrorInvalidValue;
+        const TileGemmArgs g{args.w, args.packed, args.prod, args.n_tiles, args.Cin, args.Cout / kSM};
+        const hipError_t e = launch_tile_gemm_bf16x6(g, 36 * args.Cout, stream);
+        if (e != hipSuccess) return e;
+    } else {
+        const int per_group = args.Cout / kGM;
+        const TileGemmArgs g{args.w, args.packed, args.prod, args.n_tiles, args.Cin, per_group};
+        hipLaunchKernelGGL(tile_gemm_kernel, dim3((unsigned)(args.n_tiles * 36 * per_group)), dim3(256), 0, stream, g);
+    }
     const size_t outs = (size_t)args.B * (args.H / 4) * (args.W / 4) * args.Cout;
     hipLaunchKernelGGL(winogemm_finish_kernel, dim3((unsigned)((outs + 255) / 256)), dim3(256), 0, stream, args);
     return hipGetLastError();

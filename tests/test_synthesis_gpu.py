@@ -204,14 +204,19 @@ def test_fused_upsampling_layer_matches_oracle_layerwise(library, resolution: in
         engine.close()
 
 
-@pytest.mark.parametrize("resolution,batch", [(16, 33), (8, 40), (32, 9)])
-def test_smallest_up_layers_in_scatter_form_match_oracle_layerwise(library, resolution: int, batch: int) -> None:
+@pytest.mark.parametrize("resolution,batch,split", [(16, 33, False), (8, 40, False), (32, 9, False), (16, 33, True), (32, 64, True)])
+def test_smallest_up_layers_in_scatter_form_match_oracle_layerwise(library, resolution: int, batch: int, split: bool, monkeypatch) -> None:
     """
     The 4x4 -> 8x8 and 8x8 -> 16x16 up layers as one dense GEMM each (gemm_forms.hip: pack, GEMM over tap slot x channel rows and
     sample x position columns, gather into the parity planes, then the FIR pass), which the engine takes from 512 GEMM columns
     (samples x input positions) up; every term on. The batches are no multiples of the 128-column tiles (padded columns), and
     (32, 9) has the 8x8 -> 16x16 layer in scatter form (576 columns) and the 4x4 -> 8x8 layer below the threshold (144).
+    The stride-1 layers at 8x8 / 16x16 of these networks run in the Winograd GEMM form from 256 columns up (the same GEMM kernel).
+    `split=True`: the experiment GANCE_TUNE_GEMM_BF16X6=1 (the same products on the bf16 matrix cores from operands split into three
+    bf16 parts, six product terms, fp32 accumulation) must meet the SAME bars.
     """
+    if split:
+        monkeypatch.setenv("GANCE_TUNE_GEMM_BF16X6", "1")  # (read when the engine is created)
     spec = sg2_spec.make_spec(resolution)
     variables = sg2_spec.make_random_variables(resolution, seed=6, perturb=True)
     dlatents = np.random.RandomState(8).randn(batch, spec.num_layers, 512).astype(np.float32)
