@@ -388,22 +388,23 @@ static int upfir16x_mode() {
 
 // GANCE_TUNE_UPGEMM (read once per process): the two smallest up layers (4x4 -> 8x8, 8x8 -> 16x16) run in scatter form (gemm_forms.hip:
 // one dense GEMM, no position grid to tile) when a call has at least this many GEMM columns (samples x input positions); 0 = never.
-// Default 512: from 8 samples at 8x8, 32 at 4x4 -- below that the GEMM has too few column tiles to fill the chip.
+// Default 128 (one column tile): from 2 samples at 8x8, 8 at 4x4. Measured (tools/gpu_gemm_threshold_sweep.sh, frames/s at 4 ... 32 frames
+// per call): every threshold from 32 to 128 within 0.3 %, 256 / 512 -0.5 ... -1.5 %, 1 (always) -2 % at one frame per call.
 static int upgemm_min_columns() {
     static const int columns = [] {
         const char* v = std::getenv("GANCE_TUNE_UPGEMM");
-        return v ? std::atoi(v) : 512;
+        return v ? std::atoi(v) : 128;
     }();
     return columns;
 }
 
 // GANCE_TUNE_WINOGEMM (read once per process): the stride-1 layers at 8x8 and 16x16 run in Winograd F(4x4,3x3) GEMM form (gemm_forms.hip)
-// when a call has at least this many GEMM columns (samples x 4x4 output tiles); 0 = never. Default 256: from 16 samples at 16x16, 64 at
-// 8x8. Like every Winograd form it is off in engines created with conv_form "direct" (or "winograd": F(2x2,3x3) only).
+// when a call has at least this many GEMM columns (samples x 4x4 output tiles); 0 = never. Default 64: from 4 samples at 16x16, 16 at
+// 8x8 (the same sweep). Like every Winograd form it is off in engines created with conv_form "direct" (or "winograd": F(2x2,3x3) only).
 static int winogemm_min_columns() {
     static const int columns = [] {
         const char* v = std::getenv("GANCE_TUNE_WINOGEMM");
-        return v ? std::atoi(v) : 256;
+        return v ? std::atoi(v) : 64;
     }();
     return columns;
 }
