@@ -676,7 +676,11 @@ int synthesize_from_dlat(gance_engine* e, const float* d_dlat, int B, uint8_t* d
                           c.cout);
             const ConvForm form = conv_form_of(li, have_y);
             x_prescaled = false;  // (set below where this launch scales its stores for the next layer)
-            const bool gemm_form = e->winogemm_w[li] != SIZE_MAX && B * (res / 4) * (res / 4) >= winogemm_min_columns();
+            // Winograd F(4x4,3x3) as 36 dense GEMMs: at 8x8 / 16x16 always (from winogemm_min_columns() columns up), at 32x32 ... 128x128 for the
+            // calls too small for the fused F(4x4,3x3) kernel (one tile per CU): one frame per call at 128x128, up to 4 at 64x64, 16 at 32x32
+            const int gemm_columns = B * (res / 4) * (res / 4);
+            const bool gemm_form = e->winogemm_w[li] != SIZE_MAX && gemm_columns >= winogemm_min_columns() && gemm_columns <= gance::kWinoGemmMaxColumns &&
+                                   !form.wino43;
             fused_rgb = form.fused_rgb && !gemm_form;
             const bool winograd = form.winograd, winograd_last = form.winograd_last;
             if (gemm_form) {
@@ -820,7 +824,8 @@ int synthesize_from_dlat(gance_engine* e, const float* d_dlat, int B, uint8_t* d
             const long long tc = (long long)t_plane(H);
             const long long unit = tc * c.cout;
             const long long cls_stride = unit * e->t_units[li];
-            const bool scatter = e->upgemm_w[li] != SIZE_MAX && B * H * W >= upgemm_min_columns();
+            // (the scatter form: at 4x4 / 8x8 inputs from upgemm_min_columns() columns up, at 32x32 / 64x64 inputs for calls this small)
+            const bool scatter = e->upgemm_w[li] != SIZE_MAX && B * H * W >= upgemm_min_columns() && B * H * W <= gance::kUpGemmMaxColumns;
             if (scatter) {
                 // ("convTG": pack + GEMM + gather, gemm_forms.hip)
                 std::snprintf(name, sizeof(name), "convTG%d_%dx%d_%d->%d", c.layer_idx, res, res, c.cin, c.cout);
@@ -1302,12 +1307,15 @@ int gance_engine_create(const gance_engine_config* config, const float* host_wei
         const int H = (1 << c.res_log2) / 2;
         if (c.up && gance::upgemm_supported(c.cin, c.cout, H, H)) {
             // (x 3/2: room for the three bf16 parts of the experiment's operand images, whatever this engine's knobs say)
-            e->up_packed_floats = std::max(e->up_packed_floats, gance::upgemm_packed_floats(Bmax, c.cin, H, H) * 3 / 2);
-            e->up_prod_floats = std::max(e->up_prod_floats, gance::upgemm_prod_floats(Bmax, c.cout, H, H));
+            const int samples = std::max(1, std::min(Bmax, gance::kUpGemmMaxColumns / (H * H)));
+            e->up_packed_floats = std::max(e->up_packed_floats, gance::upgemm_packed_floats(samples, c.cin, H, H) * 3 / 2);
+            e->up_prod_floats = std::max(e->up_prod_floats, gance::upgemm_prod_floats(samples, c.cout, H, H));
         }
         if (!c.up && i > 0 && gance::winogemm_supported(c.cin, c.cout, 2 * H, 2 * H)) {
-            e->up_packed_floats = std::max(e->up_packed_floats, gance::winogemm_packed_floats(Bmax, c.cin, 2 * H, 2 * H) * 3 / 2);
-            e->up_prod_floats = std::max(e->up_prod_floats, gance::winogemm_prod_floats(Bmax, c.cout, 2 * H, 2 * H));
+            const int tiles = (H / 2) * (H / 2);  // 4x4 output tiles per sample
+            const int samples = std::max(1, std::min(Bmax, gance::kWinoGemmMaxColumns / tiles));
+            e->up_packed_floats = std::max(e->up_packed_floats, gance::winogemm_packed_floats(samples, c.cin, 2 * H, 2 * H) * 3 / 2);
+            e->up_prod_floats = std::max(e->up_prod_floats, gance::winogemm_prod_floats(samples, c.cout, 2 * H, 2 * H));
         }
     }
     e->y_floats = (size_t)3 * config->resolution * config->resolution * Bmax;

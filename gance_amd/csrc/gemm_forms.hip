@@ -420,7 +420,11 @@ __global__ __launch_bounds__(256) void winogemm_finish_kernel(const WinoGemmArgs
 
 }  // namespace
 
-bool upgemm_supported(int cin, int cout, int H, int W) { return H == W && (H == 4 || H == 8) && cin % kGK == 0 && cout % kGM == 0; }
+// (4x4 and 8x8 inputs at every batch; 32x32 and 64x64 inputs for the calls too small for the fused up kernel, where the transposed-conv
+// tiles ran at half the GEMM's rate: the engine takes the form up to kUpGemmMaxColumns columns, which is what its buffers are sized for)
+bool upgemm_supported(int cin, int cout, int H, int W) {
+    return H == W && (H == 4 || H == 8 || H == 32 || H == 64) && cin % kSK == 0 && cout % kGM == 0;
+}
 size_t upgemm_weight_floats(int cin, int cout) { return (size_t)9 * cin * cout; }
 int upgemm_n_tiles(int B, int H, int W) { return (B * H * W + kGN - 1) / kGN; }
 size_t upgemm_packed_floats(int B, int cin, int H, int W) { return (size_t)upgemm_n_tiles(B, H, W) * kGN * cin; }
@@ -470,7 +474,11 @@ hipError_t launch_upgemm(const UpGemmArgs& args, hipStream_t stream) {
     return hipGetLastError();
 }
 
-bool winogemm_supported(int cin, int cout, int H, int W) { return H == W && (H == 8 || H == 16) && cin % kGK == 0 && cout % kGM == 0; }
+// (8x8 and 16x16 at every batch; 32x32 ... 128x128 for the calls too small for the fused F(4x4,3x3) kernel to fill the chip: the engine takes
+// the form up to kWinoGemmMaxColumns columns, which is what its buffers are sized for)
+bool winogemm_supported(int cin, int cout, int H, int W) {
+    return H == W && H >= 8 && H <= 128 && (H & (H - 1)) == 0 && cin % kSK == 0 && cout % kGM == 0;
+}
 size_t winogemm_weight_floats(int cin, int cout) { return (size_t)36 * cin * cout; }
 int winogemm_n_tiles(int B, int H, int W) { return (B * (H / 4) * (W / 4) + kGN - 1) / kGN; }
 size_t winogemm_packed_floats(int B, int cin, int H, int W) { return (size_t)winogemm_n_tiles(B, H, W) * kGN * 36 * cin; }

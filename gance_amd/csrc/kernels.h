@@ -233,6 +233,7 @@ struct UpGemmArgs {
     int n_tiles;  // upgemm_n_tiles(B, H, W)
     int bf16_split;  // experiment: w is upgemm_arrange_weights_split's image, `packed` holds three bf16 parts per value (1.5 x the bytes)
 };
+constexpr int kUpGemmMaxColumns = 4096;  // GEMM columns (samples x input positions) the engine's buffers hold: 64 frames at 8x8, 4 at 32x32, 1 at 64x64
 bool upgemm_supported(int cin, int cout, int H, int W);
 size_t upgemm_weight_floats(int cin, int cout);
 int upgemm_n_tiles(int B, int H, int W);
@@ -261,6 +262,7 @@ struct WinoGemmArgs {
     int n_tiles;  // winogemm_n_tiles(B, H, W)
     int bf16_split;  // experiment: w is winogemm_arrange_weights_split's image, `packed` holds three bf16 parts per value
 };
+constexpr int kWinoGemmMaxColumns = 1024;  // GEMM columns (samples x 4x4 tiles) the engine's buffers hold: 64 frames at 16x16, 4 at 64x64, 1 at 128x128
 bool winogemm_supported(int cin, int cout, int H, int W);
 size_t winogemm_weight_floats(int cin, int cout);
 int winogemm_n_tiles(int B, int H, int W);

@@ -204,7 +204,7 @@ def test_fused_upsampling_layer_matches_oracle_layerwise(library, resolution: in
         engine.close()
 
 
-@pytest.mark.parametrize("resolution,batch,split", [(16, 33, False), (8, 40, False), (32, 7, False), (16, 33, True), (32, 64, True)])
+@pytest.mark.parametrize("resolution,batch,split", [(16, 33, False), (8, 40, False), (32, 7, False), (64, 2, False), (128, 1, False), (16, 33, True), (32, 24, True)])
 def test_smallest_up_layers_in_scatter_form_match_oracle_layerwise(library, resolution: int, batch: int, split: bool, monkeypatch) -> None:
     """
     The 4x4 -> 8x8 and 8x8 -> 16x16 up layers as one dense GEMM each (gemm_forms.hip: pack, GEMM over tap slot x channel rows and
@@ -212,6 +212,8 @@ def test_smallest_up_layers_in_scatter_form_match_oracle_layerwise(library, reso
     (samples x input positions) up; every term on. The batches are no multiples of the 128-column tiles (padded columns), and
     (32, 7) has the 8x8 -> 16x16 layer in scatter form (448 columns) and the 4x4 -> 8x8 layer below the threshold (112).
     The stride-1 layers at 8x8 / 16x16 of these networks run in the Winograd GEMM form from 64 columns up (the same GEMM kernel).
+    (64, 2) and (128, 1): calls too small for the fused F(4x4,3x3) kernel to fill the chip take the Winograd GEMM form at 32x32 ... 128x128 too
+    (up to 1024 GEMM columns: what one frame per call -- the reference's call pattern -- runs on).
     `split=True`: the experiment GANCE_TUNE_GEMM_BF16X6=1 (the same products on the bf16 matrix cores from operands split into three
     bf16 parts, six product terms, fp32 accumulation) must meet the SAME bars.
     """
@@ -232,8 +234,11 @@ def test_smallest_up_layers_in_scatter_form_match_oracle_layerwise(library, reso
             assert rel < 2e-5, f"conv layer {n} ({conv.scope}): rel err {rel}"
         if os.environ.get("GANCE_TUNE_UPGEMM") is None:
             engine.synthesize_w(dlatents)
+            if (resolution, batch) in ((64, 2), (128, 1)):
+                wino = [step.name.split("_")[1] for step in engine.steps() if step.name.startswith("convVG")]
+                assert f"{resolution}x{resolution}" in wino and "32x32" in wino, wino
             scatter = [step.name.split("_")[1] for step in engine.steps() if step.name.startswith("convTG")]
-            assert scatter == [f"{2 * side}x{2 * side}" for side in (4, 8) if batch * side * side >= 128 and 2 * side <= resolution], scatter
+            assert scatter == [f"{2 * side}x{2 * side}" for side in (4, 8, 32, 64) if 128 <= batch * side * side <= 4096 and 2 * side <= resolution], scatter
     finally:
         engine.close()
 
@@ -341,8 +346,10 @@ def test_config_f_1024_at_the_batch_sizes_the_product_stream_issues(library) -> 
     print("\nlaunch of every conv layer by batch size (1024^2):")
     for tag in layers:
         print(f"  {tag:>14s}: " + "  ".join(f"B={b}: {forms[b].get(tag, '-'):<12s}" for b in sorted(forms)))
-    # F(4x4,3x3) needs a tile per CU: at 64^2 (16 channel tiles x 4 pixel tiles per frame) from 4 frames up
-    assert forms[3]["8_64x64"].startswith("convW") and forms[8]["8_64x64"].startswith("convV")
+    # the fused F(4x4,3x3) kernel needs a tile per CU: at 64^2 (16 channel tiles x 4 pixel tiles per frame) from 4 frames up; below that
+    # the same transform runs as 36 dense GEMMs ("convVG", up to 1024 GEMM columns = 4 frames at 64^2, one at 128^2)
+    assert forms[3]["8_64x64"].startswith("convVG") and forms[8]["8_64x64"].startswith("convV") and not forms[8]["8_64x64"].startswith("convVG")
+    assert forms[1]["10_128x128"].startswith("convVG") and forms[1]["9_128x128"].startswith("convTG") and forms[3]["9_128x128"].startswith("convT")
     assert forms[1]["16_1024x1024"].startswith("convV") and forms[63]["16_1024x1024"].startswith("convV")
     # the fused up kernel needs 3/4 of the CUs busy without cutting the image into short row segments
     assert forms[63]["9_128x128"].startswith("convTF")
