@@ -825,7 +825,7 @@ int synthesize_from_dlat(gance_engine* e, const float* d_dlat, int B, uint8_t* d
             const long long unit = tc * c.cout;
             const long long cls_stride = unit * e->t_units[li];
             // (the scatter form: at 4x4 / 8x8 inputs from upgemm_min_columns() columns up, at 32x32 / 64x64 inputs for calls this small)
-            const bool scatter = e->upgemm_w[li] != SIZE_MAX && B * H * W >= upgemm_min_columns() && B * H * W <= gance::kUpGemmMaxColumns;
+            const bool scatter = e->upgemm_w[li] != SIZE_MAX && B * H * W >= upgemm_min_columns() && B * H * W <= gance::upgemm_max_columns(c.cout);
             if (scatter) {
                 // ("convTG": pack + GEMM + gather, gemm_forms.hip)
                 std::snprintf(name, sizeof(name), "convTG%d_%dx%d_%d->%d", c.layer_idx, res, res, c.cin, c.cout);
@@ -1307,7 +1307,7 @@ int gance_engine_create(const gance_engine_config* config, const float* host_wei
         const int H = (1 << c.res_log2) / 2;
         if (c.up && gance::upgemm_supported(c.cin, c.cout, H, H)) {
             // (x 3/2: room for the three bf16 parts of the experiment's operand images, whatever this engine's knobs say)
-            const int samples = std::max(1, std::min(Bmax, gance::kUpGemmMaxColumns / (H * H)));
+            const int samples = std::max(1, std::min(Bmax, gance::upgemm_max_columns(c.cout) / (H * H)));
             e->up_packed_floats = std::max(e->up_packed_floats, gance::upgemm_packed_floats(samples, c.cin, H, H) * 3 / 2);
             e->up_prod_floats = std::max(e->up_prod_floats, gance::upgemm_prod_floats(samples, c.cout, H, H));
         }
