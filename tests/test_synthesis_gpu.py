@@ -204,7 +204,7 @@ def test_fused_upsampling_layer_matches_oracle_layerwise(library, resolution: in
         engine.close()
 
 
-@pytest.mark.parametrize("resolution,batch,split", [(16, 33, False), (8, 40, False), (32, 7, False), (64, 2, False), (128, 1, False), (16, 33, True), (32, 24, True)])
+@pytest.mark.parametrize("resolution,batch,split", [(16, 17, False), (8, 40, False), (32, 7, False), (64, 2, False), (128, 1, False), (16, 17, True), (32, 16, True)])
 def test_smallest_up_layers_in_scatter_form_match_oracle_layerwise(library, resolution: int, batch: int, split: bool, monkeypatch) -> None:
     """
     The 4x4 -> 8x8 and 8x8 -> 16x16 up layers as one dense GEMM each (gemm_forms.hip: pack, GEMM over tap slot x channel rows and
