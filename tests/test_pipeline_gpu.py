@@ -106,7 +106,7 @@ def test_blend_then_synthesis_with_network_switching(network_dir: Path) -> None:
 
 def test_resident_networks_share_one_workspace() -> None:
     """
-    Eight 1024^2 networks resident at 32 frames per call: weights per network (0.45 GB: 135 MB as trained + every kernel form's own image of them), ONE activation
+    Eight 1024^2 networks resident at 32 frames per call: weights per network (0.55 GB: 135 MB as trained + every kernel form's own image of them), ONE activation
     workspace per (device, resolution, max_batch) -- under 35 GB in all where private workspaces took 8 x 26 GB.
     Switching between them leaves every network's frames unchanged.
     """
