@@ -198,7 +198,7 @@ struct StepRecord {
 }  // namespace
 
 // Per-call scratch (activations, parity planes, split-K slabs, skip images, styles ...): about 0.8 GB per frame
-// of batch capacity at 1024^2 against 0.45 GB of weights per network (135 MB as trained, the rest the same weights as each kernel form's LDS image). It holds nothing between calls except its
+// of batch capacity at 1024^2 against 0.55 GB of weights per network (135 MB as trained, the rest the same weights as each kernel form's LDS image). It holds nothing between calls except its
 // zero borders, which depend only on the resolution, so every engine of one (device, resolution, max_batch)
 // shares ONE workspace: 20 resident networks cost 20 x weights + 1 x workspace. Calls that share it are ordered
 // by an event (a call waits for the previous user's last kernel, on whatever stream that ran).
@@ -394,6 +394,17 @@ static int upgemm_min_columns() {
     static const int columns = [] {
         const char* v = std::getenv("GANCE_TUNE_UPGEMM");
         return v ? std::atoi(v) : 128;
+    }();
+    return columns;
+}
+
+// GANCE_TUNE_UPGEMM_COLUMNS (read once per process): the scatter form's product buffer, in GEMM columns of a 512-channel layer (75 MB per 4096).
+// Default 16384 (302 MB): every up layer from 4 -> 8 to 128 -> 256 of a call of up to 4 ... 8 frames fits, i.e. up to where the fused up
+// kernel takes over (tools/gpu_upgemm_cap_sweep.sh: +2 ... 4 % frames/s at 2 ... 7 frames per call against 4096).
+static int upgemm_buffer_columns() {
+    static const int columns = [] {
+        const char* v = std::getenv("GANCE_TUNE_UPGEMM_COLUMNS");
+        return v ? std::max(4096, std::atoi(v)) : 16384;
     }();
     return columns;
 }
@@ -825,7 +836,7 @@ int synthesize_from_dlat(gance_engine* e, const float* d_dlat, int B, uint8_t* d
             const long long unit = tc * c.cout;
             const long long cls_stride = unit * e->t_units[li];
             // (the scatter form: at 4x4 / 8x8 inputs from upgemm_min_columns() columns up, at 32x32 / 64x64 inputs for calls this small)
-            const bool scatter = e->upgemm_w[li] != SIZE_MAX && B * H * W >= upgemm_min_columns() && B * H * W <= gance::upgemm_max_columns(c.cout);
+            const bool scatter = e->upgemm_w[li] != SIZE_MAX && B * H * W >= upgemm_min_columns() && B * H * W <= gance::upgemm_max_columns(c.cout, upgemm_buffer_columns());
             if (scatter) {
                 // ("convTG": pack + GEMM + gather, gemm_forms.hip)
                 std::snprintf(name, sizeof(name), "convTG%d_%dx%d_%d->%d", c.layer_idx, res, res, c.cin, c.cout);
@@ -1307,7 +1318,7 @@ int gance_engine_create(const gance_engine_config* config, const float* host_wei
         const int H = (1 << c.res_log2) / 2;
         if (c.up && gance::upgemm_supported(c.cin, c.cout, H, H)) {
             // (x 3/2: room for the three bf16 parts of the experiment's operand images, whatever this engine's knobs say)
-            const int samples = std::max(1, std::min(Bmax, gance::upgemm_max_columns(c.cout) / (H * H)));
+            const int samples = std::max(1, std::min(Bmax, gance::upgemm_max_columns(c.cout, upgemm_buffer_columns()) / (H * H)));
             e->up_packed_floats = std::max(e->up_packed_floats, gance::upgemm_packed_floats(samples, c.cin, H, H) * 3 / 2);
             e->up_prod_floats = std::max(e->up_prod_floats, gance::upgemm_prod_floats(samples, c.cout, H, H));
         }

@@ -421,9 +421,9 @@ __global__ __launch_bounds__(256) void winogemm_finish_kernel(const WinoGemmArgs
 }  // namespace
 
 // (4x4 and 8x8 inputs at every batch; 32x32 and 64x64 inputs for the calls too small for the fused up kernel, where the transposed-conv
-// tiles ran at half the GEMM's rate: the engine takes the form up to upgemm_max_columns(cout) columns, which is what its buffers are sized for)
+// tiles ran at half the GEMM's rate: the engine takes the form up to upgemm_max_columns(cout, ...) columns, which is what its buffers are sized for)
 bool upgemm_supported(int cin, int cout, int H, int W) {
-    return H == W && (H == 4 || H == 8 || H == 32 || H == 64) && cin % kSK == 0 && cout % kGM == 0;
+    return H == W && (H == 4 || H == 8 || H == 32 || H == 64 || H == 128) && cin % kSK == 0 && cout % kGM == 0;
 }
 size_t upgemm_weight_floats(int cin, int cout) { return (size_t)9 * cin * cout; }
 int upgemm_n_tiles(int B, int H, int W) { return (B * H * W + kGN - 1) / kGN; }

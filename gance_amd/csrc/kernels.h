@@ -233,9 +233,9 @@ struct UpGemmArgs {
     int n_tiles;  // upgemm_n_tiles(B, H, W)
     int bf16_split;  // experiment: w is upgemm_arrange_weights_split's image, `packed` holds three bf16 parts per value (1.5 x the bytes)
 };
-// GEMM columns (samples x input positions) of a layer with `cout` channels that the engine's product buffer holds: 9 x 512 x 4096 floats
-// (75 MB) = 64 frames at 8x8, 4 at 32x32 (512 channels), 2 at 64x64 (256 channels)
-constexpr int upgemm_max_columns(int cout) { return 4096 * 512 / cout; }
+// GEMM columns (samples x input positions) of a layer with `cout` channels that the engine's product buffer holds: 9 x 512 x `columns_512`
+// floats (engine.hip upgemm_buffer_columns(): 16384 = 302 MB = 16 frames at 32x32 (512 channels), 8 at 64x64 (256 channels), 4 at 128x128 (128))
+constexpr int upgemm_max_columns(int cout, int columns_512) { return (int)((long long)columns_512 * 512 / cout); }
 bool upgemm_supported(int cin, int cout, int H, int W);
 size_t upgemm_weight_floats(int cin, int cout);
 int upgemm_n_tiles(int B, int H, int W);

@@ -238,7 +238,7 @@ def test_smallest_up_layers_in_scatter_form_match_oracle_layerwise(library, reso
                 wino = [step.name.split("_")[1] for step in engine.steps() if step.name.startswith("convVG")]
                 assert f"{resolution}x{resolution}" in wino and "32x32" in wino, wino
             scatter = [step.name.split("_")[1] for step in engine.steps() if step.name.startswith("convTG")]
-            assert scatter == [f"{2 * side}x{2 * side}" for side in (4, 8, 32, 64) if 128 <= batch * side * side <= (8192 if side == 64 else 4096) and 2 * side <= resolution], scatter
+            assert scatter == [f"{2 * side}x{2 * side}" for side in (4, 8, 32, 64) if 128 <= batch * side * side <= (32768 if side == 64 else 16384) and 2 * side <= resolution], scatter
     finally:
         engine.close()
 
