@@ -285,7 +285,7 @@ struct gance_engine {
     std::vector<size_t> winogemm_w;  // weight image of the Winograd F(4x4,3x3) GEMM form of the stride-1 layers at 8x8, 16x16 (gemm_forms.hip; else SIZE_MAX)
     std::vector<size_t> upgemm_w;  // weight image of the scatter-form GEMM of the two smallest up layers (gemm_forms.hip; else SIZE_MAX)
     size_t up_packed_floats = 0, up_prod_floats = 0;
-    bool gemm_bf16 = false;  // experiment (GANCE_TUNE_GEMM_BF16X6=1 when the engine is created): the GEMM forms on the bf16 matrix cores from split operands
+    int gemm_bf16 = 0;  // experiment (GANCE_TUNE_GEMM_BF16X6 when the engine is created): the GEMM forms on the 16-bit matrix cores from split operands: 1 = bf16 x 3 (six terms), 2 = fp16 x 2 (three terms)
     std::vector<size_t> upfir16x_w;  // ... and for that geometry's pair form (F(2,2) along x: 15 MFMAs per pair of columns instead of 18)
     int num_cus = 256;
     std::vector<float> conv_ns;
@@ -719,7 +719,7 @@ int synthesize_from_dlat(gance_engine* e, const float* d_dlat, int B, uint8_t* d
                 g.s_stride = e->ctot;
                 g.d_stride = e->dtot;
                 g.n_tiles = gance::winogemm_n_tiles(B, res, res);
-                g.bf16_split = e->gemm_bf16 ? 1 : 0;
+                g.bf16_split = e->gemm_bf16;
                 const double n = (double)g.n_tiles * 128;
                 StepScope scope(e, stream, name, 2.0 * 9 * c.cin * c.cout * (double)B * res * res,
                                 4.0 * (36.0 * c.cin * c.cout + 2.0 * 36 * (c.cin + c.cout) * n + (double)B * (c.cin + c.cout) * res * res));
@@ -859,7 +859,7 @@ int synthesize_from_dlat(gance_engine* e, const float* d_dlat, int B, uint8_t* d
                 g.s_stride = e->ctot;
                 g.d_stride = e->dtot;
                 g.n_tiles = gance::upgemm_n_tiles(B, H, W);
-                g.bf16_split = e->gemm_bf16 ? 1 : 0;
+                g.bf16_split = (9 * c.cout) % 256 == 0 ? e->gemm_bf16 : 0;
                 const double n = (double)g.n_tiles * 128;
                 StepScope scope(e, stream, name, 2.0 * 9 * c.cin * c.cout * (double)B * H * W,
                                 4.0 * (9.0 * c.cin * c.cout + 2.0 * c.cin * n + 2.0 * 9 * c.cout * n + 4.0 * unit * B));
@@ -1083,7 +1083,7 @@ int gance_engine_create(const gance_engine_config* config, const float* host_wei
     gance_engine* e = new gance_engine();
     {  // (read per engine, not once per process: a test creates engines with and without it)
         const char* v = std::getenv("GANCE_TUNE_GEMM_BF16X6");
-        e->gemm_bf16 = v != nullptr && std::atoi(v) != 0;
+        e->gemm_bf16 = v != nullptr ? std::max(0, std::min(2, std::atoi(v))) : 0;
     }
     e->cfg = *config;
     e->num_cus = num_cus > 0 ? num_cus : 256;
@@ -1222,15 +1222,17 @@ int gance_engine_create(const gance_engine_config* config, const float* host_wei
             std::vector<float> scaled(wn);
             for (size_t j = 0; j < wn; ++j) scaled[j] = src[j] * coef;
             e->winogemm_w[i] = reserve(gance::winogemm_weight_floats(c.cin, c.cout) * (e->gemm_bf16 ? 3 : 2) / 2);
-            if (e->gemm_bf16) gance::winogemm_arrange_weights_split(scaled.data(), c.cin, c.cout, &pool[e->winogemm_w[i]]);
+            if (e->gemm_bf16) gance::winogemm_arrange_weights_split(scaled.data(), c.cin, c.cout, e->gemm_bf16, &pool[e->winogemm_w[i]]);
             else gance::winogemm_arrange_weights(scaled.data(), c.cin, c.cout, &pool[e->winogemm_w[i]]);
         }
         e->upgemm_w.push_back(SIZE_MAX);
         if (c.up && upgemm_min_columns() > 0 && gance::upgemm_supported(c.cin, c.cout, (1 << c.res_log2) / 2, (1 << c.res_log2) / 2)) {
             std::vector<float> scaled(wn);
             for (size_t j = 0; j < wn; ++j) scaled[j] = src[j] * coef;
-            e->upgemm_w[i] = reserve(gance::upgemm_weight_floats(c.cin, c.cout) * (e->gemm_bf16 ? 3 : 2) / 2);
-            if (e->gemm_bf16) gance::upgemm_arrange_weights_split(scaled.data(), c.cin, c.cout, kUpTapWeight, &pool[e->upgemm_w[i]]);
+            // (the experiment's 256-row block tiles need 9 Cout to be a multiple of 256: the 128-channel layer keeps the fp32 GEMM)
+            const int split_mode = (9 * c.cout) % 256 == 0 ? e->gemm_bf16 : 0;
+            e->upgemm_w[i] = reserve(gance::upgemm_weight_floats(c.cin, c.cout) * (split_mode ? 3 : 2) / 2);
+            if (split_mode) gance::upgemm_arrange_weights_split(scaled.data(), c.cin, c.cout, kUpTapWeight, split_mode, &pool[e->upgemm_w[i]]);
             else gance::upgemm_arrange_weights(scaled.data(), c.cin, c.cout, kUpTapWeight, &pool[e->upgemm_w[i]]);
         }
         e->upfir16x_w.push_back(SIZE_MAX);

@@ -67,17 +67,41 @@ __host__ __device__ inline float bf16_value(unsigned short h) {
     __builtin_memcpy(&x, &u, 4);
     return x;
 }
-__host__ __device__ inline void split3(float x, unsigned short (&part)[3]) {
+__host__ __device__ inline unsigned short f16_bits(float x) {
+    const _Float16 h = (_Float16)x;  // round to nearest even, subnormals kept
+    unsigned short u;
+    __builtin_memcpy(&u, &h, 2);
+    return u;
+}
+__host__ __device__ inline float f16_value(unsigned short u) {
+    _Float16 h;
+    __builtin_memcpy(&h, &u, 2);
+    return (float)h;
+}
+// split mode 1: three bf16 parts (24 mantissa bits, the fp32 exponent range); mode 2: two fp16 parts (22 bits; 4 bytes per value like
+// fp32, three product terms instead of six -- but fp16's exponent range: residuals below 6e-5 lose bits, values above 65504 overflow)
+__host__ __device__ constexpr int split_parts(int mode) { return mode == 2 ? 2 : 3; }
+// fp16 x 2 only: the weight images are stored times a power of two (exact) that lifts them into fp16's normal range -- runtime-scaled
+// weights are ~ 1 / sqrt(9 Cin) = 0.015, their Winograd transforms down to 1 / 576 of that: residuals of such values are fp16 subnormals
+// and lose bits --, and the gather / finish kernels multiply the products by its inverse.
+__host__ __device__ constexpr float split_weight_scale(int mode, bool winograd) { return mode == 2 ? (winograd ? 4096.f : 64.f) : 1.f; }
+__host__ __device__ inline void split_value(float x, int mode, unsigned short (&part)[3]) {
+    if (mode == 2) {
+        part[0] = f16_bits(x);
+        part[1] = f16_bits(x - f16_value(part[0]));
+        part[2] = 0;
+        return;
+    }
     part[0] = bf16_rne(x);
     const float r1 = x - bf16_value(part[0]);
     part[1] = bf16_rne(r1);
     part[2] = bf16_rne(r1 - bf16_value(part[1]));
 }
-constexpr int kSK = 32;                     // bf16 form: k per chunk = one k-step of v_mfma_f32_16x16x32_bf16
-constexpr int kSplitTile = 3 * 4 * 16 * 8;  // bf16 form: a 16-row operand tile of a chunk, [part][k group of 8][16][8] = 1536 values = 3 KB
-// index (in bf16 values) of element (row r of the operand, channel k) in an image [row tile of `rows`][chunk][16-row tile][part][k / 8][16][8]
-__host__ __device__ inline size_t split_index(int r, int k, int rows, int chunks) {
-    return ((((size_t)(r / rows) * chunks + k / kSK) * (rows / 16) + (r % rows) / 16) * kSplitTile) + ((k % kSK) / 8) * 128 + (r % 16) * 8 + k % 8;
+constexpr int kSK = 32;  // split forms: k per chunk = one k-step of v_mfma_f32_16x16x32_{bf16,f16}
+// index (in 16-bit values) of element (row r of the operand, channel k), part 0, in an image
+// [row tile of `rows`][chunk][16-row tile][part][k / 8][16][8]: a (tile, part) is 512 values = 1 KB = one LDS-DMA piece
+__host__ __device__ inline size_t split_index(int r, int k, int rows, int chunks, int parts) {
+    return ((((size_t)(r / rows) * chunks + k / kSK) * (rows / 16) + (r % rows) / 16) * (parts * 512)) + ((k % kSK) / 8) * 128 + (r % 16) * 8 + k % 8;
 }
 
 __host__ __device__ constexpr int up_tap_cls(int t) { return t < 4 ? 0 : (t < 6 ? 1 : (t < 8 ? 2 : 3)); }
@@ -103,10 +127,10 @@ __global__ __launch_bounds__(256) void upgemm_pack_kernel(const UpGemmArgs p) {
     if (p.bf16_split) {
         // (the same thread -> element map; consecutive threads are consecutive columns: 2-byte stores 16 bytes apart -- small images)
         unsigned short part[3];
-        split3(v, part);
-        unsigned short* const dst = reinterpret_cast<unsigned short*>(p.packed) + split_index(n, ci, kGN, p.Cin / kSK);
-#pragma unroll
-        for (int q = 0; q < 3; ++q) dst[q * 512] = part[q];
+        split_value(v, p.bf16_split, part);
+        const int parts = split_parts(p.bf16_split);
+        unsigned short* const dst = reinterpret_cast<unsigned short*>(p.packed) + split_index(n, ci, kGN, p.Cin / kSK, parts);
+        for (int q = 0; q < parts; ++q) dst[q * 512] = part[q];
     } else {
         p.packed[i] = v;
     }
@@ -190,13 +214,18 @@ __global__ __launch_bounds__(256, GANCE_TILE_GEMM_BLOCKS) void tile_gemm_kernel(
     }
 }
 
-// ---- the same product from split operands on the bf16 matrix cores (experiment, see the header): 256 x 128 block tiles, eight waves ----
+// ---- the same product from split operands on the 16-bit matrix cores (experiment, see the header): 256 x 128 block tiles, eight waves ----
+// PARTS = 3: bf16, six product terms; PARTS = 2: fp16, three terms
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-constexpr int kSM = 256;                                      // rows (channels) per block
-constexpr int kSplitSlotBytes = (kSM / 16 + kGN / 16) * 3072;  // 48 KB of weights + 24 KB of columns per chunk
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+constexpr int kSM = 256;  // rows (channels) per block
 
-__global__ __launch_bounds__(512, 1) void tile_gemm_bf16x6_kernel(const TileGemmArgs p) {
+template <int PARTS>
+__global__ __launch_bounds__(512, 1) void tile_gemm_split_kernel(const TileGemmArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem_split[];  // ring of two slots
+    constexpr int kTileBytes = PARTS * 1024;  // a 16-row tile of a chunk: [part][k group of 8][16][8]
+    constexpr int kABytes = (kSM / 16) * kTileBytes, kBBytes = (kGN / 16) * kTileBytes, kSlotBytes = kABytes + kBBytes;
+    constexpr int kPieces = kSlotBytes / 1024;  // 72 (48 of weights, 24 of columns) or 48
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lane = tid & 63;
@@ -205,15 +234,14 @@ __global__ __launch_bounds__(512, 1) void tile_gemm_bf16x6_kernel(const TileGemm
     const int n_tile = blockIdx.x % p.n_tiles, m_tile = blockIdx.x / p.n_tiles;
     const int chunks = p.Cin / kSK;
     const int group = m_tile / p.m_tiles_per_group;
-    constexpr int kABytes = (kSM / 16) * 3072, kBBytes = (kGN / 16) * 3072;
     const __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc(
         (void*)(reinterpret_cast<const char*>(p.w) + (size_t)m_tile * chunks * kABytes), 0, chunks * kABytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t b_rsrc = __builtin_amdgcn_make_buffer_rsrc(
         (void*)(reinterpret_cast<const char*>(p.packed) + ((size_t)group * p.n_tiles + n_tile) * chunks * kBBytes), 0, chunks * kBBytes, 0x00020000);
-    // 72 pieces of 1 KB per chunk (48 of weights, 24 of columns): wave w stages pieces w, w + 8, ...
+    // wave w stages pieces w, w + 8, ...
     auto stage = [&](int chunk, char* buf) {
 #pragma unroll
-        for (int i = 0; i < 9; ++i) {
+        for (int i = 0; i < kPieces / 8; ++i) {
             const int piece = wave + 8 * i;
             if (piece < kABytes / 1024)
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rsrc, (lds_ptr_t)(buf + piece * 1024), 16, piece * 1024 + lane * 16, chunk * kABytes, 0, 0);
@@ -233,26 +261,33 @@ __global__ __launch_bounds__(512, 1) void tile_gemm_bf16x6_kernel(const TileGemm
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        const char* const cur = smem_split + (k & 1) * kSplitSlotBytes;
-        if (k + 1 < chunks) stage(k + 1, smem_split + ((k + 1) & 1) * kSplitSlotBytes);
+        const char* const cur = smem_split + (k & 1) * kSlotBytes;
+        if (k + 1 < chunks) stage(k + 1, smem_split + ((k + 1) & 1) * kSlotBytes);
         // a lane's fragment of (tile, part): 8 consecutive channels k = 8 q4 .. + 7 of row n16 = bytes [q4][n16][8] of the part: lane x 16
-        bf16x8 a[4][3], b[4][3];
+        f32x4 a[4][PARTS], b[4][PARTS];  // (16 bytes = eight 16-bit values)
 #pragma unroll
         for (int t = 0; t < 4; ++t)
 #pragma unroll
-            for (int q = 0; q < 3; ++q) {
-                a[t][q] = *reinterpret_cast<const bf16x8*>(cur + (4 * wm + t) * 3072 + q * 1024 + lane * 16);
-                b[t][q] = *reinterpret_cast<const bf16x8*>(cur + kABytes + (4 * wn + t) * 3072 + q * 1024 + lane * 16);
+            for (int q = 0; q < PARTS; ++q) {
+                a[t][q] = *reinterpret_cast<const f32x4*>(cur + (4 * wm + t) * kTileBytes + q * 1024 + lane * 16);
+                b[t][q] = *reinterpret_cast<const f32x4*>(cur + kABytes + (4 * wn + t) * kTileBytes + q * 1024 + lane * 16);
             }
-        // six of the nine part products, smallest first: (x2 w0) (x0 w2) (x1 w1) (x1 w0) (x0 w1) (x0 w0)
-        constexpr int kTerms[6][2] = {{2, 0}, {0, 2}, {1, 1}, {1, 0}, {0, 1}, {0, 0}};
+        // the part products, smallest first. bf16 x 3: six of the nine (x2 w0) (x0 w2) (x1 w1) (x1 w0) (x0 w1) (x0 w0); fp16 x 2: (x1 w0) (x0 w1) (x0 w0)
+        constexpr int kNumTerms = PARTS == 3 ? 6 : 3;
+        constexpr int kTerms[6][2] = {{PARTS == 3 ? 2 : 1, 0}, {0, PARTS == 3 ? 2 : 1}, {PARTS == 3 ? 1 : 0, PARTS == 3 ? 1 : 0}, {1, 0}, {0, 1}, {0, 0}};
 #pragma unroll
-        for (int term = 0; term < 6; ++term)
+        for (int term = 0; term < kNumTerms; ++term)
 #pragma unroll
             for (int pt = 0; pt < 4; ++pt)
 #pragma unroll
-                for (int ct = 0; ct < 4; ++ct)
-                    acc[pt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[pt][kTerms[term][0]], a[ct][kTerms[term][1]], acc[pt][ct], 0, 0, 0);
+                for (int ct = 0; ct < 4; ++ct) {
+                    if constexpr (PARTS == 3)
+                        acc[pt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, b[pt][kTerms[term][0]]),
+                                                                              __builtin_bit_cast(bf16x8, a[ct][kTerms[term][1]]), acc[pt][ct], 0, 0, 0);
+                    else
+                        acc[pt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, b[pt][kTerms[term][0]]),
+                                                                             __builtin_bit_cast(f16x8, a[ct][kTerms[term][1]]), acc[pt][ct], 0, 0, 0);
+                }
     }
 #pragma unroll
     for (int ct = 0; ct < 4; ++ct) {
@@ -265,17 +300,23 @@ __global__ __launch_bounds__(512, 1) void tile_gemm_bf16x6_kernel(const TileGemm
     }
 }
 
-hipError_t launch_tile_gemm_bf16x6(const TileGemmArgs& g, int m_rows, hipStream_t stream) {
+hipError_t launch_tile_gemm_split(const TileGemmArgs& g, int m_rows, int mode, hipStream_t stream) {
     static PerDeviceInt ready;
     int unused = 0;
+    constexpr int kSlot3 = (kSM / 16 + kGN / 16) * 3 * 1024, kSlot2 = (kSM / 16 + kGN / 16) * 2 * 1024;
     const hipError_t e = ready.get(
         [&](int, int* value) {
             *value = 1;
-            return hipFuncSetAttribute(reinterpret_cast<const void*>(tile_gemm_bf16x6_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * kSplitSlotBytes);
+            const hipError_t err =
+                hipFuncSetAttribute(reinterpret_cast<const void*>(tile_gemm_split_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * kSlot3);
+            if (err != hipSuccess) return err;
+            return hipFuncSetAttribute(reinterpret_cast<const void*>(tile_gemm_split_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * kSlot2);
         },
         &unused);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(tile_gemm_bf16x6_kernel, dim3((unsigned)(g.n_tiles * (m_rows / kSM))), dim3(512), 2 * kSplitSlotBytes, stream, g);
+    const dim3 grid((unsigned)(g.n_tiles * (m_rows / kSM)));
+    if (mode == 2) hipLaunchKernelGGL(tile_gemm_split_kernel<2>, grid, dim3(512), 2 * kSlot2, stream, g);
+    else hipLaunchKernelGGL(tile_gemm_split_kernel<3>, grid, dim3(512), 2 * kSlot3, stream, g);
     return hipGetLastError();
 }
 
@@ -296,7 +337,7 @@ __global__ __launch_bounds__(256) void upgemm_gather_kernel(const UpGemmArgs p) 
         return (y >= 0 && y < p.H && x >= 0 && x < p.W) ? src[t * tap_stride + y * p.W + x] : 0.f;
     };
     // tap slots (engine.hip kUpTapWeight): EE (0,0) (0,-1) (-1,0) (-1,-1) | EO (0,0) (-1,0) | OE (0,0) (0,-1) | OO (0,0)
-    const float d = p.d[(size_t)b * p.d_stride + co];
+    const float d = p.d[(size_t)b * p.d_stride + co] * (1.0f / split_weight_scale(p.bf16_split, false));
     const float cls[4] = {(at(0, 0, 0) + at(1, 0, -1)) + (at(2, -1, 0) + at(3, -1, -1)), at(4, 0, 0) + at(5, -1, 0), at(6, 0, 0) + at(7, 0, -1), at(8, 0, 0)};
     float* const dst = p.t + (size_t)b * p.unit_stride + (size_t)co * (p.H + 3) * (p.W + 8) + (size_t)(yq + 1) * (p.W + 8) + xq + 4;
 #pragma unroll
@@ -350,17 +391,16 @@ __global__ __launch_bounds__(256) void winogemm_pack_kernel(const WinoGemmArgs p
             for (int c = 0; c < 6; ++c) v[r][c] = 0.f;
     }
     if (p.bf16_split) {
-        const int chunks = p.Cin / kSK;
-        const size_t image = (size_t)p.n_tiles * chunks * 8 * kSplitTile;
-        unsigned short* const dst = reinterpret_cast<unsigned short*>(p.packed) + split_index(n, ci, kGN, chunks);
+        const int chunks = p.Cin / kSK, parts = split_parts(p.bf16_split);
+        const size_t image = (size_t)p.n_tiles * chunks * 8 * (parts * 512);
+        unsigned short* const dst = reinterpret_cast<unsigned short*>(p.packed) + split_index(n, ci, kGN, chunks, parts);
 #pragma unroll
         for (int r = 0; r < 6; ++r)
 #pragma unroll
             for (int c = 0; c < 6; ++c) {
                 unsigned short part[3];
-                split3(v[r][c], part);
-#pragma unroll
-                for (int q = 0; q < 3; ++q) dst[(size_t)(r * 6 + c) * image + q * 512] = part[q];
+                split_value(v[r][c], p.bf16_split, part);
+                for (int q = 0; q < parts; ++q) dst[(size_t)(r * 6 + c) * image + q * 512] = part[q];
             }
         return;
     }
@@ -399,7 +439,7 @@ __global__ __launch_bounds__(256) void winogemm_finish_kernel(const WinoGemmArgs
         t[2][c] = s12 + 4.f * s34;
         t[3][c] = d12 + 8.f * d34 + m[5][c];
     }
-    const float d = p.d[(size_t)b * p.d_stride + co];
+    const float d = p.d[(size_t)b * p.d_stride + co] * (1.0f / split_weight_scale(p.bf16_split, true));
     const float bias = p.bias[co];
     const int oy0 = 4 * (tile / tiles_x), ox0 = 4 * (tile % tiles_x);
     const float* const nz = p.noise != nullptr ? p.noise + (size_t)b * p.noise_b_stride + (size_t)oy0 * p.W + ox0 : nullptr;
@@ -445,13 +485,14 @@ void upgemm_arrange_weights(const float* w_in, int cin, int cout, const int* up_
 }
 
 // the same rows as three bf16 parts: [row tile of 256][chunk of 32][16-row tile][part][k / 8][16][8] (1.5 x the fp32 image's bytes)
-void upgemm_arrange_weights_split(const float* w_in, int cin, int cout, const int* up_tap_weight, void* w_out) {
+void upgemm_arrange_weights_split(const float* w_in, int cin, int cout, const int* up_tap_weight, int mode, void* w_out) {
     unsigned short* const out = static_cast<unsigned short*>(w_out);
+    const int parts = split_parts(mode);
     for (int m = 0; m < 9 * cout; ++m)
         for (int ci = 0; ci < cin; ++ci) {
             unsigned short part[3];
-            split3(w_in[((size_t)up_tap_weight[m / cout] * cin + ci) * cout + m % cout], part);
-            for (int q = 0; q < 3; ++q) out[split_index(m, ci, kSM, cin / kSK) + q * 512] = part[q];
+            split_value(w_in[((size_t)up_tap_weight[m / cout] * cin + ci) * cout + m % cout] * split_weight_scale(mode, false), mode, part);
+            for (int q = 0; q < parts; ++q) out[split_index(m, ci, kSM, cin / kSK, parts) + q * 512] = part[q];
         }
 }
 
@@ -462,7 +503,7 @@ hipError_t launch_upgemm(const UpGemmArgs& args, hipStream_t stream) {
     if (args.bf16_split) {
         if (args.Cin % kSK != 0 || (9 * args.Cout) % kSM != 0) return hipErrorInvalidValue;
         const TileGemmArgs g{args.w, args.packed, args.prod, args.n_tiles, args.Cin, 9 * args.Cout / kSM};
-        const hipError_t e = launch_tile_gemm_bf16x6(g, 9 * args.Cout, stream);
+        const hipError_t e = launch_tile_gemm_split(g, 9 * args.Cout, args.bf16_split, stream);
         if (e != hipSuccess) return e;
     } else {
         const int m_tiles = 9 * args.Cout / kGM;
@@ -506,16 +547,17 @@ void winogemm_arrange_weights(const float* w_in, int cin, int cout, float* w_out
         }
 }
 
-void winogemm_arrange_weights_split(const float* w_in, int cin, int cout, void* w_out) {
+void winogemm_arrange_weights_split(const float* w_in, int cin, int cout, int mode, void* w_out) {
     std::vector<float> plain(winogemm_weight_floats(cin, cout));
     winogemm_arrange_weights(w_in, cin, cout, plain.data());
     unsigned short* const out = static_cast<unsigned short*>(w_out);
-    const int chunks = cin / kGK;
+    const int chunks = cin / kGK, parts = split_parts(mode);
     for (int m = 0; m < 36 * cout; ++m)
         for (int ci = 0; ci < cin; ++ci) {
             unsigned short part[3];
-            split3(plain[((((size_t)(m / kGM) * chunks + ci / kGK) * 8 + (m % kGM) / 16) * kGK + ci % kGK) * 16 + m % 16], part);
-            for (int q = 0; q < 3; ++q) out[split_index(m, ci, kSM, cin / kSK) + q * 512] = part[q];
+            split_value(plain[((((size_t)(m / kGM) * chunks + ci / kGK) * 8 + (m % kGM) / 16) * kGK + ci % kGK) * 16 + m % 16] * split_weight_scale(mode, true), mode,
+                        part);
+            for (int q = 0; q < parts; ++q) out[split_index(m, ci, kSM, cin / kSK, parts) + q * 512] = part[q];
         }
 }
 
@@ -526,7 +568,7 @@ hipError_t launch_winogemm(const WinoGemmArgs& args, hipStream_t stream) {
     if (args.bf16_split) {
         if (args.Cin % kSK != 0 || args.Cout % kSM != 0) return hipErrorInvalidValue;
         const TileGemmArgs g{args.w, args.packed, args.prod, args.n_tiles, args.Cin, args.Cout / kSM};
-        const hipError_t e = launch_tile_gemm_bf16x6(g, 36 * args.Cout, stream);
+        const hipError_t e = launch_tile_gemm_split(g, 36 * args.Cout, args.bf16_split, stream);
         if (e != hipSuccess) return e;
     } else {
         const int per_group = args.Cout / kGM;

@@ -231,7 +231,7 @@ struct UpGemmArgs {
     long long x_b_stride, cls_stride, unit_stride;
     int B, Cin, Cout, H, W, s_stride, d_stride;
     int n_tiles;  // upgemm_n_tiles(B, H, W)
-    int bf16_split;  // experiment: w is upgemm_arrange_weights_split's image, `packed` holds three bf16 parts per value (1.5 x the bytes)
+    int bf16_split;  // experiment (0 off): 1 = three bf16 parts per value, six product terms; 2 = two fp16 parts, three terms. w is upgemm_arrange_weights_split's image
 };
 // GEMM columns (samples x input positions) of a layer with `cout` channels that the engine's product buffer holds: 9 x 512 x `columns_512`
 // floats (engine.hip upgemm_buffer_columns(): 16384 = 302 MB = 16 frames at 32x32 (512 channels), 8 at 64x64 (256 channels), 4 at 128x128 (128))
@@ -242,7 +242,7 @@ int upgemm_n_tiles(int B, int H, int W);
 size_t upgemm_packed_floats(int B, int cin, int H, int W);
 size_t upgemm_prod_floats(int B, int cout, int H, int W);
 void upgemm_arrange_weights(const float* w_in /*[9][cin][cout] scaled*/, int cin, int cout, const int* up_tap_weight, float* w_out);
-void upgemm_arrange_weights_split(const float* w_in, int cin, int cout, const int* up_tap_weight, void* w_out /* 1.5 x upgemm_weight_floats floats */);
+void upgemm_arrange_weights_split(const float* w_in, int cin, int cout, const int* up_tap_weight, int mode, void* w_out /* 1.5 x upgemm_weight_floats floats */);
 hipError_t launch_upgemm(const UpGemmArgs& args, hipStream_t stream);
 
 // The stride-1 layers at 8x8 and 16x16 in Winograd F(4x4, 3x3) GEMM form (gemm_forms.hip): input transform into 36 B images, the
@@ -262,7 +262,7 @@ struct WinoGemmArgs {
     int noise_b_stride;
     int B, Cin, Cout, H, W, s_stride, d_stride;
     int n_tiles;  // winogemm_n_tiles(B, H, W)
-    int bf16_split;  // experiment: w is winogemm_arrange_weights_split's image, `packed` holds three bf16 parts per value
+    int bf16_split;  // experiment (0 off, 1 bf16 x 3, 2 fp16 x 2): w is winogemm_arrange_weights_split's image
 };
 constexpr int kWinoGemmMaxColumns = 1024;  // GEMM columns (samples x 4x4 tiles) the engine's buffers hold: 64 frames at 16x16, 4 at 64x64, 1 at 128x128
 bool winogemm_supported(int cin, int cout, int H, int W);
@@ -271,7 +271,7 @@ int winogemm_n_tiles(int B, int H, int W);
 size_t winogemm_packed_floats(int B, int cin, int H, int W);
 size_t winogemm_prod_floats(int B, int cout, int H, int W);
 void winogemm_arrange_weights(const float* w_in /*[9][cin][cout] scaled*/, int cin, int cout, float* w_out);
-void winogemm_arrange_weights_split(const float* w_in, int cin, int cout, void* w_out /* 1.5 x winogemm_weight_floats floats */);
+void winogemm_arrange_weights_split(const float* w_in, int cin, int cout, int mode, void* w_out /* 1.5 x winogemm_weight_floats floats */);
 hipError_t launch_winogemm(const WinoGemmArgs& args, hipStream_t stream);
 
 // ---- aux_kernels.hip ----

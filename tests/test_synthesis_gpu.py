@@ -214,8 +214,8 @@ def test_fused_upsampling_layer_matches_oracle_layerwise(library, resolution: in
         engine.close()
 
 
-@pytest.mark.parametrize("resolution,batch,split", [(16, 17, False), (8, 40, False), (32, 7, False), (64, 2, False), (128, 1, False), (16, 17, True), (32, 16, True)])
-def test_smallest_up_layers_in_scatter_form_match_oracle_layerwise(library, resolution: int, batch: int, split: bool, monkeypatch) -> None:
+@pytest.mark.parametrize("resolution,batch,split", [(16, 17, 0), (8, 40, 0), (32, 7, 0), (64, 2, 0), (128, 1, 0), (16, 17, 1), (32, 16, 1), (16, 17, 2), (32, 16, 2)])
+def test_smallest_up_layers_in_scatter_form_match_oracle_layerwise(library, resolution: int, batch: int, split: int, monkeypatch) -> None:
     """
     The 4x4 -> 8x8 and 8x8 -> 16x16 up layers as one dense GEMM each (gemm_forms.hip: pack, GEMM over tap slot x channel rows and
     sample x position columns, gather into the parity planes, then the FIR pass), which the engine takes from 128 GEMM columns
@@ -224,11 +224,11 @@ def test_smallest_up_layers_in_scatter_form_match_oracle_layerwise(library, reso
     The stride-1 layers at 8x8 / 16x16 of these networks run in the Winograd GEMM form from 64 columns up (the same GEMM kernel).
     (64, 2) and (128, 1): calls too small for the fused F(4x4,3x3) kernel to fill the chip take the Winograd GEMM form at 32x32 ... 128x128 too
     (up to 1024 GEMM columns: what one frame per call -- the reference's call pattern -- runs on).
-    `split=True`: the experiment GANCE_TUNE_GEMM_BF16X6=1 (the same products on the bf16 matrix cores from operands split into three
-    bf16 parts, six product terms, fp32 accumulation) must meet the SAME bars.
+    `split` 1 / 2: the experiment GANCE_TUNE_GEMM_BF16X6 (the same products on the 16-bit matrix cores from operands split into three
+    bf16 parts, six product terms -- or two fp16 parts, three terms --, fp32 accumulation) must meet the SAME bars.
     """
     if split:
-        monkeypatch.setenv("GANCE_TUNE_GEMM_BF16X6", "1")  # (read when the engine is created)
+        monkeypatch.setenv("GANCE_TUNE_GEMM_BF16X6", str(split))  # (read when the engine is created)
     spec = sg2_spec.make_spec(resolution)
     variables = sg2_spec.make_random_variables(resolution, seed=6, perturb=True)
     dlatents = np.random.RandomState(8).randn(batch, spec.num_layers, 512).astype(np.float32)
@@ -568,17 +568,32 @@ def test_winograd_kernel_fallback_forms_agree_with_the_default(library, tmp_path
 STRESS_RELATIVE_TOLERANCE = 1e-4
 
 
-@pytest.mark.parametrize("conv_form", ["direct", "winograd", "winograd43"])
-def test_stress_network_256_layerwise_and_image(library, conv_form: str) -> None:
+@pytest.mark.parametrize("conv_form,split_mode", [("direct", 0), ("winograd", 0), ("winograd43", 0), ("winograd43", 1), ("winograd43", 2)])
+def test_stress_network_256_layerwise_and_image(library, conv_form: str, split_mode: int, monkeypatch) -> None:
+    """
+    ... `split_mode` 1 / 2: the experiment GANCE_TUNE_GEMM_BF16X6 on the layers this call runs as dense GEMMs (Winograd at 32^2 / 64^2, the
+    scatter form of four up layers at two frames per call): fp32 products from three bf16 / two fp16 parts per operand. The stress
+    network is where fp16's exponent range would show (|style| ~ 10, weight scales over 10^+-1).
+    """
     resolution, batch = 256, 2
     spec = sg2_spec.make_spec(resolution)
     variables = sg2_spec.make_stress_variables(resolution, seed=0)
     z = np.random.RandomState(1).randn(batch, 512).astype(np.float32)
-    wants: list = []
-    with torch.no_grad():
-        w = ref.truncate(ref.g_mapping(torch.from_numpy(z).double(), variables, spec.num_layers), variables, 1.2)
-        want_image = ref.g_synthesis(w, variables, resolution, collect=wants)
+
+    def oracle():
+        collected: list = []
+        with torch.no_grad():
+            w_ = ref.truncate(ref.g_mapping(torch.from_numpy(z).double(), variables, spec.num_layers), variables, 1.2)
+            image_ = ref.g_synthesis(w_, variables, resolution, collect=collected)
+        return w_, image_, collected
+
+    w, want_image, wants = _oracle_once("stress_256", oracle)
     dlatents = w.numpy().astype(np.float32)
+    if split_mode:
+        monkeypatch.setenv("GANCE_TUNE_GEMM_BF16X6", str(split_mode))  # (read when the engine is created)
+        conv_form_label = f"{conv_form} + GEMM forms from split operands (mode {split_mode})"
+    else:
+        conv_form_label = conv_form
     engine = hip_lib.Engine(variables, resolution, max_batch=batch, conv_form=conv_form)
     worst = 0.0
     try:
@@ -593,7 +608,7 @@ def test_stress_network_256_layerwise_and_image(library, conv_form: str) -> None
         engine.close()
     scale = float(want_image.abs().max())
     err = float(np.abs(image - want_image.numpy()).max())
-    print(f"\nstress network 256^2, {conv_form}: worst layer rel err {worst:.2e}, image max err {err:.2e} on a range of {scale:.2f} = {err / scale:.2e}")
+    print(f"\nstress network 256^2, {conv_form_label}: worst layer rel err {worst:.2e}, image max err {err:.2e} on a range of {scale:.2f} = {err / scale:.2e}")
     assert err < STRESS_RELATIVE_TOLERANCE * scale, f"{conv_form}: image err {err} on a range of {scale}"
     want_u8 = ref.convert_images_to_uint8(want_image)
     diff = np.abs(frames.astype(np.int16) - want_u8.astype(np.int16))

@@ -30,6 +30,13 @@ def split(x: np.ndarray):
     return x0, x1, x2
 
 
+def split_f16(x: np.ndarray):
+    """Two fp16 parts (22 mantissa bits in four bytes; fp16's exponent range: residuals below 6e-5 are subnormals)."""
+    h0 = x.astype(np.float16).astype(np.float32)
+    h1 = (x - h0).astype(np.float32).astype(np.float16).astype(np.float32)
+    return h0, h1
+
+
 def dot_fp32(a: np.ndarray, b: np.ndarray, chunk: int = 4) -> np.ndarray:
     """[M][K] x [K][N] with fp32 accumulation in MFMA order: k-steps of `chunk` products added to the running sum."""
     acc = np.zeros((a.shape[0], b.shape[1]), dtype=np.float32)
@@ -59,6 +66,13 @@ def main() -> None:
             for i, j in sorted(pairs, key=lambda ij: -(ij[0] + ij[1])):
                 acc = (acc + dot_fp32(ws[i], xs[j], chunk=32)).astype(np.float32)
             print(f"  bf16 split, {count} terms       max |err| / max |y| = {np.abs(acc - want).max() / scale:.2e}   (matrix time x{count / 16:.3f} of fp32)")
+        # two fp16 parts, three terms; the second line with the weights as small as runtime-scaled Winograd weights are (x 1e-3): the
+        # residuals become subnormals -- what a power-of-two scale of the weight image repairs (gemm_forms.hip split_weight_scale)
+        for note, factor in (("", 1.0), (" weights x 1e-3", 1e-3), (" weights x 1e-3, stored x 4096", 1e-3 * 4096)):
+            (w0, w1), (x0, x1) = split_f16((w * factor).astype(np.float32)), split_f16(x)
+            acc = (dot_fp32(w1, x0, chunk=32) + dot_fp32(w0, x1, chunk=32)).astype(np.float32)
+            acc = (acc + dot_fp32(w0, x0, chunk=32)).astype(np.float32)
+            print(f"  fp16 split, 3 terms{note:32s} max |err| / max |y| = {np.abs(acc - want * factor).max() / (scale * factor):.2e}   (matrix time x0.188)")
 
 
 if __name__ == "__main__":
