@@ -36,14 +36,14 @@ def compute_spectrogram(time_series_audio: np.ndarray, num_frequency_bins: int, 
     dB spectrogram of an audio stream (apply_spectrogram.py:49-82): stereo is averaged to mono; windows
     of `num_frequency_bins - 1 * 2` samples (operator precedence in the reference: bins - 2) every
     `num_frequency_bins` samples, periodic Hann, FFT, `20 log10(|X| / max |X|)` against the GLOBAL maximum.
-    :return: float64 (window // 2, frames) when truncated (the only form the path uses).
+    :param truncate: keep the first window // 2 bins (the form the path uses) or, with False, every bin of the two-sided
+    spectrum (apply_spectrogram.py:75-78); the maximum is taken over the bins that are kept.
+    :return: float64 (window // 2, frames), or (window, frames) with `truncate=False`.
     """
     audio = np.asarray(time_series_audio)
     if audio.ndim != 1:
         audio = np.mean(audio, axis=1)  # apply_spectrogram.py:63-66
-    if not truncate:
-        raise NotImplementedError("only the truncated (one-sided) spectrogram the path uses is built")
-    return hip_lib.vec_spectrogram(audio, num_frequency_bins)
+    return hip_lib.vec_spectrogram(audio, num_frequency_bins, truncate=truncate)
 
 
 def compute_spectrogram_smooth_scale(

@@ -38,54 +38,41 @@ namespace gance_audio {
 // host: operator tables
 // ------------------------------------------------------------------------------------------
 
-// inverse of the (p+1)x(p+1) normal matrix sum_j x_j^(a+b), x_j = j - h, j = 0..w-1
-static void normal_inverse(int w, int p, long double inv[4][4]) {
-    const int n = p + 1;
-    const long double h = (w - 1) / 2.0L;
-    long double a[4][8];
-    for (int r = 0; r < n; ++r)
-        for (int c = 0; c < n; ++c) {
-            long double s = 0;
-            for (int j = 0; j < w; ++j) s += powl((long double)j - h, r + c);
-            a[r][c] = s;
-            a[r][n + c] = (r == c) ? 1.0L : 0.0L;
-        }
-    for (int col = 0; col < n; ++col) {
-        int piv = col;
-        for (int r = col + 1; r < n; ++r)
-            if (fabsl(a[r][col]) > fabsl(a[piv][col])) piv = r;
-        for (int c = 0; c < 2 * n; ++c) std::swap(a[col][c], a[piv][c]);
-        const long double d = a[col][col];
-        for (int c = 0; c < 2 * n; ++c) a[col][c] /= d;
-        for (int r = 0; r < n; ++r)
-            if (r != col) {
-                const long double f = a[r][col];
-                for (int c = 0; c < 2 * n; ++c) a[r][c] -= f * a[col][c];
-            }
-    }
-    for (int r = 0; r < n; ++r)
-        for (int c = 0; c < n; ++c) inv[r][c] = a[r][n + c];
-}
-
-// Savitzky-Golay (window w, order p, deriv 0): interior taps c[0..w-1] (symmetric) and the edge
+// Savitzky-Golay (window w, order p < w, deriv 0): interior taps c[0..w-1] (symmetric) and the edge
 // matrix E[i][j], i < w/2: value at position i of the polynomial fitted to the first w samples
 // (scipy.signal.savgol_filter mode='interp', _fit_edges_polyfit). Table layout: c[w] then E[h][w].
+// The least-squares fit of a polynomial of degree p to w equally spaced samples is the projection onto the
+// first p + 1 discrete orthogonal polynomials over those points (built here by modified Gram-Schmidt on the
+// monomials, in long double, points scaled to [-1, 1]): weight(i, j) = sum_k Q_k(x_i) Q_k(x_j), Q_k
+// orthonormal. Any polyorder the reference's callers pass (vector_sources_common.py:136-188 hands it to
+// scipy unchanged); rounds 1 - 4 inverted the 4 x 4 normal matrix, which stopped at polyorder 3.
 static std::vector<double> savgol_table(int w, int p) {
     const int h = w / 2;
-    long double inv[4][4];
-    normal_inverse(w, p, inv);
-    std::vector<double> table((size_t)w + (size_t)h * w);
     const long double hc = (w - 1) / 2.0L;
-    auto weight = [&](long double xi, int j) {
+    const long double scale = hc > 0 ? hc : 1.0L;
+    std::vector<std::vector<long double>> q((size_t)p + 1, std::vector<long double>((size_t)w));
+    for (int k = 0; k <= p; ++k) {
+        for (int j = 0; j < w; ++j) q[k][j] = powl(((long double)j - hc) / scale, k);
+        for (int pass = 0; pass < 2; ++pass)  // (re-orthogonalised once: the monomials are nearly dependent at high orders)
+            for (int l = 0; l < k; ++l) {
+                long double dot = 0;
+                for (int j = 0; j < w; ++j) dot += q[k][j] * q[l][j];
+                for (int j = 0; j < w; ++j) q[k][j] -= dot * q[l][j];
+            }
+        long double norm = 0;
+        for (int j = 0; j < w; ++j) norm += q[k][j] * q[k][j];
+        norm = sqrtl(norm);
+        for (int j = 0; j < w; ++j) q[k][j] /= norm;
+    }
+    std::vector<double> table((size_t)w + (size_t)h * w);
+    auto weight = [&](int i, int j) {
         long double s = 0;
-        const long double xj = (long double)j - hc;
-        for (int a = 0; a <= p; ++a)
-            for (int b = 0; b <= p; ++b) s += powl(xi, a) * inv[a][b] * powl(xj, b);
+        for (int k = 0; k <= p; ++k) s += q[k][i] * q[k][j];
         return s;
     };
-    for (int j = 0; j < w; ++j) table[j] = (double)weight(0.0L, j);
+    for (int j = 0; j < w; ++j) table[j] = (double)weight(h, j);  // the fitted value at the window's centre sample
     for (int i = 0; i < h; ++i)
-        for (int j = 0; j < w; ++j) table[(size_t)w + (size_t)i * w + j] = (double)weight((long double)i - hc, j);
+        for (int j = 0; j < w; ++j) table[(size_t)w + (size_t)i * w + j] = (double)weight(i, j);
     return table;
 }
 
@@ -179,14 +166,14 @@ __device__ float pairwise_sum_f32(Load a, int lo, int n) {
 __global__ __launch_bounds__(256) void dft_magnitude_kernel(const float* __restrict__ audio, int L, int m,
                                                             const double* __restrict__ window,
                                                             const double* __restrict__ twiddle,  // cos[m], sin[m]
-                                                            double* __restrict__ mag, unsigned long long* max_key) {
+                                                            double* __restrict__ mag, unsigned long long* max_key, int bins) {
+    // bins: m / 2 (the one-sided spectrum the path uses, apply_spectrogram.py:75-76) or m (truncate=False, :77-78)
     extern __shared__ double lds[];
     double* xs = lds;          // [m]
     double* tc = lds + m;      // [m]
     double* ts = lds + 2 * m;  // [m]
     __shared__ unsigned long long wave_best[4];
     const int t = blockIdx.x;
-    const int bins = m / 2;
     for (int n = threadIdx.x; n < m; n += blockDim.x) {
         xs[n] = __dmul_rn((double)audio[(size_t)t * L + n], window[n]);
         tc[n] = twiddle[n];
@@ -767,8 +754,8 @@ int gance_blend_create(const gance_blend_config* config, int32_t device, gance_b
     if (c.num_networks < 1) return audio_fail(GANCE_ERR_INVALID_ARGUMENT, "num_networks must be >= 1");
     if (c.index_savgol_window_length != 0 &&
         (c.index_savgol_window_length < 3 || c.index_savgol_window_length > 7 || c.index_savgol_window_length % 2 == 0 ||
-         c.index_savgol_polyorder < 0 || c.index_savgol_polyorder > 3 || c.index_savgol_polyorder >= c.index_savgol_window_length))
-        return audio_fail(GANCE_ERR_INVALID_ARGUMENT, "index savgol: window_length odd in [3, 7], polyorder in [0, 3] and < window_length");
+         c.index_savgol_polyorder < 0 || c.index_savgol_polyorder >= c.index_savgol_window_length))
+        return audio_fail(GANCE_ERR_INVALID_ARGUMENT, "index savgol: window_length odd in [3, 7], polyorder in [0, window_length)");
     int device_count = 0;
     const hipError_t count_err = hipGetDeviceCount(&device_count);
     if (count_err != hipSuccess || device_count < 1)
@@ -888,7 +875,7 @@ int gance_blend_run(gance_blend* b, const float* d_audio, uint64_t num_samples, 
     GANCE_AUDIO_CHECK(hipMemcpyAsync(b->keys, init_keys, sizeof(init_keys), hipMemcpyHostToDevice, stream));
 
     hipLaunchKernelGGL(gance_audio::dft_magnitude_kernel, dim3(N), dim3(256), 3 * (size_t)m * sizeof(double), stream,
-                       d_audio, L, m, b->window, b->twiddle, b->mag, b->keys);
+                       d_audio, L, m, b->window, b->twiddle, b->mag, b->keys, bins);
     hipLaunchKernelGGL(gance_audio::db_resample_kernel,
                        dim3((N + gance_audio::kResampleFrames - 1) / gance_audio::kResampleFrames), dim3(512),
                        (size_t)gance_audio::kResampleFrames * bins * sizeof(double), stream, b->mag, N, bins, L,
@@ -1001,7 +988,6 @@ int gance_vec_savgol_f64(const double* d_in, int32_t num_vectors, int32_t vector
     // scipy.signal.savgol_filter's own argument checks (mode="interp")
     if (window_length < 1 || window_length % 2 == 0) return audio_fail(GANCE_ERR_INVALID_ARGUMENT, "window_length must be a positive odd integer.");
     if (polyorder < 0 || polyorder >= window_length) return audio_fail(GANCE_ERR_INVALID_ARGUMENT, "polyorder must be less than window_length.");
-    if (polyorder > 3) return audio_fail(GANCE_ERR_INVALID_ARGUMENT, "polyorder above 3 is not supported");
     if (window_length > line)
         return audio_fail(GANCE_ERR_INVALID_ARGUMENT, "If mode is 'interp', window_length must be less than or equal to the size of x.");
     hipStream_t stream;
@@ -1048,10 +1034,12 @@ int gance_debug_fourier_resample_matrix(int32_t in_length, int32_t out_length, d
     return GANCE_OK;
 }
 
-int gance_vec_spectrogram_f64(const float* d_audio, uint64_t num_samples, int32_t num_frequency_bins, double* d_out, void* stream_) {
+int gance_vec_spectrogram2_f64(const float* d_audio, uint64_t num_samples, int32_t num_frequency_bins, int32_t truncate, double* d_out,
+                               void* stream_) {
     if (d_audio == nullptr || d_out == nullptr) return audio_fail(GANCE_ERR_INVALID_ARGUMENT, "NULL argument to gance_vec_spectrogram_f64");
-    const int L = num_frequency_bins, m = L - 2, bins = m / 2;  // apply_spectrogram.py:68 (operator precedence) and :76
+    const int L = num_frequency_bins, m = L - 2;  // apply_spectrogram.py:68 (operator precedence)
     if (L < 4 || m % 2 != 0 || num_samples < (uint64_t)m) return audio_fail(GANCE_ERR_INVALID_ARGUMENT, "num_frequency_bins must be even and >= 4, with at least one window of samples");
+    const int bins = truncate ? m / 2 : m;  // :75-78: fft[: m // 2], or every bin of the two-sided spectrum
     const int N = (int)((num_samples - m) / L + 1);  // view_as_windows(window m, step L)
     hipStream_t stream;
     if (int rc = vec_begin(d_audio, &stream, stream_)) return rc;
@@ -1071,13 +1059,17 @@ int gance_vec_spectrogram_f64(const float* d_audio, uint64_t num_samples, int32_
     GANCE_AUDIO_CHECK(hipMemcpyAsync(d_tables.ptr, tables.data(), tables.size() * sizeof(double), hipMemcpyHostToDevice, stream));
     GANCE_AUDIO_CHECK(hipMemsetAsync(d_key.ptr, 0, sizeof(unsigned long long), stream));
     hipLaunchKernelGGL(gance_audio::dft_magnitude_kernel, dim3(N), dim3(256), 3 * (size_t)m * sizeof(double), stream, d_audio, L, m,
-                       (const double*)d_tables.ptr, (const double*)d_tables.ptr + m, (double*)d_mag.ptr, (unsigned long long*)d_key.ptr);
+                       (const double*)d_tables.ptr, (const double*)d_tables.ptr + m, (double*)d_mag.ptr, (unsigned long long*)d_key.ptr, bins);
     const size_t total = (size_t)N * bins;
     hipLaunchKernelGGL(gance_audio::vec_db_transpose_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream,
                        (const double*)d_mag.ptr, N, bins, (const unsigned long long*)d_key.ptr, d_out);
     GANCE_AUDIO_CHECK(hipGetLastError());
     GANCE_AUDIO_CHECK(hipStreamSynchronize(stream));
     return GANCE_OK;
+}
+
+int gance_vec_spectrogram_f64(const float* d_audio, uint64_t num_samples, int32_t num_frequency_bins, double* d_out, void* stream_) {
+    return gance_vec_spectrogram2_f64(d_audio, num_samples, num_frequency_bins, 1, d_out, stream_);
 }
 
 int gance_vec_minmax_scale_f64(double* d_data, uint64_t count, double lo, double hi, void* stream_) {
@@ -1135,7 +1127,6 @@ int gance_vec_rms_rolling_average(const float* d_audio, uint64_t num_samples, in
     if (rolling_window < 1) return audio_fail(GANCE_ERR_INVALID_ARGUMENT, "rolling window must be >= 1");
     if (savgol_window_length < 1 || savgol_window_length % 2 == 0) return audio_fail(GANCE_ERR_INVALID_ARGUMENT, "window_length must be a positive odd integer.");
     if (savgol_polyorder < 0 || savgol_polyorder >= savgol_window_length) return audio_fail(GANCE_ERR_INVALID_ARGUMENT, "polyorder must be less than window_length.");
-    if (savgol_polyorder > 3) return audio_fail(GANCE_ERR_INVALID_ARGUMENT, "polyorder above 3 is not supported");
     if (savgol_window_length > n)
         return audio_fail(GANCE_ERR_INVALID_ARGUMENT, "If mode is 'interp', window_length must be less than or equal to the size of x.");
     hipStream_t stream;

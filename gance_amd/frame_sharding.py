@@ -24,6 +24,21 @@ CONTROL_GROUP_TIMEOUT = datetime.timedelta(seconds=int(os.environ.get("GANCE_PRO
 DRAIN_MODES = ("rank0", "per-rank")
 
 
+def collectives_forced() -> bool:
+    """
+    GANCE_FORCE_COLLECTIVES=1: with a process group of ONE rank the scatter / gather / status exchange still go through
+    `torch.distributed` instead of the world-size-1 short cuts. This is how a one-GPU box runs the RCCL code path
+    (backend "nccl", world size 1: `dist.scatter`, the asynchronous `dist.gather`, the gloo control group beside it, the
+    reader stream's `work.wait()`) -- tests/test_full_size_stream_gpu.py; nothing else sets it.
+    """
+    return os.environ.get("GANCE_FORCE_COLLECTIVES", "0") == "1" and dist.is_initialized()
+
+
+def single_process() -> bool:
+    """No collective is needed: not initialised, or one rank and the collectives are not forced."""
+    return not dist.is_initialized() or (dist.get_world_size() == 1 and not collectives_forced())
+
+
 def shard_bounds(num_frames: int, world_size: int, rank: int) -> Tuple[int, int]:
     """Half-open frame range owned by `rank` (contiguous blocks, last ranks may be short/empty)."""
     if world_size < 1 or not 0 <= rank < world_size:
@@ -41,7 +56,7 @@ def scatter_latents(all_latents: Optional[torch.Tensor], num_frames: int, device
     """
     world_size = dist.get_world_size() if dist.is_initialized() else 1
     rank = dist.get_rank() if dist.is_initialized() else 0
-    if world_size == 1:
+    if single_process():
         assert all_latents is not None
         return all_latents.to(device)
     per_rank = -(-num_frames // world_size)
@@ -72,7 +87,7 @@ def gather_frames(
     """
     world_size = dist.get_world_size() if dist.is_initialized() else 1
     rank = dist.get_rank() if dist.is_initialized() else 0
-    if world_size == 1:
+    if single_process():
         return local_frames[:num_frames], None
     per_rank = -(-num_frames // world_size)
     if local_frames.shape[0] != per_rank:
@@ -131,7 +146,7 @@ def scatter_for_stream(all_inputs: Optional[torch.Tensor], num_frames: int, fram
     """
     world_size = dist.get_world_size() if dist.is_initialized() else 1
     rank = dist.get_rank() if dist.is_initialized() else 0
-    if world_size == 1:
+    if single_process():
         assert all_inputs is not None
         return all_inputs.to(device)
     meta = [None]
@@ -170,7 +185,7 @@ def control_group():
     would put a stream synchronisation into every chunk, and a rank that died leaves an RCCL collective hanging until
     the watchdog aborts the process, whereas a gloo collective raises after the group's timeout.
     """
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if single_process():
         return None
     if dist.get_backend() == "gloo":
         return dist.group.WORLD
@@ -239,7 +254,8 @@ def ordered_device_chunks(  # pylint: disable=too-many-arguments,too-many-locals
         raise ValueError(f"drain must be one of {DRAIN_MODES}, got {drain!r}")
     world_size = dist.get_world_size() if dist.is_initialized() else 1
     rank = dist.get_rank() if dist.is_initialized() else 0
-    per_rank_drain = drain == "per-rank" and world_size > 1
+    collective = not single_process()  # (several ranks -- or one, with the collectives forced: collectives_forced)
+    per_rank_drain = drain == "per-rank" and collective
     chunks = stream_chunks(num_frames, world_size, frames_per_rank)
     per_chunk = world_size * frames_per_rank
     on_gpu = device.type == "cuda"
@@ -247,7 +263,7 @@ def ordered_device_chunks(  # pylint: disable=too-many-arguments,too-many-locals
     hands_out = rank == 0 or per_rank_drain
     gathered = None
     if hands_out:
-        gathered = local if world_size == 1 or per_rank_drain else [torch.empty((per_chunk, *frame_shape), dtype=torch.uint8, device=device) for _ in range(2)]
+        gathered = local if not collective or per_rank_drain else [torch.empty((per_chunk, *frame_shape), dtype=torch.uint8, device=device) for _ in range(2)]
     writes_into = bool(getattr(synthesize_piece, "writes_into", False))
     reader_stream = torch.cuda.Stream(device) if on_gpu and hands_out else None
     issued = [None, None]  # per buffer: event behind the last synthesis / gather issued into it
@@ -313,7 +329,7 @@ def ordered_device_chunks(  # pylint: disable=too-many-arguments,too-many-locals
             if failure is not None:
                 settled = True
                 raise failure
-            if world_size > 1 and not per_rank_drain:
+            if collective and not per_rank_drain:
                 works[slot] = dist.gather(local[slot], gather_list=list(gathered[slot].chunk(world_size, dim=0)) if rank == 0 else None, dst=0, async_op=True)
             if reader_stream is not None:
                 issued[slot] = torch.cuda.Event()

@@ -168,6 +168,7 @@ SIGNATURES = {
         ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p]
     ),
     "gance_vec_spectrogram_f64": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p]),
+    "gance_vec_spectrogram2_f64": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p]),
     "gance_vec_minmax_scale_f64": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_double, ctypes.c_double, ctypes.c_void_p]),
     "gance_vec_remap_f64": (
         ctypes.c_int,
@@ -780,8 +781,8 @@ def vec_fourier_resample(data: np.ndarray, out_length: int, device: int = 0) -> 
     return d_out.cpu().numpy()
 
 
-def vec_spectrogram(audio: np.ndarray, num_frequency_bins: int, device: int = 0) -> np.ndarray:
-    """compute_spectrogram: float32 mono samples -> float64 [(bins - 2) // 2][frames] dB magnitudes."""
+def vec_spectrogram(audio: np.ndarray, num_frequency_bins: int, device: int = 0, truncate: bool = True) -> np.ndarray:
+    """compute_spectrogram: float32 mono samples -> float64 [(bins - 2) // 2][frames] dB magnitudes ([bins - 2][frames] with `truncate=False`)."""
     lib = load_library()
     host = np.ascontiguousarray(audio, dtype=np.float32)
     window = num_frequency_bins - 2
@@ -789,10 +790,13 @@ def vec_spectrogram(audio: np.ndarray, num_frequency_bins: int, device: int = 0)
         raise ValueError("fewer samples than one window")
     frames = (host.shape[0] - window) // num_frequency_bins + 1
     d_audio = torch.from_numpy(host).to(_cuda(device))
-    d_out = torch.empty((window // 2, frames), dtype=torch.float64, device=d_audio.device)
+    d_out = torch.empty((window // 2 if truncate else window, frames), dtype=torch.float64, device=d_audio.device)
     stream = torch.cuda.current_stream(d_audio.device).cuda_stream
     _value_error_on_invalid_argument(
-        lib, lib.gance_vec_spectrogram_f64(d_audio.data_ptr(), ctypes.c_uint64(host.shape[0]), int(num_frequency_bins), d_out.data_ptr(), stream or None)
+        lib,
+        lib.gance_vec_spectrogram2_f64(
+            d_audio.data_ptr(), ctypes.c_uint64(host.shape[0]), int(num_frequency_bins), 1 if truncate else 0, d_out.data_ptr(), stream or None
+        ),
     )
     return d_out.cpu().numpy()
 

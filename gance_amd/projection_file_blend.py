@@ -528,26 +528,29 @@ def projection_file_blend_frame_chunks(  # pylint: disable=too-many-arguments,to
         if failure is not None:
             raise failure
         num_frames = inputs.num_frames
-        if world_size > 1:
+        if not frame_sharding.single_process():
             count = [num_frames]
             dist.broadcast_object_list(count, src=0)
             num_frames = count[0]
         if on_total is not None:
-            failure = None
-            if rank == 0:
+            # rank 0 first (it creates the output), then the others (they open it); a failure on ANY rank is relayed before the
+            # stream's collectives start: a rank that cannot map the shared output must not leave the others in the scatter
+            for turn_of_rank_0 in (True, False):
+                failure = None
+                if (rank == 0) == turn_of_rank_0:
+                    try:
+                        on_total(num_frames)
+                    except Exception as error:  # pylint: disable=broad-except
+                        failure = error
                 try:
-                    on_total(num_frames)
-                except Exception as error:  # pylint: disable=broad-except
-                    failure = error
-            try:
-                frame_sharding.exchange_status(failure is not None, "preparing the output")
-            except frame_sharding.StreamRankError:
-                if failure is None:
-                    raise
-            if failure is not None:
-                raise failure
-            if rank != 0:
-                on_total(num_frames)
+                    frame_sharding.exchange_status(failure is not None, "preparing the output" if turn_of_rank_0 else "opening the output")
+                except frame_sharding.StreamRankError:
+                    if failure is None:
+                        raise
+                if failure is not None:
+                    raise failure
+                if world_size == 1:
+                    break
         clock = time.perf_counter()
         dlatents = frame_sharding.scatter_for_stream(inputs.dlatents, num_frames, frames_per_call, device)
         indices = frame_sharding.scatter_for_stream(inputs.indices, num_frames, frames_per_call, device)

@@ -19,7 +19,7 @@
 extern "C" {
 #endif
 
-#define GANCE_ABI_VERSION 5
+#define GANCE_ABI_VERSION 6
 
 enum gance_status {
     GANCE_OK = 0,
@@ -244,11 +244,14 @@ int gance_blend_read_stage(gance_blend* blend, int32_t stage, void* h_out, uint6
  *
  * gance_vec_savgol_f64            smooth_across_vectors (axis 0) / smooth_each_vector (axis 1)
  *                                 (gance/vector_sources/vector_sources_common.py:136-188): scipy.signal.savgol_filter,
- *                                 mode "interp", along one axis of [num_vectors][vector_length]; polyorder <= 3
+ *                                 mode "interp", along one axis of [num_vectors][vector_length]; any polyorder < window_length
  * gance_vec_fourier_resample_f64  scale_vectors_to_length_resample (:211-230): scipy.signal.resample per vector
  * gance_vec_spectrogram_f64       compute_spectrogram (gance/apply_spectrogram.py:49-82): periodic-Hann windows of
  *                                 num_frequency_bins - 2 samples, hop num_frequency_bins, 20 log10(|X| / max |X|);
  *                                 d_out is [(bins - 2) / 2][frames] like the reference's array
+ * gance_vec_spectrogram2_f64      the same with the reference's `truncate` argument (:75-78): truncate = 0 keeps all
+ *                                 num_frequency_bins - 2 bins of the two-sided spectrum (the maximum is then taken over all
+ *                                 of them, the Nyquist bin included); d_out is [bins - 2][frames]
  * gance_vec_minmax_scale_f64      sklearn minmax_scale of the whole array, in place (apply_spectrogram.py:43)
  * gance_vec_remap_f64             remap_values_into_range (:44-61): interp1d through two points (asynchronous)
  * gance_vec_rms_rolling_average   reduce_vector_rms_rolling_average (gance/vector_sources/vector_reduction.py:102-124):
@@ -263,6 +266,8 @@ int gance_vec_savgol_f64(const double* d_in, int32_t num_vectors, int32_t vector
 int gance_vec_fourier_resample_f64(const double* d_in, int32_t num_vectors, int32_t in_length, int32_t out_length, double* d_out,
                                    void* stream);
 int gance_vec_spectrogram_f64(const float* d_audio, uint64_t num_samples, int32_t num_frequency_bins, double* d_out, void* stream);
+int gance_vec_spectrogram2_f64(const float* d_audio, uint64_t num_samples, int32_t num_frequency_bins, int32_t truncate, double* d_out,
+                               void* stream);
 int gance_vec_minmax_scale_f64(double* d_data, uint64_t count, double lo, double hi, void* stream);
 int gance_vec_remap_f64(const double* d_in, uint64_t count, double in_lo, double in_hi, double out_lo, double out_hi, double* d_out,
                         void* stream);

@@ -250,6 +250,11 @@ def standalone_cases() -> None:
     arrays["across_default"] = vsc.smooth_across_vectors(vectors, 24)
     arrays["each_9_3"] = vsc.smooth_each_vector(vectors, 24, window_length=9, polyorder=3)
     arrays["each_3_1"] = vsc.smooth_each_vector(vectors, 24, window_length=3, polyorder=1)
+    # polynomial orders above 3 (the reference hands any order to scipy.signal.savgol_filter)
+    arrays["each_9_5"] = vsc.smooth_each_vector(vectors, 24, window_length=9, polyorder=5)
+    arrays["each_11_8"] = vsc.smooth_each_vector(vectors, 24, window_length=11, polyorder=8)
+    arrays["across_7_4"] = vsc.smooth_across_vectors(vectors, 24, window_length=7, polyorder=4)
+    arrays["across_7_6"] = vsc.smooth_across_vectors(vectors, 24, window_length=7, polyorder=6)  # interpolating: the filter is the identity
     remap_in = rng.rand(37) * 7.0 - 2.0
     arrays["remap_in"] = remap_in
     arrays["remap_out"] = np.array(vsc.remap_values_into_range(remap_in, (-2.0, 5.0), (10.0, -3.0)))
@@ -263,6 +268,9 @@ def standalone_cases() -> None:
     arrays["smooth_scale_m2_2"] = apply_spectrogram.compute_spectrogram_smooth_scale(audio, L, (-2, 2))
     stereo = np.stack([audio, audio[::-1]], axis=1)
     arrays["db_stereo"] = apply_spectrogram.compute_spectrogram(stereo, L)
+    arrays["db_full"] = apply_spectrogram.compute_spectrogram(audio, L, truncate=False)  # all 510 bins of the two-sided spectrum
+    layers_order_5 = vector_reduction.reduce_vector_rms_rolling_average(audio, L, rolling_average_window=3, savgol_window_length=9, savgol_polyorder=5)
+    arrays["rms_smoothed_9_5"] = np.asarray(layers_order_5.result.data)
     layers = vector_reduction.reduce_vector_rms_rolling_average(audio, L, rolling_average_window=5, savgol_window_length=9, savgol_polyorder=2)
     arrays["rms_raw"] = np.asarray(layers.layers[1].data)
     arrays["rms_rolling_5"] = np.asarray(layers.layers[0].data)

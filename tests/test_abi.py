@@ -44,7 +44,7 @@ def test_library_exports_every_declared_symbol(library: ctypes.CDLL) -> None:
     for name in declared_functions():
         assert hasattr(library, name), f"{name} declared in gance_hip.h but not exported"
         assert name in hip_lib.SIGNATURES, f"{name} has no ctypes prototype in hip_lib.SIGNATURES"
-    assert library.gance_abi_version() == 5
+    assert library.gance_abi_version() == 6
 
 
 def test_blob_size_agrees_between_python_and_c(library: ctypes.CDLL) -> None:

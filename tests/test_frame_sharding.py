@@ -274,3 +274,56 @@ def test_a_failing_consumer_on_rank_0_ends_the_stream_on_the_other_ranks_promptl
     mp.spawn(_failing_consumer_worker, args=(2, _free_port(), results), nprocs=2, join=True)
     assert results[0][0] == "own", dict(results)
     assert results[1][0].startswith("relayed: rank 0 failed consuming the stream") and results[1][1] < 30.0, dict(results)
+
+
+def _forced_collectives_worker(rank: int, world_size: int, port: int, results) -> None:
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["GANCE_FORCE_COLLECTIVES"] = "1"
+    dist.init_process_group("gloo", rank=rank, world_size=world_size)
+    try:
+        assert frame_sharding.collectives_forced() and not frame_sharding.single_process()
+        assert frame_sharding.control_group() is not None
+        device = torch.device("cpu")
+        num_frames, per_rank = 11, 4
+        mine = frame_sharding.scatter_for_stream(torch.arange(num_frames, dtype=torch.float32).reshape(num_frames, 1), num_frames, per_rank, device)
+        assert mine[:, 0].tolist() == [float(f) for f in range(num_frames)]
+        calls = {"gather": 0}
+        real_gather = dist.gather
+
+        def counting_gather(*args, **kwargs):
+            calls["gather"] += 1
+            return real_gather(*args, **kwargs)
+
+        dist.gather = counting_gather
+        try:
+            class Producer:  # pylint: disable=too-few-public-methods
+                writes_into = True
+
+                def __call__(self, offset: int, count: int, out: torch.Tensor) -> None:
+                    out.copy_(mine[offset : offset + count, 0].to(torch.uint8).reshape(count, 1, 1, 1).expand(count, 2, 2, 3))
+
+            got = []
+            for first, frames in frame_sharding.ordered_frame_stream(Producer(), num_frames, per_rank, (2, 2, 3), device):
+                assert first == len(got)
+                got.extend(int(frame[0, 0, 0]) for frame in frames.copy())
+        finally:
+            dist.gather = real_gather
+        assert got == list(range(num_frames))
+        latents = frame_sharding.scatter_latents(torch.arange(6, dtype=torch.float32).reshape(6, 1), 6, device)
+        gathered, _ = frame_sharding.gather_frames(torch.zeros((6, 2, 2, 3), dtype=torch.uint8), 6)
+        results[rank] = (calls["gather"], latents[:, 0].tolist(), tuple(gathered.shape))
+    finally:
+        dist.destroy_process_group()
+        os.environ.pop("GANCE_FORCE_COLLECTIVES", None)
+
+
+def test_one_rank_with_the_collectives_forced_runs_them() -> None:
+    """
+    GANCE_FORCE_COLLECTIVES=1 with a process group of one rank: scatter, one gather per chunk and the status exchange go
+    through torch.distributed (how the GPU suite runs the RCCL path on a one-GPU box); same frames as the short cut.
+    """
+    manager = mp.Manager()
+    results = manager.dict()
+    mp.spawn(_forced_collectives_worker, args=(1, _free_port(), results), nprocs=1, join=True)
+    assert results[0] == (3, [0.0, 1.0, 2.0, 3.0, 4.0, 5.0], (6, 2, 2, 3))

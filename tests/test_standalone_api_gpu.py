@@ -64,6 +64,11 @@ def test_resample_and_smoothing_match_the_reference(standalone, helpers) -> None
     np.testing.assert_allclose(vector_sources_common.smooth_across_vectors(vectors, 24), standalone["across_default"], **TOL)
     np.testing.assert_allclose(vector_sources_common.smooth_each_vector(vectors, 24, window_length=9, polyorder=3), standalone["each_9_3"], **TOL)
     np.testing.assert_allclose(vector_sources_common.smooth_each_vector(vectors, 24, window_length=3, polyorder=1), standalone["each_3_1"], **TOL)
+    # polynomial orders above 3: scipy takes any order below the window length, and so do the reference's functions
+    np.testing.assert_allclose(vector_sources_common.smooth_each_vector(vectors, 24, window_length=9, polyorder=5), standalone["each_9_5"], **TOL)
+    np.testing.assert_allclose(vector_sources_common.smooth_each_vector(vectors, 24, window_length=11, polyorder=8), standalone["each_11_8"], **TOL)
+    np.testing.assert_allclose(vector_sources_common.smooth_across_vectors(vectors, 24, window_length=7, polyorder=4), standalone["across_7_4"], **TOL)
+    np.testing.assert_allclose(vector_sources_common.smooth_across_vectors(vectors, 24, window_length=7, polyorder=6), standalone["across_7_6"], **TOL)
     data = helpers["data"]
     np.testing.assert_allclose(vector_sources_common.smooth_across_vectors(data, 8, 7, 3), helpers["smooth_across_7_3"], **TOL)
     np.testing.assert_allclose(vector_sources_common.smooth_each_vector(data, 64, 5, 3), helpers["smooth_each_5_3"], **TOL)
@@ -100,6 +105,9 @@ def test_spectrogram_stages_match_the_reference(standalone) -> None:
     np.testing.assert_allclose(db, standalone["db"], rtol=0, atol=1e-8)  # dB of magnitudes down to 1e-9 of the maximum
     stereo = np.stack([audio, audio[::-1]], axis=1)
     np.testing.assert_allclose(apply_spectrogram.compute_spectrogram(stereo, 512), standalone["db_stereo"], rtol=0, atol=1e-8)
+    full = apply_spectrogram.compute_spectrogram(audio, 512, truncate=False)  # apply_spectrogram.py:75-78: every bin, maximum over all of them
+    assert full.shape == (510, num_frames) and full.dtype == np.float64
+    np.testing.assert_allclose(full, standalone["db_full"], rtol=0, atol=1e-8)
     reference_db = standalone["db"]
     np.testing.assert_allclose(apply_spectrogram.reshape_spectrogram_to_vectors(reference_db, 512, None), standalone["vectors_no_range"], **TOL)
     np.testing.assert_allclose(apply_spectrogram.reshape_spectrogram_to_vectors(reference_db, 512, (0, 3)), standalone["vectors_range_0_3"], **TOL)
@@ -122,6 +130,8 @@ def test_rms_reduction_and_quantisation_match_the_reference(standalone, helpers)
     assert layers.layers[1].data.dtype == np.float32 and np.array_equal(layers.layers[1].data, standalone["rms_raw"])  # bit-exact
     np.testing.assert_allclose(layers.layers[0].data, standalone["rms_rolling_5"], rtol=1e-15, atol=0)
     np.testing.assert_allclose(layers.result.data, standalone["rms_smoothed_9_2"], rtol=1e-13, atol=0)
+    order_5 = vector_reduction.reduce_vector_rms_rolling_average(audio, 512, rolling_average_window=3, savgol_window_length=9, savgol_polyorder=5)
+    np.testing.assert_allclose(order_5.result.data, standalone["rms_smoothed_9_5"], rtol=1e-12, atol=0)
     quantized = vector_reduction.quantize_results_layers(layers, [0, 1, 2, 3])
     assert quantized.result.label == str(standalone["rms_quantized_label"][0])
     assert np.array_equal(quantized.result.data, standalone["rms_quantized_4"])
