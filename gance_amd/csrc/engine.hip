@@ -719,7 +719,7 @@ int synthesize_from_dlat(gance_engine* e, const float* d_dlat, int B, uint8_t* d
                 g.s_stride = e->ctot;
                 g.d_stride = e->dtot;
                 g.n_tiles = gance::winogemm_n_tiles(B, res, res);
-                g.bf16_split = e->gemm_bf16;
+                g.bf16_split = c.cout % 256 == 0 ? e->gemm_bf16 : 0;  // (the split GEMM's block tiles are 256 rows: as the weights were arranged)
                 const double n = (double)g.n_tiles * 128;
                 StepScope scope(e, stream, name, 2.0 * 9 * c.cin * c.cout * (double)B * res * res,
                                 4.0 * (36.0 * c.cin * c.cout + 2.0 * 36 * (c.cin + c.cout) * n + (double)B * (c.cin + c.cout) * res * res));
@@ -1221,8 +1221,10 @@ int gance_engine_create(const gance_engine_config* config, const float* host_wei
             gance::winogemm_supported(c.cin, c.cout, 1 << c.res_log2, 1 << c.res_log2)) {
             std::vector<float> scaled(wn);
             for (size_t j = 0; j < wn; ++j) scaled[j] = src[j] * coef;
-            e->winogemm_w[i] = reserve(gance::winogemm_weight_floats(c.cin, c.cout) * (e->gemm_bf16 ? 3 : 2) / 2);
-            if (e->gemm_bf16) gance::winogemm_arrange_weights_split(scaled.data(), c.cin, c.cout, e->gemm_bf16, &pool[e->winogemm_w[i]]);
+            // (the experiment's 256-row block tiles need Cout to be a multiple of 256: a 128-channel layer of a reduced network keeps the fp32 GEMM)
+            const int split_mode = c.cout % 256 == 0 ? e->gemm_bf16 : 0;
+            e->winogemm_w[i] = reserve(gance::winogemm_weight_floats(c.cin, c.cout) * (split_mode ? 3 : 2) / 2);
+            if (split_mode) gance::winogemm_arrange_weights_split(scaled.data(), c.cin, c.cout, split_mode, &pool[e->winogemm_w[i]]);
             else gance::winogemm_arrange_weights(scaled.data(), c.cin, c.cout, &pool[e->winogemm_w[i]]);
         }
         e->upgemm_w.push_back(SIZE_MAX);

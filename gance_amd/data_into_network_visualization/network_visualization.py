@@ -19,7 +19,7 @@ import numpy as np
 from gance_amd.data_into_network_visualization.visualization_common import VisualizationInput
 from gance_amd.gance_types import ImageSourceType, RGBInt8ImageType
 from gance_amd.logger_common import LOGGER
-from gance_amd.network_interface.network_functions import DEFAULT_MAX_BATCH, MultiNetwork
+from gance_amd.network_interface.network_functions import MultiNetwork
 from gance_amd.vector_sources.vector_sources_common import sub_vectors
 
 
@@ -82,7 +82,7 @@ def vector_synthesis(  # pylint: disable=too-many-arguments,unused-argument
     indices = indices[: len(samples)]
 
     def frames() -> Iterator[RGBInt8ImageType]:
-        yield from _batched_frames(samples, indices, networks, DEFAULT_MAX_BATCH)
+        yield from _batched_frames(samples, indices, networks, networks.max_batch)  # full engine calls: the capacity the networks were loaded with
         if unload_networks_when_complete:
             networks.unload()
 

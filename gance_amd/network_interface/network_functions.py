@@ -36,7 +36,9 @@ from gance_amd.vector_sources.vector_types import SingleMatrix, SingleVector, is
 
 NETWORK_SUFFIX = ".pkl"  # network_functions.py:38
 TRUNCATION_PSI = 1.2  # network_functions.py:124,155
-DEFAULT_MAX_BATCH = 16  # frames per engine call of the batched entry points (about 0.8 GB of workspace per frame at 1024^2)
+# frames per engine call of the batched entry points: the batch the kernels are tuned for (64: 1350 frames/s class at 1024^2; 16: -12 %),
+# about 0.8 GB of activation workspace per frame of capacity at 1024^2 (51 of the 288 GB), shared by every resident network
+DEFAULT_MAX_BATCH = 64
 DEFAULT_DEVICE = 0
 
 
@@ -239,6 +241,11 @@ class MultiNetwork:
             network.stop()
         self._loaded = None
         self._expected_vector_length = None
+
+    @property
+    def max_batch(self: "MultiNetwork") -> int:
+        """Frames per engine call the resident networks were created for (not in the reference)."""
+        return self._max_batch
 
     def _network_at(self: "MultiNetwork", index: int) -> LoadedNetwork:
         return self._loaded[self._network_paths[index]]

@@ -30,7 +30,7 @@ from gance_amd import divisor, frame_sharding, hip_lib, torch_ops  # noqa: F401 
 from gance_amd.data_into_network_visualization import visualization_inputs
 from gance_amd.data_into_network_visualization.visualization_common import DataLabel, ResultLayers
 from gance_amd.logger_common import LOGGER
-from gance_amd.network_interface.network_functions import DEFAULT_MAX_BATCH, TRUNCATION_PSI, MultiNetwork
+from gance_amd.network_interface.network_functions import TRUNCATION_PSI, MultiNetwork
 
 # frames per engine call and rank of the frame stream: the batch the kernels are tuned for (one block per CU on every
 # layer from 64^2 up; 32: -2 %, 16: -8 %); the activation workspace it needs is 51 GB of the 288 GB at 1024^2
@@ -61,7 +61,7 @@ def synthesize_device_frames(  # pylint: disable=too-many-locals
     network_indices: torch.Tensor,
     networks: MultiNetwork,
     output_side_length: Optional[int] = None,
-    batch: int = DEFAULT_MAX_BATCH,
+    batch: Optional[int] = None,
 ) -> Iterator[torch.Tensor]:
     """
     dlatents [n, W18, L] float32 and network_indices [n] int32 on the GPU -> uint8 frame batches
@@ -73,6 +73,7 @@ def synthesize_device_frames(  # pylint: disable=too-many-locals
     """
     indices = network_indices.cpu().numpy()
     out_side = _common_output_side(networks, indices, output_side_length)
+    batch = batch or networks.max_batch  # (default: full engine calls, the capacity the networks were loaded with)
     for start in range(0, dlatents.shape[0], batch):
         stop = min(dlatents.shape[0], start + batch)
         chunk = indices[start:stop]
@@ -99,7 +100,7 @@ def synthesize_device_frames_network_major(  # pylint: disable=too-many-locals
     network_indices: torch.Tensor,
     networks: MultiNetwork,
     output_side_length: Optional[int] = None,
-    batch: int = DEFAULT_MAX_BATCH,
+    batch: Optional[int] = None,
     out: Optional[torch.Tensor] = None,
 ) -> torch.Tensor:
     """
@@ -114,6 +115,7 @@ def synthesize_device_frames_network_major(  # pylint: disable=too-many-locals
     indices = network_indices if isinstance(network_indices, np.ndarray) else network_indices.cpu().numpy()
     num_frames = int(dlatents.shape[0])
     out_side = _common_output_side(networks, indices, output_side_length)
+    batch = batch or networks.max_batch  # (default: full engine calls, the capacity the networks were loaded with)
     if out is None:
         out = torch.empty((num_frames, out_side, out_side, 3), dtype=torch.uint8, device=device)
     elif tuple(out.shape) != (num_frames, out_side, out_side, 3) or out.dtype != torch.uint8 or not out.is_contiguous():
