@@ -287,6 +287,8 @@ struct gance_engine {
     size_t up_packed_floats = 0, up_prod_floats = 0;
     int gemm_bf16 = 0;  // experiment (GANCE_TUNE_GEMM_BF16X6 when the engine is created): the GEMM forms on the 16-bit matrix cores from split operands: 1 = bf16 x 3 (six terms), 2 = fp16 x 2 (three terms)
     std::vector<size_t> upfir16x_w;  // ... and for that geometry's pair form (F(2,2) along x: 15 MFMAs per pair of columns instead of 18)
+    std::vector<size_t> upfirs_w;    // split-operand form of the fused up kernel (upfir_split.hip: three bf16 parts per value, six terms, fp32 accumulation)
+    int upfir_split = 1;  // GANCE_TUNE_UPFIR_SPLIT when the engine is created: 0 never, 1 (default) where a launch fills the chip without row segments, 2 wherever supported
     int num_cus = 256;
     std::vector<float> conv_ns;
     std::vector<int> conv_s_off, conv_d_off;
@@ -658,6 +660,17 @@ int synthesize_from_dlat(gance_engine* e, const float* d_dlat, int B, uint8_t* d
         if (!c.up || upfir_mode == 0 || (e->upfir_w[idx] == SIZE_MAX && e->upfir16_w[idx] == SIZE_MAX)) return false;
         gance::UpFirArgs u{};
         u.Cin = c.cin;
+        // the split-operand form (upfir_split.hip) sweeps the whole image height per block: where its launch fills the chip
+        if (e->upfirs_w[idx] != SIZE_MAX && upfir_mode != 0) {
+            gance::upfirs_plan(B, c.cout, H, H, e->num_cus, &u);
+            if (e->upfir_split == 2 || u.total_blocks >= e->num_cus * 3 / 4) {
+                u.pair_form = 2;  // (marks the plan: the caller launches launch_upfir_split)
+                if (plan != nullptr) *plan = u;
+                return true;
+            }
+            u = gance::UpFirArgs{};
+            u.Cin = c.cin;
+        }
         if (e->upfir16_w[idx] != SIZE_MAX)
             gance::upfir16_plan(B, c.cout, H, H, e->num_cus, &u);
         else
@@ -792,11 +805,12 @@ int synthesize_from_dlat(gance_engine* e, const float* d_dlat, int B, uint8_t* d
             {
                 gance::UpFirArgs u{};
                 if (up_runs_fused(li, &u)) {
-                    const bool geometry16 = e->upfir16_w[li] != SIZE_MAX;
+                    const bool split_form = u.pair_form == 2;
+                    const bool geometry16 = !split_form && e->upfir16_w[li] != SIZE_MAX;
                     const bool pair_form = geometry16 && e->upfir16x_w[li] != SIZE_MAX && input_prescaled;
                     u.pair_form = pair_form ? 1 : 0;
                     u.x = x_in;
-                    u.w = e->pool + (pair_form ? e->upfir16x_w[li] : (geometry16 ? e->upfir16_w[li] : e->upfir_w[li]));
+                    u.w = e->pool + (split_form ? e->upfirs_w[li] : (pair_form ? e->upfir16x_w[li] : (geometry16 ? e->upfir16_w[li] : e->upfir_w[li])));
                     u.s = e->ws->styles + e->conv_s_off[li];
                     u.d = e->ws->demod + e->conv_d_off[li];
                     u.noise = noise;
@@ -816,13 +830,15 @@ int synthesize_from_dlat(gance_engine* e, const float* d_dlat, int B, uint8_t* d
                     u.input_prescaled = input_prescaled ? 1 : 0;
                     // ("convTFp": upfir_fused_pre_kernel, the input arrives multiplied by this layer's style)
                     // (a trailing "/16": the 16-channel, two-blocks-per-CU geometry, upfir16_fused*_kernel; "/16x": its pair form)
+                    // ("/s3": the split-operand form, upfirs_fused*_kernel: bf16 x 3 parts, six product terms, fp32 accumulation)
                     std::snprintf(name, sizeof(name), input_prescaled ? "convTFp%d_%dx%d_%d->%d%s" : "convTF%d_%dx%d_%d->%d%s", c.layer_idx, res, res, c.cin,
-                                  c.cout, pair_form ? "/16x" : (geometry16 ? "/16" : ""));
+                                  c.cout, split_form ? "/s3" : (pair_form ? "/16x" : (geometry16 ? "/16" : "")));
                     {
                         const double flops = 2.0 * 9 * (double)c.cin * c.cout * H * W * B;
                         const double bytes = 4.0 * ((double)B * c.cin * H * W + (double)B * c.cout * res * res + 9.0 * c.cin * c.cout);
                         StepScope scope(e, stream, name, flops, bytes);
-                        GANCE_HIP_CHECK(geometry16 ? gance::launch_upfir16_fused(u, stream) : gance::launch_upfir_fused(u, stream));
+                        GANCE_HIP_CHECK(split_form ? gance::launch_upfir_split(u, stream)
+                                                   : (geometry16 ? gance::launch_upfir16_fused(u, stream) : gance::launch_upfir_fused(u, stream)));
                     }
                     x_in = x_out;
                     x_b_stride = out_b;
@@ -1084,6 +1100,8 @@ int gance_engine_create(const gance_engine_config* config, const float* host_wei
     {  // (read per engine, not once per process: a test creates engines with and without it)
         const char* v = std::getenv("GANCE_TUNE_GEMM_BF16X6");
         e->gemm_bf16 = v != nullptr ? std::max(0, std::min(2, std::atoi(v))) : 0;
+        const char* const split = std::getenv("GANCE_TUNE_UPFIR_SPLIT");
+        e->upfir_split = split != nullptr ? std::max(0, std::min(2, std::atoi(split))) : 1;
     }
     e->cfg = *config;
     e->num_cus = num_cus > 0 ? num_cus : 256;
@@ -1236,6 +1254,13 @@ int gance_engine_create(const gance_engine_config* config, const float* host_wei
             e->upgemm_w[i] = reserve(gance::upgemm_weight_floats(c.cin, c.cout) * (split_mode ? 3 : 2) / 2);
             if (split_mode) gance::upgemm_arrange_weights_split(scaled.data(), c.cin, c.cout, kUpTapWeight, split_mode, &pool[e->upgemm_w[i]]);
             else gance::upgemm_arrange_weights(scaled.data(), c.cin, c.cout, kUpTapWeight, &pool[e->upgemm_w[i]]);
+        }
+        e->upfirs_w.push_back(SIZE_MAX);
+        if (c.up && e->upfir_split != 0 && upfir16_mode() != 0 && gance::upfirs_supported(c.cin, c.cout, (1 << c.res_log2) / 2, (1 << c.res_log2) / 2)) {
+            std::vector<float> scaled(wn);
+            for (size_t j = 0; j < wn; ++j) scaled[j] = src[j] * coef;
+            e->upfirs_w[i] = reserve(gance::upfirs_weight_floats(c.cin, c.cout));
+            gance::upfirs_arrange_weights(scaled.data(), c.cin, c.cout, kUpTapWeight, &pool[e->upfirs_w[i]]);
         }
         e->upfir16x_w.push_back(SIZE_MAX);
         if (c.up && upfir16_mode() != 0 && upfir16x_mode() != 0 && gance::upfir16x_supported(c.cin, c.cout, (1 << c.res_log2) / 2, (1 << c.res_log2) / 2)) {

@@ -217,6 +217,15 @@ bool upfir16x_supported(int cin, int cout, int H, int W);
 size_t upfir16x_weight_floats(int cin, int cout);
 void upfir16x_arrange_weights(const float* w_in /*[9][cin][cout] scaled*/, int cin, int cout, const int* up_tap_weight, float* w_out);
 
+// The same layer with its K loop on the bf16 matrix cores from split operands (upfir_split.hip: three bf16 parts per fp32 value, six
+// product terms, fp32 accumulation -- fp32 accuracy): 16 channels per block, one block per CU, whole image height per block (no row
+// segments), inputs whose width the 64-column strips tile. w points at upfirs_arrange_weights' image (bf16 parts).
+bool upfirs_supported(int cin, int cout, int H, int W);
+size_t upfirs_weight_floats(int cin, int cout);
+void upfirs_arrange_weights(const float* w_in /*[9][cin][cout] scaled*/, int cin, int cout, const int* up_tap_weight, float* w_out);
+void upfirs_plan(int B, int cout, int H, int W, int num_cus, UpFirArgs* args);
+hipError_t launch_upfir_split(const UpFirArgs& args, hipStream_t stream);
+
 // The two smallest up layers (4x4 -> 8x8, 8x8 -> 16x16) in scatter form (gemm_forms.hip): pack (x * style -> the GEMM's B image),
 // ONE dense GEMM P[tap slot * Cout + co][b H W + position] (M = 9 Cout, K = Cin), gather (taps of a class, x demod) into the parity
 // planes the FIR pass reads. Replaces the transposed-conv launch where the position grid tiles badly (81 of 256 tile slots).

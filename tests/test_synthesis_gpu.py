@@ -215,6 +215,89 @@ def test_fused_upsampling_layer_matches_oracle_layerwise(library, resolution: in
         engine.close()
 
 
+@pytest.mark.parametrize(
+    "resolution,batch,noise,conv_form",
+    [(128, 3, True, "auto"), (256, 2, True, "winograd43"), (256, 3, False, "winograd43"), (256, 2, True, "direct"), (512, 1, True, "winograd43")],
+)
+def test_split_operand_up_layers_match_oracle_layerwise(library, resolution: int, batch: int, noise: bool, conv_form: str, monkeypatch) -> None:
+    """
+    Conv0_up with its K loop on the bf16 matrix cores from SPLIT operands (upfir_split.hip: every fp32 value as three bf16
+    parts, the six largest part products, fp32 accumulation), forced at a small batch (GANCE_TUNE_UPFIR_SPLIT=2; the default takes
+    it where a launch fills the chip): the SAME bar as the fp32-MFMA forms, 2e-5 of the activation's range per layer against the fp64
+    oracle, every term on. Inputs 64 ... 256 wide: one, two and four strips (recomputed halo columns from the per-chunk side
+    buffer), 2 ... 16 chunks of 32 input channels, pre-scaled input ("winograd43": the F(4x4,3x3) launch before it folds the style
+    into its stores) and plain input (the style multiplied in while staging), with and without noise.
+    """
+    monkeypatch.setenv("GANCE_TUNE_UPFIR_SPLIT", "2")  # (read when the engine is created)
+    spec = sg2_spec.make_spec(resolution)
+    variables = sg2_spec.make_random_variables(resolution, seed=3, perturb=True)
+    if not noise:
+        variables = {name: (np.zeros_like(value) if name.endswith("/noise_strength") else value) for name, value in variables.items()}
+    dlatents = np.random.RandomState(5).randn(batch, spec.num_layers, 512).astype(np.float32)
+    engine = hip_lib.Engine(variables, resolution, max_batch=batch, up_form="fused", conv_form=conv_form, profile=True)
+
+    def layers_of_the_oracle():
+        collected: list = []
+        with torch.no_grad():
+            ref.g_synthesis(torch.from_numpy(dlatents).double(), variables, resolution, collect=collected)
+        return collected
+
+    wants = _oracle_once(("split_up_layerwise", resolution, batch, noise), layers_of_the_oracle)
+    try:
+        worst = 0.0
+        for n, conv in enumerate(spec.convs, start=1):
+            if not (conv.up and 2 ** conv.res_log2 >= 128):
+                continue
+            got = engine.debug_activation_after(dlatents, n)
+            want = wants[n - 1].numpy()
+            rel = np.abs(got - want).max() / np.abs(want).max()
+            worst = max(worst, rel)
+            assert rel < 2e-5, f"conv layer {n} ({conv.scope}): rel err {rel}"
+        engine.synthesize_w(dlatents)
+        split = [step.name for step in engine.steps() if step.name.endswith("/s3")]
+        assert len(split) == int(np.log2(resolution)) - 6, split  # every up layer whose input is >= 64 wide
+        print(f"\nsplit-operand up layers at {resolution}^2, batch {batch}: worst layer {worst:.2e} of its range")
+    finally:
+        engine.close()
+
+
+@pytest.mark.parametrize("log2_scale", [40, -40, -100])
+def test_split_operand_up_layer_keeps_the_fp32_exponent_range(library, log2_scale: int, monkeypatch) -> None:
+    """
+    bf16 has fp32's exponent, so the three parts of a value are normal numbers wherever 2^-17 of the value is: the weights of the
+    one split-operand layer of a 128^2 network scaled by 2^+40, 2^-40 and 2^-100 (parts down to 1e-37) must neither overflow nor
+    flush. The layer's own range is the yardstick: scaled down, its bias and noise are zeroed (the demodulation's epsilon of 1e-8
+    then dominates its factor and the activation is tiny, 1e-8 ... 1e-26, but it is all convolution); the bar is the unchanged 2e-5.
+    """
+    monkeypatch.setenv("GANCE_TUNE_UPFIR_SPLIT", "2")
+    resolution, batch = 128, 2
+    spec = sg2_spec.make_spec(resolution)
+    variables = dict(sg2_spec.make_random_variables(resolution, seed=7, perturb=True))
+    scope = "G_synthesis/128x128/Conv0_up"
+    assert f"{scope}/weight" in variables
+    variables[f"{scope}/weight"] = (variables[f"{scope}/weight"].astype(np.float64) * 2.0 ** log2_scale).astype(np.float32)
+    if log2_scale < 0:
+        for leaf in ("bias", "noise_strength"):
+            variables[f"{scope}/{leaf}"] = np.zeros_like(variables[f"{scope}/{leaf}"])
+    dlatents = np.random.RandomState(9).randn(batch, spec.num_layers, 512).astype(np.float32)
+    engine = hip_lib.Engine(variables, resolution, max_batch=batch, up_form="fused", conv_form="winograd43", profile=True)
+    wants: list = []
+    with torch.no_grad():
+        ref.g_synthesis(torch.from_numpy(dlatents).double(), variables, resolution, collect=wants)
+    try:
+        n = next(i for i, conv in enumerate(spec.convs, start=1) if conv.scope.endswith("128x128/Conv0_up"))
+        got = engine.debug_activation_after(dlatents, n)
+        want = wants[n - 1].numpy()
+        assert np.isfinite(got).all() and np.abs(want).max() > 0
+        rel = np.abs(got - want).max() / np.abs(want).max()
+        print(f"\nsplit-operand up layer, weights x 2^{log2_scale}: range {np.abs(want).max():.3e}, rel err {rel:.2e}")
+        assert rel < 2e-5, f"weights x 2^{log2_scale}: rel err {rel}"
+        engine.synthesize_w(dlatents)
+        assert any(step.name.endswith("/s3") for step in engine.steps())
+    finally:
+        engine.close()
+
+
 @pytest.mark.parametrize("resolution,batch,split", [(16, 17, 0), (8, 40, 0), (32, 7, 0), (64, 2, 0), (128, 1, 0), (16, 17, 1), (32, 16, 1), (16, 17, 2), (32, 16, 2)])
 def test_smallest_up_layers_in_scatter_form_match_oracle_layerwise(library, resolution: int, batch: int, split: int, monkeypatch) -> None:
     """
