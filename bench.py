@@ -42,6 +42,8 @@ import datetime  # noqa: E402
 # a rank that dies must not leave the others in a collective for ever (default: 10 minutes for RCCL, 30 for gloo)
 PROCESS_GROUP_TIMEOUT = datetime.timedelta(seconds=int(os.environ.get("GANCE_PROCESS_GROUP_TIMEOUT_S", "180")))
 FP32_MFMA_PEAK_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
+BF16_MFMA_PEAK_TFLOPS = 2516.6  # the same guide: 512 MACs per clock and SIMD x 1024 SIMDs x 2.4 GHz ("~2.5 PF dense"; v_mfma_f32_16x16x32_bf16: 8192 MACs in 16 cycles)
+SPLIT_DTYPE = "f32 (bf16x3 split operands, 6 terms, fp32 accumulate)"
 HBM_PEAK_GBS = 8000.0
 ALGORITHMIC_GFLOP_PER_FRAME_1024 = 148.5
 
@@ -62,6 +64,8 @@ def kernel_of_step(step_name: str) -> str:
     """The HIP kernel behind a conv launch of the engine's step table (names: engine.hip)."""
     if step_name.startswith("convTF"):  # ("p": input pre-scaled by the Winograd launch before it; "/16": the 16-channel geometry)
         pre = "_pre" if step_name.startswith("convTFp") else ""
+        if step_name.endswith("/s3"):  # the split-operand form (upfir_split.hip): bf16 x 3 parts, six product terms, fp32 accumulation
+            return f"upfirs_fused{pre}_kernel"
         if not step_name.endswith(("/16", "/16x")):
             return f"upfir_fused{pre}_kernel"
         side = int(re.search(r"_(\d+)x\1_", step_name).group(1)) // 2  # the layer's INPUT width picks the strip geometry
@@ -91,7 +95,19 @@ def executed_fraction(step_name: str) -> float:
         return 0.25
     if step_name.endswith("/16x"):
         return 15.0 / 18.0
+    if step_name.endswith("/s3"):
+        return 6.0  # six bf16 x bf16 part products per fp32 product, on the bf16 matrix cores (matrix_peak: 2516.6 TFLOP/s)
     return 4.0 / 9.0 if step_name.startswith("convW") else 1.0
+
+
+def matrix_peak(step_name: str) -> float:
+    """Dense peak of the matrix pipe a launch's products execute on: bf16 MFMA for the split-operand form, fp32 MFMA otherwise."""
+    return BF16_MFMA_PEAK_TFLOPS if step_name.endswith("/s3") else FP32_MFMA_PEAK_TFLOPS
+
+
+def matrix_pipe(step_name: str) -> str:
+    """Name of that pipe, for the roofline record."""
+    return "bf16 MFMA (fp32 products from three bf16 parts per operand, six part products each, fp32 accumulation)" if step_name.endswith("/s3") else "fp32 MFMA"
 
 
 def kernel_sources_digest() -> str:
@@ -315,8 +331,8 @@ def product_stream_measurement(  # pylint: disable=too-many-arguments,too-many-l
             # the matrix cores EXECUTE (a Winograd F(4x4,3x3) launch: 1/4 of the layer's direct-form flops), always <= 1 of the peak;
             # the layer priced as a direct convolution stands beside it as `*_direct_form` (it may exceed the peak).
             "achieved": round(executed_fraction(last_conv) * timed_flops / (timed_ms * 1e-3) / 1e12, 3) if timed else None,
-            "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(executed_fraction(last_conv) * timed_flops / (timed_ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4) if timed else None,
+            "peak": matrix_peak(last_conv), "unit": "TFLOP/s", "pipe": matrix_pipe(last_conv),
+            "frac": round(executed_fraction(last_conv) * timed_flops / (timed_ms * 1e-3) / 1e12 / matrix_peak(last_conv), 4) if timed else None,
             "achieved_direct_form": round(timed_flops / (timed_ms * 1e-3) / 1e12, 3) if timed else None,
             "frac_direct_form": round(timed_flops / (timed_ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4) if timed else None,
             "audio_stage": {
@@ -611,7 +627,10 @@ def main() -> int:
     conv_flops = sum(s.flops for s in conv_steps)
     # Winograd F(2x2,3x3) launches ("convW..."): flops above are the ALGORITHMIC (direct-form) ones; the
     # matrix cores execute 4/9 of them
-    executed_flops = sum(s.flops * executed_fraction(s.name) for s in conv_steps)
+    executed_flops = sum(s.flops * executed_fraction(s.name) for s in conv_steps if not s.name.endswith("/s3"))  # on the fp32 matrix pipe
+    split_steps = [s for s in conv_steps if s.name.endswith("/s3")]
+    # matrix-pipe time the step's products need at the pipes' peaks (each launch on its own pipe) -- over the wall time: the utilisation
+    pipe_seconds = sum(s.flops * executed_fraction(s.name) / (matrix_peak(s.name) * 1e12) for s in conv_steps)
     winograd_launches = sum(1 for s in conv_steps if s.name.startswith(("convW", "convV")))
     winograd43_launches = sum(1 for s in conv_steps if s.name.startswith("convV"))
     total_ms = sum(s.ms for s in steps_info)
@@ -637,7 +656,7 @@ def main() -> int:
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32",
+            "dtype": SPLIT_DTYPE if split_steps else "f32",
             "data": "synthetic (random-init weights seed 0, RandomState(1) z vectors)" + (" --all-terms: noise strengths and biases non-zero" if args.all_terms else "") + (" REHEARSAL: ranks share one GPU over gloo, not a measurement" if rehearsal else ""),
             "config": {
                 "workload": "BASELINE.json configs[1]: FFHQ config-f %dx%d random-init, batched random-z synthesis (mapping + truncation psi=1.2 + synthesis + uint8 NHWC), frames resident in HBM" % (resolution, resolution),
@@ -654,9 +673,10 @@ def main() -> int:
                 # executes 15/18 of the layer's direct-form flops (a Winograd launch 1/4 or 4/9); SURVEY.md section 8(d)'s ALGORITHMIC
                 # figure -- the layer priced as a direct convolution -- stands beside it as `*_direct_form` and may exceed the peak.
                 "achieved": round(executed_fraction(dominant.name) * dominant.flops / (dominant.ms * 1e-3) / 1e12, 3),
-                "peak": FP32_MFMA_PEAK_TFLOPS,
+                "peak": matrix_peak(dominant.name),
                 "unit": "TFLOP/s",
-                "frac": round(executed_fraction(dominant.name) * dominant.flops / (dominant.ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4),
+                "pipe": matrix_pipe(dominant.name),
+                "frac": round(executed_fraction(dominant.name) * dominant.flops / (dominant.ms * 1e-3) / 1e12 / matrix_peak(dominant.name), 4),
                 "achieved_direct_form": round(dominant.flops / (dominant.ms * 1e-3) / 1e12, 3),
                 "frac_direct_form": round(dominant.flops / (dominant.ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4),
                 "executed_share_of_direct_form": round(executed_fraction(dominant.name), 4),
@@ -675,8 +695,11 @@ def main() -> int:
                 "all_conv_launches": {
                     # executed matrix-core flops of all conv launches over their summed durations (Winograd launches
                     # count 4/9 of their direct-form flops: that is what runs)
-                    "achieved": round(executed_flops / (conv_ms * 1e-3) / 1e12, 3),
-                    "frac": round(executed_flops / (conv_ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4),
+                    "frac": round(pipe_seconds / (conv_ms * 1e-3), 4),
+                    "frac_note": "time the launches' executed products need at the dense peak of the matrix pipe each runs on (fp32 MFMA 157.3 TFLOP/s; "
+                    "the %d split-operand launches: bf16 MFMA 2516.6 TFLOP/s, six part products per fp32 product) over their measured time" % len(split_steps),
+                    "fp32_pipe_achieved": round(executed_flops / (sum(s.ms for s in conv_steps if not s.name.endswith("/s3")) * 1e-3) / 1e12, 3),
+                    "bf16_pipe_achieved": round(sum(6.0 * s.flops for s in split_steps) / (sum(s.ms for s in split_steps) * 1e-3) / 1e12, 3) if split_steps else None,
                     "algorithmic_direct_form": round(conv_flops / (conv_ms * 1e-3) / 1e12, 3),
                     "share_of_step_time": round(conv_ms / total_ms, 4),
                     "winograd_launches": winograd_launches,
@@ -685,7 +708,7 @@ def main() -> int:
                 },
                 # the whole step (mapping, styles, ToRGB, uint8 included) against the matrix peak: executed flops of a
                 # step over its wall time; and the same in direct-form flops, the work a direct implementation would do
-                "whole_path_frac": round(executed_flops / (elapsed / args.steps) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4),
+                "whole_path_frac": round(pipe_seconds / (elapsed / args.steps), 4),
                 "whole_path_direct_form_frac": round(
                     (fps / world_size) * ALGORITHMIC_GFLOP_PER_FRAME_1024 * (resolution / 1024) ** 2 / 1e3 / FP32_MFMA_PEAK_TFLOPS, 4
                 ),

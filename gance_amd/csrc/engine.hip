@@ -289,6 +289,7 @@ struct gance_engine {
     std::vector<size_t> upfir16x_w;  // ... and for that geometry's pair form (F(2,2) along x: 15 MFMAs per pair of columns instead of 18)
     std::vector<size_t> upfirs_w;    // split-operand form of the fused up kernel (upfir_split.hip: three bf16 parts per value, six terms, fp32 accumulation)
     int upfir_split = 1;  // GANCE_TUNE_UPFIR_SPLIT when the engine is created: 0 never, 1 (default) where a launch fills the chip without row segments, 2 wherever supported
+    int upfir_split_max_res = 512;  // GANCE_TUNE_UPFIR_SPLIT_MAXRES: the largest OUTPUT side that takes the split form in mode 1 (measured: DESIGN.md section 3)
     int num_cus = 256;
     std::vector<float> conv_ns;
     std::vector<int> conv_s_off, conv_d_off;
@@ -663,7 +664,7 @@ int synthesize_from_dlat(gance_engine* e, const float* d_dlat, int B, uint8_t* d
         // the split-operand form (upfir_split.hip) sweeps the whole image height per block: where its launch fills the chip
         if (e->upfirs_w[idx] != SIZE_MAX && upfir_mode != 0) {
             gance::upfirs_plan(B, c.cout, H, H, e->num_cus, &u);
-            if (e->upfir_split == 2 || u.total_blocks >= e->num_cus * 3 / 4) {
+            if (e->upfir_split == 2 || (u.total_blocks >= e->num_cus * 3 / 4 && 2 * H <= e->upfir_split_max_res)) {
                 u.pair_form = 2;  // (marks the plan: the caller launches launch_upfir_split)
                 if (plan != nullptr) *plan = u;
                 return true;
@@ -1102,6 +1103,8 @@ int gance_engine_create(const gance_engine_config* config, const float* host_wei
         e->gemm_bf16 = v != nullptr ? std::max(0, std::min(2, std::atoi(v))) : 0;
         const char* const split = std::getenv("GANCE_TUNE_UPFIR_SPLIT");
         e->upfir_split = split != nullptr ? std::max(0, std::min(2, std::atoi(split))) : 1;
+        const char* const split_res = std::getenv("GANCE_TUNE_UPFIR_SPLIT_MAXRES");
+        if (split_res != nullptr) e->upfir_split_max_res = std::atoi(split_res);
     }
     e->cfg = *config;
     e->num_cus = num_cus > 0 ? num_cus : 256;

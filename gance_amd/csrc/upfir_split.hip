@@ -51,6 +51,13 @@
 
 #include "kernels.h"
 
+// Timing ablations (wrong results; only in builds with -DGANCE_UPFIRS_ABLATE=<flags>, Makefile target ../libgance_hip_upfirsab<flags>.so, used
+// through GANCE_HIP_LIBRARY): 1 no split arithmetic (the raw values are written), 2 no epilogue, 4 no global loads of patch rows in the row
+// loop, 8 no MFMAs, 16 no LDS writes of staged rows, 32 no barrier per row, 64 no halo tile / edge copy
+#ifndef GANCE_UPFIRS_ABLATE
+#define GANCE_UPFIRS_ABLATE 0
+#endif
+
 namespace gance {
 
 namespace {
@@ -74,7 +81,10 @@ constexpr int kRing = 3;
 constexpr int kHaloCols = 4;        // input columns X0 - 2, X0 - 1, X0 + 63, X0 + 64
 constexpr int kHaloUnits = kRows * kHaloCols * kPlanes;
 constexpr int kHaloTasks = kRows * kHaloCols * 4;  // (row, column, k-group): 144
-constexpr int kDepth = 3;           // patch rows in flight between their global loads and their LDS writes
+#ifndef GANCE_UPFIRS_DEPTH
+#define GANCE_UPFIRS_DEPTH 6
+#endif
+constexpr int kDepth = GANCE_UPFIRS_DEPTH;  // patch rows in flight between their global loads and their LDS writes (3 or 6: 8 registers each)
 constexpr int kCarryRows = 3;
 constexpr int kPassCh = 4;          // channels per epilogue pass
 constexpr int kPassRows = 8;        // T rows per pass: four position rows
@@ -87,7 +97,7 @@ constexpr int kCarryFloats = kBM * kCarryRows * kTW;
 constexpr int kStageFloats = kPassCh * kPassRows * kTW;
 constexpr int kNzPieces = 2 * kPassRows * 2 * kSW / 256;  // noise of a step's 16 output rows in 1 KiB DMA pieces
 constexpr float kSqrt2f = 1.4142135623730951f;
-static_assert(kRows % kDepth == 0 && kRows % kRing == 0, "ring slots and staging registers rotate with the unrolled rows");
+static_assert((2 * kRows) % kDepth == 0 && kDepth + 2 < kRows && kRows % kRing == 0, "ring slots and staging registers rotate with the unrolled rows of a chunk pair");
 
 // LDS (bytes): ring | halo side buffers (two chunks) | T window of a pass | the step's noise | carry | style [Cin] | demod | bias | next style
 constexpr size_t kRingBytes = (size_t)kRing * kSlotUnits * 16;
@@ -128,6 +138,11 @@ __device__ __forceinline__ void split_pair(float a, float b, unsigned& p0, unsig
 // eight fp32 values (the channels of one k-group at one position) -> the position's three 16-byte units
 __device__ __forceinline__ void split_unit(const unsigned (&raw)[8], u32x4 (&part)[3]) {
     unsigned w[3][4];
+    if (GANCE_UPFIRS_ABLATE & 1) {
+#pragma unroll
+        for (int q = 0; q < 3; ++q) part[q] = u32x4{raw[q], raw[q + 1], raw[q + 2], raw[q + 3]};
+        return;
+    }
 #pragma unroll
     for (int e = 0; e < 4; ++e) split_pair(__builtin_bit_cast(float, raw[2 * e]), __builtin_bit_cast(float, raw[2 * e + 1]), w[0][e], w[1][e], w[2][e]);
 #pragma unroll
@@ -179,35 +194,29 @@ __device__ __forceinline__ void upfirs_body(const UpFirArgs& p) {
     const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(
         (void*)(reinterpret_cast<const unsigned char*>(p.w) + (size_t)m_tile * chunks * 27 * 1024), 0, chunks * 27 * 1024, 0x00020000);
 
-    // ---- the stream of patch rows: (step, chunk, row j) in the order they are consumed; the producer runs 2 + kDepth rows ahead.
-    // Past the last row it stays on it (reloading a row is harmless, a branch would cut the scheduling region of a row). ----
-    int ps = 0, pc = 0, pj = 0;
-    auto advance = [&]() {
-        if (ps == steps - 1 && pc == chunks - 1 && pj == kRows - 1) return;
-        if (++pj == kRows) {
-            pj = 0;
-            if (++pc == chunks) {
-                pc = 0;
-                ++ps;
-            }
-        }
-    };
+    // ---- the stream of patch rows: (step, chunk, row j) in the order they are consumed; the producer runs 2 + kDepth rows ahead,
+    // so the row it loads is row (j + 2 + kDepth) % 9 of the consumer's chunk or of the chunk after it: known where the load is written ----
     // per-lane LDS bases: everything that changes with the row, the chunk parity or the part is a compile-time offset from one of them
     // (the instruction's immediate): per-row address registers would not fit beside 144 accumulators and 108 weight registers
     u32x4* const ring_w = ring + wave * kPlaneStride + lane + 1;                  // staging write: k-group = wave, ring column = x - X0 + 1
     const u32x4* const ring_r = ring + kg * kPlaneStride + 16 * wave + n16;       // fragment read of position column 16 wave + n16, dx = -1 (+ 1: dx = 0)
-    u32x4* const ring_e = ring + (lane >> 2) * 4 * kPlaneStride + (lane & 3) * kPlaneStride;  // edge copy: lane = part * 4 + k-group, ring column 0
-    const u32x4* const halo_e = halo + lane;                                      // ... from unit [row][column 1][lane]
+    // column X0 - 1 of a ring row (the dx = -1 fragment of the strip's first lane) is not a main staging task (64 lanes = 64 columns):
+    // twelve lanes of wave 3 copy its units (lane = part * 4 + k-group) from the halo side buffer of the row's chunk; every other lane
+    // copies the same unit into the padding of its plane row (columns 65 .. 79 are never read): no branch in the row's instruction stream
+    const bool edge_copy = wave == 3 && lane < kPlanes;
+    const int e_unit = lane % kPlanes;
+    u32x4* const ring_e = ring + (e_unit >> 2) * 4 * kPlaneStride + (e_unit & 3) * kPlaneStride + (edge_copy ? 0 : 66 + wave);
+    const u32x4* const halo_e = halo + e_unit;                                    // ... from unit [row][column 1][part * 4 + k-group]
     const u32x4* const halo_r = halo + ((n16 & 7) * kHaloCols + 2 * (n16 >> 3)) * kPlanes + kg;  // halo tile slot n16 = (side, position row)
     const u32x4* const halo_f = halo + ((kRows - 1) * kHaloCols + 2 * (n16 >> 3)) * kPlanes + kg;  // ... of position row y' = H: the chunk's last row
-    // main staging task of this lane: column X0 + lane, k-group = wave: eight dword loads (row `kTH ps + pj` of the bordered tensor)
+    // main staging task of this lane: column X0 + lane, k-group = wave: eight dword loads (buffer row `brow` of the bordered tensor)
     const int st_voff = (X0 + 4 + lane) * 4;
     unsigned st[kDepth][8];
-    auto stage_load = [&](unsigned(&dst)[8]) {
-        const int soff = ((pc * kKC + wave * 8) * Hp + kTH * ps + pj) * Wp * 4;
+    auto stage_load = [&](unsigned(&dst)[8], int chunk, int brow, bool in_loop = false) {
+        if ((GANCE_UPFIRS_ABLATE & 4) && in_loop) return;
+        const int soff = ((chunk * kKC + wave * 8) * Hp + brow) * Wp * 4;
 #pragma unroll
         for (int e = 0; e < 8; ++e) dst[e] = __builtin_amdgcn_raw_buffer_load_b32(x_rsrc, st_voff, soff + e * HpWp4, 0);
-        advance();
     };
     // (style of the channels this lane stages: the consumer's chunk is known where the write happens)
     auto scale8 = [&](unsigned(&raw)[8], int chunk, int group) {
@@ -226,35 +235,28 @@ __device__ __forceinline__ void upfirs_body(const UpFirArgs& p) {
         u32x4 part[3];
         split_unit(raw, part);
 #pragma unroll
-        for (int q = 0; q < 3; ++q) ring_w[slot * kSlotUnits + q * 4 * kPlaneStride] = part[q];
+        for (int q = 0; q < 3; ++q)
+            if (!(GANCE_UPFIRS_ABLATE & 16)) ring_w[slot * kSlotUnits + q * 4 * kPlaneStride] = part[q];
     };
-    // column X0 - 1 of a ring row (the dx = -1 fragment of the strip's first lane) is not a main staging task (64 lanes = 64 columns):
-    // twelve lanes of wave 3 (which has no halo task) copy its units from the halo side buffer of the row's chunk
-    const bool edge_copy = wave == 3 && lane < kPlanes;
-    auto edge_store = [&](int slot, int hbuf, int hrow) {
-        if (edge_copy) ring_e[slot * kSlotUnits] = halo_e[hbuf * kHaloUnits + (hrow * kHaloCols + 1) * kPlanes];
-    };
+    auto edge_store = [&](int slot, int hbuf, int hrow) { if (!(GANCE_UPFIRS_ABLATE & 64)) ring_e[slot * kSlotUnits] = halo_e[hbuf * kHaloUnits + (hrow * kHaloCols + 1) * kPlanes]; };
     // halo side buffer of a chunk: task = (row, column, k-group); unit [(row * 4 + column) * 12 + part * 4 + k-group]
-    const bool halo_task = tid < kHaloTasks;
-    const int h_col = tid & 3, h_kg = (tid >> 2) & 3, h_row = tid >> 4;
+    // (every lane has one: the lanes beyond the 144 repeat the first ones -- the same values to the same place, no branch)
+    const int h_task = tid < kHaloTasks ? tid : tid - kHaloTasks;
+    const int h_col = h_task & 3, h_kg = (h_task >> 2) & 3, h_row = h_task >> 4;
     const int h_voff = ((h_kg * 8 * Hp + h_row) * Wp + X0 + 2 + (h_col & 1) + (h_col >> 1) * 65) * 4;  // bordered columns of X0 - 2, X0 - 1, X0 + 63, X0 + 64
     u32x4* const halo_w = halo + (h_row * kHaloCols + h_col) * kPlanes + h_kg;
     unsigned hraw[8];
     auto halo_load = [&](int step, int chunk) {
-        if (halo_task) {
-            const int soff = (chunk * kKC * Hp + kTH * step) * Wp * 4;
+        const int soff = (chunk * kKC * Hp + kTH * step) * Wp * 4;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) hraw[e] = __builtin_amdgcn_raw_buffer_load_b32(x_rsrc, h_voff, soff + e * HpWp4, 0);
-        }
+        for (int e = 0; e < 8; ++e) hraw[e] = __builtin_amdgcn_raw_buffer_load_b32(x_rsrc, h_voff, soff + e * HpWp4, 0);
     };
     auto halo_store = [&](int chunk, int buf) {
-        if (halo_task) {
-            scale8(hraw, chunk, h_kg);
-            u32x4 part[3];
-            split_unit(hraw, part);
+        scale8(hraw, chunk, h_kg);
+        u32x4 part[3];
+        split_unit(hraw, part);
 #pragma unroll
-            for (int q = 0; q < 3; ++q) halo_w[buf * kHaloUnits + q * 4] = part[q];
-        }
+        for (int q = 0; q < 3; ++q) halo_w[buf * kHaloUnits + q * 4] = part[q];
     };
 
     // ---- weight fragments: A[tap][part], 16 bytes per lane each, from the split image. ONE set (108 registers; two sets spilled,
@@ -279,8 +281,8 @@ __device__ __forceinline__ void upfirs_body(const UpFirArgs& p) {
     };
 
     // ---- prologue: constants, the zeroed carry, halo buffer of the first chunk, rows 0 and 1 in the ring, rows 2..4 in flight ----
-    stage_load(st[0]);
-    stage_load(st[1]);
+    stage_load(st[0], 0, 0);
+    stage_load(st[1], 0, 1);
     load_a3(0, 0, A[0]);
     halo_load(0, 0);
     if constexpr (!kPre)
@@ -297,9 +299,8 @@ __device__ __forceinline__ void upfirs_body(const UpFirArgs& p) {
     stage_store(st[0], 0, 0);
     stage_store(st[1], 1, 0);
     halo_store(0, 0);
-    stage_load(st[2]);
-    stage_load(st[0]);
-    stage_load(st[1]);
+#pragma unroll
+    for (int r = 2; r < 2 + kDepth; ++r) stage_load(st[r % kDepth], 0, r);  // (row r of the stream waits in st[r % kDepth])
     lds_barrier();
     edge_store(0, 0, 0);
     edge_store(1, 0, 1);
@@ -346,18 +347,29 @@ __device__ __forceinline__ void upfirs_body(const UpFirArgs& p) {
                 if (j == 4) halo_store(n_chunk, ab ^ 1);
                 load_b((j + 1) % kRing, Bf[cur ^ 1]);
                 edge_store((j + 2) % kRing, j + 2 < kRows ? ab : ab ^ 1, (j + 2) % kRows);
-                stage_store(st[(j + 2) % kDepth], (j + 2) % kRing, j + 2 < kRows ? chunk : n_chunk);
-                stage_load(st[(j + 2) % kDepth]);
+                // (row index in the stream modulo the chunk pair: 9 ab + j; its staging registers: that modulo kDepth)
+                stage_store(st[(kRows * ab + j + 2) % kDepth], (j + 2) % kRing, j + 2 < kRows ? chunk : n_chunk);
+                stage_load(st[(kRows * ab + j + 2) % kDepth], j + 2 + kDepth < kRows ? chunk : n_chunk, kTH * (j + 2 + kDepth < kRows ? si : n_step) + (j + 2 + kDepth) % kRows, true);
                 if (j + 1 < kRows) {
 #pragma unroll
                     for (int t = 0; t < 9; ++t) {
                         const int row = tap_dy(t) ? j : j - 1;
                         if (row < 0 || row >= kTH) continue;
 #pragma unroll
-                        for (int term = 0; term < 6; ++term)
+                        for (int term = 0; term < ((GANCE_UPFIRS_ABLATE & 8) ? 0 : 6); ++term)
                             acc[row][tap_cls(t)] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
                                 __builtin_bit_cast(bf16x8, A[t][kTerms[term][1]]), __builtin_bit_cast(bf16x8, Bf[cur][tap_dx(t)][kTerms[term][0]]),
                                 acc[row][tap_cls(t)], 0, 0, 0);
+                    }
+                    // The row is ONE branch-free scheduling region: its MFMAs, and for the rows ahead six fragment reads, the edge copy, the
+                    // split of a staged row (44 vector instructions, three LDS writes) and eight loads. A bf16 MFMA holds the vector issue
+                    // for 8 of its 16 cycles: dealt out two per MFMA the other instructions ride in its shadow; in a clump in front of the
+                    // MFMAs (where the dependences alone would put them) they cost their full issue time.
+#pragma unroll
+                    for (int i = 0; i < 54; ++i) {
+                        if (i >= (j == 0 ? 18 : 54)) break;                 // (row 0 only has the dy = -1 taps)
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // one MFMA
+                        __builtin_amdgcn_sched_group_barrier(0x092, 2, 0);  // two of: vector ALU, vector memory, LDS
                     }
                 } else {
                     // The chunk's last row, tap by tap (the dy = -1 taps first: the next chunk's first row needs them first): the row's
@@ -381,7 +393,7 @@ __device__ __forceinline__ void upfirs_body(const UpFirArgs& p) {
                                     __builtin_bit_cast(bf16x8, A[t][kTerms[term][1]]), __builtin_bit_cast(bf16x8, Bf[cur][tap_dx(t)][kTerms[term][0]]),
                                     accf[tap_cls(t)], 0, 0, 0);
                         }
-                        if (wave == tap_cls(t)) {
+                        if (wave == tap_cls(t) && !(GANCE_UPFIRS_ABLATE & 64)) {
                             u32x4 hf[3];
 #pragma unroll
                             for (int q = 0; q < 3; ++q) hf[q] = halo_r[ab * kHaloUnits + ((1 - tap_dy(t)) * kHaloCols + 1 - tap_dx(t)) * kPlanes + q * 4];
@@ -402,7 +414,7 @@ __device__ __forceinline__ void upfirs_body(const UpFirArgs& p) {
                         load_a3(n_chunk, t, A[t]);
                     }
                 }
-                lds_barrier();
+                if (!(GANCE_UPFIRS_ABLATE & 32)) lds_barrier();
             }
         };
 #pragma unroll 1
@@ -515,6 +527,15 @@ __device__ __forceinline__ void upfirs_body(const UpFirArgs& p) {
                 }
             }
         };
+        if (GANCE_UPFIRS_ABLATE & 2) {  // (the accumulators stay alive: a store that never happens)
+            float sum = acch[0] + acchf[0] + accf[0][0] + accf[1][0];
+#pragma unroll
+            for (int r = 0; r < kTH; ++r)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) sum += acc[r][c][0] + acc[r][c][3];
+            if (sum == 12345.678f) p.out[tid] = sum;
+            continue;
+        }
         run_passes(std::false_type{});
         if (last_step) {
             lds_barrier();  // (the carry of the last pass is read by every row group of the flush pass)

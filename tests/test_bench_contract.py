@@ -39,6 +39,13 @@ def test_step_names_map_to_kernels_and_executed_flops() -> None:
     # Winograd F(4x4, 3x3): 36 multiplies per 4x4 tile and input channel instead of 144
     assert bench.kernel_of_step("convV8+rgb_64x64_512->512") == "winograd43_rgb_kernel" and bench.executed_fraction("convV8+rgb_64x64_512->512") == 0.25
     assert bench.executed_fraction("conv4_16x16_512->512") == 1.0
+    # the split-operand form of the fused up kernel: six bf16 part products per fp32 product, priced against the bf16 matrix peak
+    name = "convTFp15_1024x1024_64->32/s3"
+    assert bench.kernel_of_step(name) == "upfirs_fused_pre_kernel" and bench.kernel_of_step("convTF9_128x128_512->256/s3") == "upfirs_fused_kernel"
+    assert bench.executed_fraction(name) == 6.0 and bench.matrix_peak(name) == bench.BF16_MFMA_PEAK_TFLOPS
+    assert bench.matrix_peak("convTFp15_1024x1024_64->32/16x") == bench.FP32_MFMA_PEAK_TFLOPS
+    # even at the fp32 pipe's whole algorithmic rate (157.3 TFLOP/s of direct-form flops) the split form is well under its own roof
+    assert 6.0 * bench.FP32_MFMA_PEAK_TFLOPS / bench.BF16_MFMA_PEAK_TFLOPS < 0.4
 
 
 def test_traffic_record_covers_the_dominant_launches_of_the_default_workload() -> None:
