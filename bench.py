@@ -60,10 +60,15 @@ def usable_cores() -> int:
     return max(1, cores)
 
 
+SPLIT_SUFFIXES = ("/s3", "/s3r")  # launches whose products run on the bf16 matrix cores from split operands (engine.hip step names)
+
+
 def kernel_of_step(step_name: str) -> str:
     """The HIP kernel behind a conv launch of the engine's step table (names: engine.hip)."""
     if step_name.startswith("convTF"):  # ("p": input pre-scaled by the Winograd launch before it; "/16": the 16-channel geometry)
         pre = "_pre" if step_name.startswith("convTFp") else ""
+        if step_name.endswith("/s3r"):  # the split-operand form in two wave roles (upfir_split_roles.hip): matrix waves + vector waves
+            return f"upfirr_fused{pre}_kernel"
         if step_name.endswith("/s3"):  # the split-operand form (upfir_split.hip): bf16 x 3 parts, six product terms, fp32 accumulation
             return f"upfirs_fused{pre}_kernel"
         if not step_name.endswith(("/16", "/16x")):
@@ -95,19 +100,19 @@ def executed_fraction(step_name: str) -> float:
         return 0.25
     if step_name.endswith("/16x"):
         return 15.0 / 18.0
-    if step_name.endswith("/s3"):
+    if step_name.endswith(SPLIT_SUFFIXES):
         return 6.0  # six bf16 x bf16 part products per fp32 product, on the bf16 matrix cores (matrix_peak: 2516.6 TFLOP/s)
     return 4.0 / 9.0 if step_name.startswith("convW") else 1.0
 
 
 def matrix_peak(step_name: str) -> float:
     """Dense peak of the matrix pipe a launch's products execute on: bf16 MFMA for the split-operand form, fp32 MFMA otherwise."""
-    return BF16_MFMA_PEAK_TFLOPS if step_name.endswith("/s3") else FP32_MFMA_PEAK_TFLOPS
+    return BF16_MFMA_PEAK_TFLOPS if step_name.endswith(SPLIT_SUFFIXES) else FP32_MFMA_PEAK_TFLOPS
 
 
 def matrix_pipe(step_name: str) -> str:
     """Name of that pipe, for the roofline record."""
-    return "bf16 MFMA (fp32 products from three bf16 parts per operand, six part products each, fp32 accumulation)" if step_name.endswith("/s3") else "fp32 MFMA"
+    return "bf16 MFMA (fp32 products from three bf16 parts per operand, six part products each, fp32 accumulation)" if step_name.endswith(SPLIT_SUFFIXES) else "fp32 MFMA"
 
 
 def kernel_sources_digest() -> str:
@@ -627,8 +632,8 @@ def main() -> int:
     conv_flops = sum(s.flops for s in conv_steps)
     # Winograd F(2x2,3x3) launches ("convW..."): flops above are the ALGORITHMIC (direct-form) ones; the
     # matrix cores execute 4/9 of them
-    executed_flops = sum(s.flops * executed_fraction(s.name) for s in conv_steps if not s.name.endswith("/s3"))  # on the fp32 matrix pipe
-    split_steps = [s for s in conv_steps if s.name.endswith("/s3")]
+    executed_flops = sum(s.flops * executed_fraction(s.name) for s in conv_steps if not s.name.endswith(SPLIT_SUFFIXES))  # on the fp32 matrix pipe
+    split_steps = [s for s in conv_steps if s.name.endswith(SPLIT_SUFFIXES)]
     # matrix-pipe time the step's products need at the pipes' peaks (each launch on its own pipe) -- over the wall time: the utilisation
     pipe_seconds = sum(s.flops * executed_fraction(s.name) / (matrix_peak(s.name) * 1e12) for s in conv_steps)
     winograd_launches = sum(1 for s in conv_steps if s.name.startswith(("convW", "convV")))
@@ -698,7 +703,7 @@ def main() -> int:
                     "frac": round(pipe_seconds / (conv_ms * 1e-3), 4),
                     "frac_note": "time the launches' executed products need at the dense peak of the matrix pipe each runs on (fp32 MFMA 157.3 TFLOP/s; "
                     "the %d split-operand launches: bf16 MFMA 2516.6 TFLOP/s, six part products per fp32 product) over their measured time" % len(split_steps),
-                    "fp32_pipe_achieved": round(executed_flops / (sum(s.ms for s in conv_steps if not s.name.endswith("/s3")) * 1e-3) / 1e12, 3),
+                    "fp32_pipe_achieved": round(executed_flops / (sum(s.ms for s in conv_steps if not s.name.endswith(SPLIT_SUFFIXES)) * 1e-3) / 1e12, 3),
                     "bf16_pipe_achieved": round(sum(6.0 * s.flops for s in split_steps) / (sum(s.ms for s in split_steps) * 1e-3) / 1e12, 3) if split_steps else None,
                     "algorithmic_direct_form": round(conv_flops / (conv_ms * 1e-3) / 1e12, 3),
                     "share_of_step_time": round(conv_ms / total_ms, 4),

@@ -209,6 +209,7 @@ struct gance_workspace {
     std::vector<float*> act;      // per conv layer: zero-bordered output [Bmax][cout][res+2][res+8]
     std::vector<float*> tplanes;  // per up layer: [4 cls][max_units][cout][H+3][W+8] (else nullptr)
     float* slabs = nullptr;       // split-K scratch of the small stride-1 convs (dense)
+    void* x_units = nullptr;  // an up layer's input split into bf16 parts (upfir_split_roles.hip: launch_upfirr_split_activation)
     float *up_packed = nullptr, *up_prod = nullptr;  // the GEMM forms' operand images and products (gemm_forms.hip: scatter-form up layers, Winograd at 8x8 / 16x16)
     float* ybuf[2] = {nullptr, nullptr};
     float* rgb_coef = nullptr;  // [Bmax][8 m tiles][16][64]: A operands of a ToRGB product fused into a Winograd conv epilogue
@@ -237,6 +238,7 @@ struct gance_workspace {
         for (float* ptr : act) hipFree(ptr);
         for (float* ptr : tplanes) hipFree(ptr);
         hipFree(slabs);
+        hipFree(x_units);
         hipFree(up_packed);
         hipFree(up_prod);
         hipFree(ybuf[0]);
@@ -285,10 +287,12 @@ struct gance_engine {
     std::vector<size_t> winogemm_w;  // weight image of the Winograd F(4x4,3x3) GEMM form of the stride-1 layers at 8x8, 16x16 (gemm_forms.hip; else SIZE_MAX)
     std::vector<size_t> upgemm_w;  // weight image of the scatter-form GEMM of the two smallest up layers (gemm_forms.hip; else SIZE_MAX)
     size_t up_packed_floats = 0, up_prod_floats = 0;
+    size_t x_units_bytes = 0;  // the largest split input image of an up layer that can take the role-split form
     int gemm_bf16 = 0;  // experiment (GANCE_TUNE_GEMM_BF16X6 when the engine is created): the GEMM forms on the 16-bit matrix cores from split operands: 1 = bf16 x 3 (six terms), 2 = fp16 x 2 (three terms)
     std::vector<size_t> upfir16x_w;  // ... and for that geometry's pair form (F(2,2) along x: 15 MFMAs per pair of columns instead of 18)
     std::vector<size_t> upfirs_w;    // split-operand form of the fused up kernel (upfir_split.hip: three bf16 parts per value, six terms, fp32 accumulation)
     int upfir_split = 1;  // GANCE_TUNE_UPFIR_SPLIT when the engine is created: 0 never, 1 (default) where a launch fills the chip without row segments, 2 wherever supported
+    int upfir_split_roles = 1;  // GANCE_TUNE_UPFIR_SPLIT_ROLES: 1 (default) the split form with matrix and vector waves (upfir_split_roles.hip), 0 the one-role kernel (upfir_split.hip)
     int upfir_split_max_res = 512;  // GANCE_TUNE_UPFIR_SPLIT_MAXRES: the largest OUTPUT side that takes the split form in mode 1 (measured: DESIGN.md section 3)
     int num_cus = 256;
     std::vector<float> conv_ns;
@@ -663,9 +667,11 @@ int synthesize_from_dlat(gance_engine* e, const float* d_dlat, int B, uint8_t* d
         u.Cin = c.cin;
         // the split-operand form (upfir_split.hip) sweeps the whole image height per block: where its launch fills the chip
         if (e->upfirs_w[idx] != SIZE_MAX && upfir_mode != 0) {
-            gance::upfirs_plan(B, c.cout, H, H, e->num_cus, &u);
+            const bool roles = e->upfir_split_roles != 0 && gance::upfirr_supported(c.cin, c.cout, H, H);
+            if (roles) gance::upfirr_plan(B, c.cout, H, H, e->num_cus, &u);
+            else gance::upfirs_plan(B, c.cout, H, H, e->num_cus, &u);
             if (e->upfir_split == 2 || (u.total_blocks >= e->num_cus * 3 / 4 && 2 * H <= e->upfir_split_max_res)) {
-                u.pair_form = 2;  // (marks the plan: the caller launches launch_upfir_split)
+                u.pair_form = roles ? 3 : 2;  // (marks the plan: the caller launches launch_upfir_split_roles / launch_upfir_split)
                 if (plan != nullptr) *plan = u;
                 return true;
             }
@@ -806,7 +812,8 @@ int synthesize_from_dlat(gance_engine* e, const float* d_dlat, int B, uint8_t* d
             {
                 gance::UpFirArgs u{};
                 if (up_runs_fused(li, &u)) {
-                    const bool split_form = u.pair_form == 2;
+                    const bool roles_form = u.pair_form == 3;
+                    const bool split_form = u.pair_form == 2 || roles_form;
                     const bool geometry16 = !split_form && e->upfir16_w[li] != SIZE_MAX;
                     const bool pair_form = geometry16 && e->upfir16x_w[li] != SIZE_MAX && input_prescaled;
                     u.pair_form = pair_form ? 1 : 0;
@@ -829,16 +836,25 @@ int synthesize_from_dlat(gance_engine* e, const float* d_dlat, int B, uint8_t* d
                     u.x_b_stride = x_b_stride;
                     u.s_next = s_next;
                     u.input_prescaled = input_prescaled ? 1 : 0;
+                    u.x_units = e->ws->x_units;
                     // ("convTFp": upfir_fused_pre_kernel, the input arrives multiplied by this layer's style)
                     // (a trailing "/16": the 16-channel, two-blocks-per-CU geometry, upfir16_fused*_kernel; "/16x": its pair form)
                     // ("/s3": the split-operand form, upfirs_fused*_kernel: bf16 x 3 parts, six product terms, fp32 accumulation)
+                    // ("/s3r": the same products with the block's work in two roles, upfirr_fused*_kernel: matrix waves and vector waves)
                     std::snprintf(name, sizeof(name), input_prescaled ? "convTFp%d_%dx%d_%d->%d%s" : "convTF%d_%dx%d_%d->%d%s", c.layer_idx, res, res, c.cin,
-                                  c.cout, split_form ? "/s3" : (pair_form ? "/16x" : (geometry16 ? "/16" : "")));
+                                  c.cout, roles_form ? "/s3r" : split_form ? "/s3" : (pair_form ? "/16x" : (geometry16 ? "/16" : "")));
+                    if (roles_form) {
+                        // the layer's input times its style (unless the producer multiplied it in), split into three bf16 parts per value
+                        char split_name[64];
+                        std::snprintf(split_name, sizeof(split_name), "split%d_%dx%d_%d", c.layer_idx, H, W, c.cin);
+                        StepScope scope(e, stream, split_name, 0.0, 10.0 * (double)B * c.cin * (H + 2) * (W + 8));
+                        GANCE_HIP_CHECK(gance::launch_upfirr_split_activation(x_in, x_b_stride, input_prescaled ? nullptr : u.s, u.s_stride, e->ws->x_units, B, c.cin, H, W, stream));
+                    }
                     {
                         const double flops = 2.0 * 9 * (double)c.cin * c.cout * H * W * B;
                         const double bytes = 4.0 * ((double)B * c.cin * H * W + (double)B * c.cout * res * res + 9.0 * c.cin * c.cout);
                         StepScope scope(e, stream, name, flops, bytes);
-                        GANCE_HIP_CHECK(split_form ? gance::launch_upfir_split(u, stream)
+                        GANCE_HIP_CHECK(roles_form ? gance::launch_upfir_split_roles(u, stream) : split_form ? gance::launch_upfir_split(u, stream)
                                                    : (geometry16 ? gance::launch_upfir16_fused(u, stream) : gance::launch_upfir_fused(u, stream)));
                     }
                     x_in = x_out;
@@ -1003,6 +1019,7 @@ int acquire_workspace(gance_engine* e) {
         if (ok && c.up)
             ok = alloc((void**)&ws->tplanes[i], (size_t)4 * e->t_units[i] * c.cout * t_plane((1 << c.res_log2) / 2) * sizeof(float), true);
     }
+    ok = ok && alloc((void**)&ws->x_units, std::max<size_t>(16, e->x_units_bytes), false);
     ok = ok && alloc((void**)&ws->up_packed, std::max<size_t>(1, e->up_packed_floats) * sizeof(float), false) &&
          alloc((void**)&ws->up_prod, std::max<size_t>(1, e->up_prod_floats) * sizeof(float), false);
     ok = ok && alloc((void**)&ws->slabs, e->slab_floats * sizeof(float), false) &&
@@ -1103,6 +1120,8 @@ int gance_engine_create(const gance_engine_config* config, const float* host_wei
         e->gemm_bf16 = v != nullptr ? std::max(0, std::min(2, std::atoi(v))) : 0;
         const char* const split = std::getenv("GANCE_TUNE_UPFIR_SPLIT");
         e->upfir_split = split != nullptr ? std::max(0, std::min(2, std::atoi(split))) : 1;
+        const char* const roles = std::getenv("GANCE_TUNE_UPFIR_SPLIT_ROLES");
+        if (roles != nullptr) e->upfir_split_roles = std::atoi(roles) != 0 ? 1 : 0;
         const char* const split_res = std::getenv("GANCE_TUNE_UPFIR_SPLIT_MAXRES");
         if (split_res != nullptr) e->upfir_split_max_res = std::atoi(split_res);
     }
@@ -1360,6 +1379,12 @@ int gance_engine_create(const gance_engine_config* config, const float* host_wei
             e->up_packed_floats = std::max(e->up_packed_floats, gance::winogemm_packed_floats(samples, c.cin, 2 * H, 2 * H) * 3 / 2);
             e->up_prod_floats = std::max(e->up_prod_floats, gance::winogemm_prod_floats(samples, c.cout, 2 * H, 2 * H));
         }
+    }
+    // the split input image of the up layers that can take the role-split form (whatever this engine's knobs say: the workspace is shared)
+    for (int i = 0; i < nconv; ++i) {
+        const ConvLayerHost& c = e->convs[i];
+        const int H = (1 << c.res_log2) / 2;
+        if (c.up && gance::upfirr_supported(c.cin, c.cout, H, H)) e->x_units_bytes = std::max(e->x_units_bytes, gance::upfirr_units_bytes(Bmax, c.cin, H, H));
     }
     e->y_floats = (size_t)3 * config->resolution * config->resolution * Bmax;
     // partial ToRGB images of the Winograd conv launches whose pixels span several channel tiles: [Cout / 64][Bmax][3][R][R]

@@ -199,6 +199,7 @@ struct UpFirArgs {
     const float* s_next;
     int input_prescaled;  // x arrives multiplied by this layer's own style (its producer was given s_next): no style scale in the K loop
     int pair_form;        // upfir16 only: w is the pair-form image (upfir16x_arrange_weights): F(2,2) along x, 15 MFMAs per pair of columns instead of 18
+    const void* x_units;  // upfir_split_roles only: x times the layer's style, split into bf16 parts (launch_upfirr_split_activation's image)
 };
 bool upfir_supported(int cin, int cout, int H, int W);
 size_t upfir_weight_floats(int cin, int cout);
@@ -225,6 +226,17 @@ size_t upfirs_weight_floats(int cin, int cout);
 void upfirs_arrange_weights(const float* w_in /*[9][cin][cout] scaled*/, int cin, int cout, const int* up_tap_weight, float* w_out);
 void upfirs_plan(int B, int cout, int H, int W, int num_cus, UpFirArgs* args);
 hipError_t launch_upfir_split(const UpFirArgs& args, hipStream_t stream);
+
+// The split-operand form with the work of a block in two roles (upfir_split_roles.hip): four matrix waves (MFMAs only) and four
+// vector waves (staging, split, FIR epilogue of the step before) per block, two waves per SIMD, 4 position rows per step. Same
+// weight image as upfir_split.hip (upfirs_arrange_weights); the plan sets step_rows = 4.
+bool upfirr_supported(int cin, int cout, int H, int W);
+void upfirr_plan(int B, int cout, int H, int W, int num_cus, UpFirArgs* args);
+hipError_t launch_upfir_split_roles(const UpFirArgs& args, hipStream_t stream);
+// ... and its input image: x (times the style s, or s == nullptr) as three bf16 parts per value in 16-byte units of 8 channels,
+// [B][Cin / 32][H + 2][part * 4 + k-group][W + 8]: upfirr_units_bytes(B, Cin, H, W) bytes
+size_t upfirr_units_bytes(int B, int cin, int H, int W);
+hipError_t launch_upfirr_split_activation(const float* x, long long x_b_stride, const float* s, int s_stride, void* out, int B, int cin, int H, int W, hipStream_t stream);
 
 // The two smallest up layers (4x4 -> 8x8, 8x8 -> 16x16) in scatter form (gemm_forms.hip): pack (x * style -> the GEMM's B image),
 // ONE dense GEMM P[tap slot * Cout + co][b H W + position] (M = 9 Cout, K = Cin), gather (taps of a class, x demod) into the parity
