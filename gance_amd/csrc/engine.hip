@@ -210,6 +210,7 @@ struct gance_workspace {
     std::vector<float*> tplanes;  // per up layer: [4 cls][max_units][cout][H+3][W+8] (else nullptr)
     float* slabs = nullptr;       // split-K scratch of the small stride-1 convs (dense)
     void* x_units = nullptr;  // an up layer's input split into bf16 parts (upfir_split_roles.hip: launch_upfirr_split_activation)
+    size_t x_units_bytes = 0;
     float *up_packed = nullptr, *up_prod = nullptr;  // the GEMM forms' operand images and products (gemm_forms.hip: scatter-form up layers, Winograd at 8x8 / 16x16)
     float* ybuf[2] = {nullptr, nullptr};
     float* rgb_coef = nullptr;  // [Bmax][8 m tiles][16][64]: A operands of a ToRGB product fused into a Winograd conv epilogue
@@ -292,7 +293,7 @@ struct gance_engine {
     std::vector<size_t> upfir16x_w;  // ... and for that geometry's pair form (F(2,2) along x: 15 MFMAs per pair of columns instead of 18)
     std::vector<size_t> upfirs_w;    // split-operand form of the fused up kernel (upfir_split.hip: three bf16 parts per value, six terms, fp32 accumulation)
     int upfir_split = 1;  // GANCE_TUNE_UPFIR_SPLIT when the engine is created: 0 never, 1 (default) where a launch fills the chip without row segments, 2 wherever supported
-    int upfir_split_roles = 1;  // GANCE_TUNE_UPFIR_SPLIT_ROLES: 1 (default) the split form with matrix and vector waves (upfir_split_roles.hip), 0 the one-role kernel (upfir_split.hip)
+    int upfir_split_roles = 0;  // GANCE_TUNE_UPFIR_SPLIT_ROLES when the engine is created: 0 (default) the one-role kernel (upfir_split.hip); 1 the experiment with matrix and vector waves (upfir_split_roles.hip + a split pass over its input: slower than the one-role kernel once that pass is paid for)
     int upfir_split_max_res = 512;  // GANCE_TUNE_UPFIR_SPLIT_MAXRES: the largest OUTPUT side that takes the split form in mode 1 (measured: DESIGN.md section 3)
     int num_cus = 256;
     std::vector<float> conv_ns;
@@ -984,6 +985,8 @@ int acquire_workspace(gance_engine* e) {
         if (it != g_workspaces.end())
             if (auto alive = it->second.lock()) {
                 e->ws = alive;
+                // (a workspace made by an engine without the role-split experiment has no room for its input image: this engine goes without it too)
+                if (e->x_units_bytes > alive->x_units_bytes) e->upfir_split_roles = 0;
                 return GANCE_OK;
             }
     }
@@ -1020,6 +1023,7 @@ int acquire_workspace(gance_engine* e) {
             ok = alloc((void**)&ws->tplanes[i], (size_t)4 * e->t_units[i] * c.cout * t_plane((1 << c.res_log2) / 2) * sizeof(float), true);
     }
     ok = ok && alloc((void**)&ws->x_units, std::max<size_t>(16, e->x_units_bytes), false);
+    ws->x_units_bytes = e->x_units_bytes;
     ok = ok && alloc((void**)&ws->up_packed, std::max<size_t>(1, e->up_packed_floats) * sizeof(float), false) &&
          alloc((void**)&ws->up_prod, std::max<size_t>(1, e->up_prod_floats) * sizeof(float), false);
     ok = ok && alloc((void**)&ws->slabs, e->slab_floats * sizeof(float), false) &&
@@ -1384,7 +1388,7 @@ int gance_engine_create(const gance_engine_config* config, const float* host_wei
     for (int i = 0; i < nconv; ++i) {
         const ConvLayerHost& c = e->convs[i];
         const int H = (1 << c.res_log2) / 2;
-        if (c.up && gance::upfirr_supported(c.cin, c.cout, H, H)) e->x_units_bytes = std::max(e->x_units_bytes, gance::upfirr_units_bytes(Bmax, c.cin, H, H));
+        if (c.up && e->upfir_split_roles != 0 && gance::upfirr_supported(c.cin, c.cout, H, H)) e->x_units_bytes = std::max(e->x_units_bytes, gance::upfirr_units_bytes(Bmax, c.cin, H, H));
     }
     e->y_floats = (size_t)3 * config->resolution * config->resolution * Bmax;
     // partial ToRGB images of the Winograd conv launches whose pixels span several channel tiles: [Cout / 64][Bmax][3][R][R]

@@ -239,6 +239,18 @@ __device__ __forceinline__ void upfirr_body(const UpFirArgs& p) {
             const int off = ((2 * kTH * fs - 2 + 2 * wave + (nl >> 5)) * (2 * W) + 2 * X0 + 4 * (nl & 31)) * 4;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(nz_rsrc, (lds_ptr_t)(nz_lds + wave * 256), 16, off, 0, 0, 0);
         };
+        // The next chunk's weight fragments: 27 pieces of 1 KB ([tap][part][lane]) by LDS-DMA, seven (six) per matrix wave, issued in row 0 of a
+        // chunk (18 MFMAs: the row with time to spare; the buffer was read in row 4 of the chunk before) and landed before the barrier of row 3.
+        // On the vector waves they shared the in-order vmcnt queue with ten rows of staging loads and the output stores: 62 of its 63 slots at
+        // 512 -> 1024, and a wait for them was a wait for the stores in front of them.
+        auto weights_dma = [&](int chunk) {
+            int wl;
+            asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(wl));
+#pragma unroll
+            for (int k = 0; k < 7; ++k)
+                if (k < 6 || wave < 3)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, (lds_ptr_t)(w_lds + (wave + 4 * k) * 64), 16, wl * 16, (chunk * 27 + wave + 4 * k) * 1024, 0, 0);
+        };
         u32x4 Bf[2][2][3];
         auto load_b = [&](int slot, u32x4(&dst)[2][3]) {
 #pragma unroll
@@ -269,10 +281,11 @@ __device__ __forceinline__ void upfirr_body(const UpFirArgs& p) {
             u32x4 hf[3];  // fragments of this wave's next halo tap
             auto run_chunk = [&](auto parity, const int chunk) {
                 constexpr int ab = decltype(parity)::value;
-                (void)chunk;
+                const int n_chunk = chunk + 1 < chunks ? chunk + 1 : 0;
 #pragma unroll
                 for (int j = 0; j < kRows; ++j) {
                     if (kNoise && ab == 0 && j == 0 && chunk == 0 && si > 0) noise_dma(si - 1);
+                    if (j == 0 && !(GANCE_UPFIRR_ABLATE & 32)) weights_dma(n_chunk);
                     // Row j of this chunk: its fragments are in Bf[cur]; row j + 1 is in the ring (written before the last barrier): read them now
                     const int cur = (j + ab) & 1;
                     if (j + 1 < kRows) load_b(cur ^ 1, Bf[cur ^ 1]);
@@ -337,6 +350,7 @@ __device__ __forceinline__ void upfirr_body(const UpFirArgs& p) {
                         load_b(cur ^ 1, Bf[cur ^ 1]);
                     }
                     if (kNoise && ab == 0 && j == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the noise: the first FIR slice runs in period 2)
+                    if (j == 3) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                          // (the weight fragments: read in row 4)
                     lds_barrier();
                 }
             };
@@ -420,18 +434,6 @@ __device__ __forceinline__ void upfirr_body(const UpFirArgs& p) {
     const int h_plane = h_task % kPlanes, h_col = (h_task / kPlanes) & 3, h_row = h_task / (kPlanes * kHaloCols);
     const int h_colunits = X0 + 2 + (h_col & 1) + (h_col >> 1) * 65;  // bordered columns of X0 - 2, X0 - 1, X0 + 63, X0 + 64
     u32x4* const halo_w = halo + h_task;
-    // the next chunk's weight fragments: 27 pieces of 1 KB ([tap][part][lane]) by LDS-DMA, no registers: issued in row 0 (the matrix waves
-    // read the buffer in row 4 of the chunk before), landed before the barrier of row 3 (weights_wait)
-    typedef __attribute__((address_space(3))) void* lds_ptr_t;
-    auto weights_dma = [&](int chunk) {
-#pragma unroll
-        for (int k = 0; k < 7; ++k)
-            if (k < 6 || v < 3)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, (lds_ptr_t)(w_lds + (v + 4 * k) * 64), 16, lane * 16, (chunk * 27 + v + 4 * k) * 1024, 0, 0);
-    };
-    // vmcnt counts in issue order: behind the pieces this wave has issued at least the 13 loads of rows 0 .. 3 (3 per row + the halo
-    // unit; the stores of a FIR pass may or may not be there), so "all but the youngest 13" covers the pieces
-    auto weights_wait = [&]() { asm volatile("s_waitcnt vmcnt(13)" ::: "memory"); };
     u32x4 hreg;
     auto halo_load = [&](int step, int chunk) {
         const int brow = min(kTH * step + h_row, H + 1);
@@ -560,10 +562,15 @@ __device__ __forceinline__ void upfirr_body(const UpFirArgs& p) {
                 // it into the slot row j left; row j + 12: issue its loads into the same registers. A FIR pass that is due reads its window
                 // first and computes last, the copies under its LDS latency.
                 const int slot = (j + ab) & 1;
-                if (j == 0 && !(GANCE_UPFIRR_ABLATE & 32)) weights_dma(c1);
+                // A slice's window rows are read into registers right behind the slice BEFORE it (the first one's in period 0, behind the dump's
+                // barrier): a vector wave is alone on its SIMD's issue port for vector work, an LDS round trip it waits for is lost time.
                 const int period = kRows * chunk + j;
-                const bool slice_now = slice < kSlices && 2 + ((slice * slice_span) >> 4) <= period;
-                if (slice_now) slice_reads(slice >> 2, slice & 3);
+                if (ab == 0 && j == 0 && chunk == 0 && slice < kSlices) slice_reads(0, 0);
+                if (slice < kSlices && 2 + ((slice * slice_span) >> 4) <= period) {
+                    slice_compute(slice >> 2, slice & 3, si - 1);
+                    ++slice;
+                    if (slice < kSlices) slice_reads(slice >> 2, slice & 3);
+                }
                 const bool here = j + 2 < kRows;   // row j + 2 is a row of this chunk
                 const bool here3 = j + 3 < kRows;  // ... and row j + 3
                 stage_store(st[(kRows * ab + j + 2) % kDepth], slot);
@@ -575,16 +582,11 @@ __device__ __forceinline__ void upfirr_body(const UpFirArgs& p) {
                     if (!(GANCE_UPFIRR_ABLATE & 512)) halo_load(s2, c2);
                 }
                 stage_load(st[(kRows * ab + j + 2) % kDepth], here ? c2 : c3, here ? s2 : s3, (j + 2) % kRows, true);
-                if (slice_now) {
+                if (slice < kSlices && 2 + ((slice * slice_span) >> 4) <= period) {  // (two chunks per step: a second one)
                     slice_compute(slice >> 2, slice & 3, si - 1);
                     ++slice;
-                    if (slice < kSlices && 2 + ((slice * slice_span) >> 4) <= period) {  // (two chunks per step: a second one)
-                        slice_reads(slice >> 2, slice & 3);
-                        slice_compute(slice >> 2, slice & 3, si - 1);
-                        ++slice;
-                    }
+                    if (slice < kSlices) slice_reads(slice >> 2, slice & 3);
                 }
-                if (j == 3 && !(GANCE_UPFIRR_ABLATE & 32)) weights_wait();
                 lds_barrier();
             }
         };
@@ -597,10 +599,11 @@ __device__ __forceinline__ void upfirr_body(const UpFirArgs& p) {
     }
     // the last step's slices (position row y' = H), beside nothing
     lds_barrier();  // (its noise: the matrix waves' last act)
+    slice_reads(0, 0);
 #pragma unroll 1
     for (int sl = 0; sl < kSlices; ++sl) {
-        slice_reads(sl >> 2, sl & 3);
         slice_compute(sl >> 2, sl & 3, steps - 1);
+        if (sl + 1 < kSlices) slice_reads((sl + 1) >> 2, (sl + 1) & 3);
     }
 }
 

@@ -59,6 +59,18 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
 constexpr int kKC = 4;                         // input channels per chunk = one k-step of the 16x16x4 MFMA
+// LDS banks of the window reads (experiment of round 5, OFF: GANCE_W43_ODD_SHIFT = 2 and GANCE_W43_WINDOW = 3, Makefile target
+// ../libgance_hip_w43banks.so). A lane group of an 8-byte read is 32 lanes = the sixteen tiles of TWO input-channel planes; bank =
+// (address / 4) mod 64. Tiles are 4 floats apart, planes and rows multiples of 4: every lane of both planes reads the same two residues
+// mod 4, two lanes per bank; the dword reads of columns 3 / 8 (32 banks) put four lanes on a bank. With the odd planes two floats to
+// the right (their DMA pieces from 8 bytes further left) and columns 3 / 8 read as halves of 8-byte pairs every window read is
+// conflict-free by that model. Measured: SQ_LDS_BANK_CONFLICT 5.0e8 -> 4.0e8 per launch (the rest is not in the window reads), run
+// time +2 ... 3 % (3.57 / 3.62 / 3.91 / 4.53 / 5.45 -> 3.68 / 3.73 / 4.01 / 4.63 / 5.47 ms per 64 frames; either half alone: +1 ... 2 %):
+// the LDS array is 31 % busy in this kernel; its conflicts are not what the waves wait for.
+#ifndef GANCE_W43_ODD_SHIFT
+#define GANCE_W43_ODD_SHIFT 0
+#endif
+constexpr int kOddShift = GANCE_W43_ODD_SHIFT;
 constexpr int kBM = 32;                        // output channels per block (2 channel tiles of 16)
 constexpr int kUnit = 16 * 36;                 // a (channel tile, ci) unit of weights: [co % 16][36]: a lane's 36 weights are nine aligned float4
 constexpr int kWPieces = 18;                   // 8 units = 4608 floats = 18 pieces of 256 floats
@@ -234,10 +246,12 @@ __device__ __forceinline__ void winograd43_body(const ConvArgs& p) {
                 const int q4 = f % (kPW / 4);
                 const int row = (f / (kPW / 4)) % kPH;
                 const int c = f / (kPW / 4 * kPH);
-                piece_voff[r] = ((c * Hp + row) * Wp + 4 * q4) * 4;
+                // (odd planes sit TWO FLOATS to the right in LDS -- kOddShift: their 16-byte pieces come from 8 bytes further left; the two
+                // floats in front of a row's first piece are the row above's last ones: never read)
+                piece_voff[r] = ((c * Hp + row) * Wp + 4 * q4 - kOddShift * (c & 1)) * 4;
             }
         }
-        win_off = kWFloats + g * kPlane + 4 * (pg * kTR + n16 / kTC) * kPW + 4 * (n16 % kTC);
+        win_off = kWFloats + g * kPlane + 4 * (pg * kTR + n16 / kTC) * kPW + 4 * (n16 % kTC) + kOddShift * (g & 1);
         a_off = (cot * 4 + g) * kUnit + n16 * 36;
     };
     lane_setup();
@@ -350,8 +364,14 @@ __device__ __forceinline__ void winograd43_body(const ConvArgs& p) {
 #else
             c45[y] = *reinterpret_cast<const f32x2*>(P + y * kPW + 4);
             c67[y] = *reinterpret_cast<const f32x2*>(P + y * kPW + 6);
+#if GANCE_W43_WINDOW == 3
+            // (experiment: columns 3 and 8 as the halves of two 8-byte reads -- see kOddShift)
+            c38[y][0] = (*reinterpret_cast<const f32x2*>(P + y * kPW + 2))[1];
+            c38[y][1] = (*reinterpret_cast<const f32x2*>(P + y * kPW + 8))[0];
+#else
             c38[y][0] = P[y * kPW + 3];
             c38[y][1] = P[y * kPW + 8];
+#endif
 #endif
         }
 #if GANCE_W43_ABLATE & 4

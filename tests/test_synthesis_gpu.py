@@ -216,10 +216,19 @@ def test_fused_upsampling_layer_matches_oracle_layerwise(library, resolution: in
 
 
 @pytest.mark.parametrize(
-    "resolution,batch,noise,conv_form",
-    [(128, 3, True, "auto"), (256, 2, True, "winograd43"), (256, 3, False, "winograd43"), (256, 2, True, "direct"), (512, 1, True, "winograd43")],
+    "resolution,batch,noise,conv_form,roles",
+    [
+        (128, 3, True, "auto", 0),
+        (256, 2, True, "winograd43", 0),
+        (256, 3, False, "winograd43", 0),
+        (256, 2, True, "direct", 0),
+        (512, 1, True, "winograd43", 0),
+        (256, 2, True, "winograd43", 1),
+        (256, 3, False, "direct", 1),
+        (512, 1, True, "winograd43", 1),
+    ],
 )
-def test_split_operand_up_layers_match_oracle_layerwise(library, resolution: int, batch: int, noise: bool, conv_form: str, monkeypatch) -> None:
+def test_split_operand_up_layers_match_oracle_layerwise(library, resolution: int, batch: int, noise: bool, conv_form: str, roles: int, monkeypatch) -> None:
     """
     Conv0_up with its K loop on the bf16 matrix cores from SPLIT operands (upfir_split.hip: every fp32 value as three bf16
     parts, the six largest part products, fp32 accumulation), forced at a small batch (GANCE_TUNE_UPFIR_SPLIT=2; the default takes
@@ -227,14 +236,18 @@ def test_split_operand_up_layers_match_oracle_layerwise(library, resolution: int
     oracle, every term on. Inputs 64 ... 256 wide: one, two and four strips (recomputed halo columns from the per-chunk side
     buffer), 2 ... 16 chunks of 32 input channels, pre-scaled input ("winograd43": the F(4x4,3x3) launch before it folds the style
     into its stores) and plain input (the style multiplied in while staging), with and without noise.
+    `roles` 1: the experiment GANCE_TUNE_UPFIR_SPLIT_ROLES (upfir_split_roles.hip: the same products with a block's work in two wave
+    roles -- matrix waves and vector waves -- behind a pass that splits the layer's input; launch names end in "/s3r"), same bar.
     """
     monkeypatch.setenv("GANCE_TUNE_UPFIR_SPLIT", "2")  # (read when the engine is created)
+    monkeypatch.setenv("GANCE_TUNE_UPFIR_SPLIT_ROLES", str(roles))
     spec = sg2_spec.make_spec(resolution)
     variables = sg2_spec.make_random_variables(resolution, seed=3, perturb=True)
     if not noise:
         variables = {name: (np.zeros_like(value) if name.endswith("/noise_strength") else value) for name, value in variables.items()}
     dlatents = np.random.RandomState(5).randn(batch, spec.num_layers, 512).astype(np.float32)
-    engine = hip_lib.Engine(variables, resolution, max_batch=batch, up_form="fused", conv_form=conv_form, profile=True)
+    # (the experiment's input image lives in the workspace: an engine that joined a workspace made without it would go without it too)
+    engine = hip_lib.Engine(variables, resolution, max_batch=batch, up_form="fused", conv_form=conv_form, profile=True, private_workspace=bool(roles))
 
     def layers_of_the_oracle():
         collected: list = []
@@ -242,7 +255,7 @@ def test_split_operand_up_layers_match_oracle_layerwise(library, resolution: int
             ref.g_synthesis(torch.from_numpy(dlatents).double(), variables, resolution, collect=collected)
         return collected
 
-    wants = _oracle_once(("split_up_layerwise", resolution, batch, noise), layers_of_the_oracle)
+    wants = _oracle_once(("split_up_layerwise", resolution, batch, noise), layers_of_the_oracle)  # (shared by the two kernels: same seeds)
     try:
         worst = 0.0
         for n, conv in enumerate(spec.convs, start=1):
@@ -254,7 +267,7 @@ def test_split_operand_up_layers_match_oracle_layerwise(library, resolution: int
             worst = max(worst, rel)
             assert rel < 2e-5, f"conv layer {n} ({conv.scope}): rel err {rel}"
         engine.synthesize_w(dlatents)
-        split = [step.name for step in engine.steps() if step.name.endswith(("/s3", "/s3r"))]
+        split = [step.name for step in engine.steps() if step.name.endswith("/s3r" if roles else "/s3")]
         assert len(split) == int(np.log2(resolution)) - 6, split  # every up layer whose input is >= 64 wide
         print(f"\nsplit-operand up layers at {resolution}^2, batch {batch}: worst layer {worst:.2e} of its range")
     finally:
