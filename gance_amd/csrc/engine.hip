@@ -294,7 +294,7 @@ struct gance_engine {
     std::vector<size_t> upfirs_w;    // split-operand form of the fused up kernel (upfir_split.hip: three bf16 parts per value, six terms, fp32 accumulation)
     int upfir_split = 1;  // GANCE_TUNE_UPFIR_SPLIT when the engine is created: 0 never, 1 (default) where a launch fills the chip without row segments, 2 wherever supported
     int upfir_split_roles = 0;  // GANCE_TUNE_UPFIR_SPLIT_ROLES when the engine is created: 0 (default) the one-role kernel (upfir_split.hip); 1 the experiment with matrix and vector waves (upfir_split_roles.hip + a split pass over its input: slower than the one-role kernel once that pass is paid for)
-    int upfir_split_max_res = 512;  // GANCE_TUNE_UPFIR_SPLIT_MAXRES: the largest OUTPUT side that takes the split form in mode 1 (measured: DESIGN.md section 3)
+    int upfir_split_max_res = 1024;  // GANCE_TUNE_UPFIR_SPLIT_MAXRES: the largest OUTPUT side that takes the split form in mode 1 (measured: DESIGN.md section 3; 512 until the staging went to 16-byte loads)
     int num_cus = 256;
     std::vector<float> conv_ns;
     std::vector<int> conv_s_off, conv_d_off;

@@ -102,8 +102,10 @@ static_assert((2 * kRows) % kDepth == 0 && kDepth + 2 < kRows && kRows % kRing =
 // LDS (bytes): ring | halo side buffers (two chunks) | T window of a pass | the step's noise | carry | style [Cin] | demod | bias | next style
 constexpr size_t kRingBytes = (size_t)kRing * kSlotUnits * 16;
 constexpr size_t kHaloBytes = (size_t)2 * kHaloUnits * 16;
+constexpr int kWUnits = 27 * 64;  // 16-byte units of a chunk's weight fragments: [tap][part][lane]
+constexpr size_t kWBytes = (size_t)kWUnits * 16;
 constexpr size_t lds_bytes(int cin) {
-    return kRingBytes + kHaloBytes + sizeof(float) * ((size_t)kStageFloats + kNzPieces * 256 + kCarryFloats + cin + 3 * kBM);
+    return kRingBytes + kHaloBytes + kWBytes + sizeof(float) * ((size_t)kStageFloats + kNzPieces * 256 + kCarryFloats + cin + 3 * kBM);
 }
 
 // transposed-conv tap tables, in the order the weights are stored (engine.hip kUpTapWeight):
@@ -123,6 +125,18 @@ __device__ __forceinline__ int fresh_lane() {
     asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
     return l;
 }
+
+// Ring column of position P = x - X0 (0 .. 63); column 64 holds x = X0 - 1. Staging is two 16-byte loads per lane (4 columns x 2 channels:
+// a wave may have 63 vector-memory operations outstanding, and with dword loads -- 256 bytes per instruction, six rows of eight in flight
+// beside the 27 weight loads -- the K loop was bound by that window, round 5), split, then a 4 x 4 transpose over the four lane rows
+// (v_permlane32_swap, v_permlane16_swap): lane (row r, column group g) ends up with the units of position 4 g + r. Eight neighbouring
+// lanes then write positions 4 apart, sixteen lanes of a fragment read 16 neighbouring positions. Bits of the column: c0 = P2, c1 = P3,
+// c2 = P4 ^ P0, c3 = P1, c4 = P0, c5 = P5 -- c[2:0] runs through all 8 bank quads over P[4:2] (the 8 lanes of a ds_write_b128 group) and
+// c[3:0] through all 16 over P[3:0] (the 16 lanes of a ds_read_b128 group): both conflict-free.
+__device__ __forceinline__ int ring_column(int P) {
+    return ((P >> 2) & 3) | ((((P >> 4) ^ P) & 1) << 2) | (((P >> 1) & 1) << 3) | ((P & 1) << 4) | (P & 32);
+}
+constexpr int kEdgeColumn = 64;
 
 // two neighbouring channels of one position -> their three bf16 parts, packed (a in the low half): round to nearest even each
 // time, the residuals exact in fp32 (Sterbenz: a part and what it was rounded from agree in their leading bits)
@@ -156,7 +170,8 @@ __device__ __forceinline__ void upfirs_body(const UpFirArgs& p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     u32x4* const ring = reinterpret_cast<u32x4*>(smem_raw);
     u32x4* const halo = ring + kRing * kSlotUnits;
-    float* const stage = reinterpret_cast<float*>(halo + 2 * kHaloUnits);  // [4 ch][8 rows][kTW]
+    u32x4* const w_lds = halo + 2 * kHaloUnits;                            // [tap][part][lane]: the weight fragments of the chunk after the one being multiplied
+    float* const stage = reinterpret_cast<float*>(w_lds + kWUnits);        // [4 ch][8 rows][kTW]
     float* const nz_lds = stage + kStageFloats;                            // [16 output rows][2 kSW]
     float* const carry = nz_lds + kNzPieces * 256;                         // [16 ch][3 rows][kTW]
     float* const s_lds = carry + kCarryFloats;                             // style [Cin] (absent when the input is pre-scaled)
@@ -198,25 +213,53 @@ __device__ __forceinline__ void upfirs_body(const UpFirArgs& p) {
     // so the row it loads is row (j + 2 + kDepth) % 9 of the consumer's chunk or of the chunk after it: known where the load is written ----
     // per-lane LDS bases: everything that changes with the row, the chunk parity or the part is a compile-time offset from one of them
     // (the instruction's immediate): per-row address registers would not fit beside 144 accumulators and 108 weight registers
-    u32x4* const ring_w = ring + wave * kPlaneStride + lane + 1;                  // staging write: k-group = wave, ring column = x - X0 + 1
-    const u32x4* const ring_r = ring + kg * kPlaneStride + 16 * wave + n16;       // fragment read of position column 16 wave + n16, dx = -1 (+ 1: dx = 0)
+    const int st_pair = lane >> 4, st_g = lane & 15;                              // staging task: channel pair 4 wave + st_pair, columns X0 + 4 st_g .. + 3
+    u32x4* const ring_w = ring + wave * kPlaneStride + ring_column(4 * st_g + st_pair);  // ... after the transpose: the units of position 4 st_g + st_pair, k-group = wave
+    // fragment reads of position 16 wave + n16 (dx = 0) and of the position to its left (dx = -1; left of the strip: the edge column)
+    const int m_pos = 16 * wave + n16;
+    const u32x4* const ring_r0 = ring + kg * kPlaneStride + ring_column(m_pos);
+    const u32x4* const ring_r1 = ring + kg * kPlaneStride + (m_pos > 0 ? ring_column(m_pos - 1) : kEdgeColumn);
     // column X0 - 1 of a ring row (the dx = -1 fragment of the strip's first lane) is not a main staging task (64 lanes = 64 columns):
     // twelve lanes of wave 3 copy its units (lane = part * 4 + k-group) from the halo side buffer of the row's chunk; every other lane
     // copies the same unit into the padding of its plane row (columns 65 .. 79 are never read): no branch in the row's instruction stream
     const bool edge_copy = wave == 3 && lane < kPlanes;
     const int e_unit = lane % kPlanes;
-    u32x4* const ring_e = ring + (e_unit >> 2) * 4 * kPlaneStride + (e_unit & 3) * kPlaneStride + (edge_copy ? 0 : 66 + wave);
+    u32x4* const ring_e = ring + (e_unit >> 2) * 4 * kPlaneStride + (e_unit & 3) * kPlaneStride + (edge_copy ? kEdgeColumn : 66 + wave);
     const u32x4* const halo_e = halo + e_unit;                                    // ... from unit [row][column 1][part * 4 + k-group]
     const u32x4* const halo_r = halo + ((n16 & 7) * kHaloCols + 2 * (n16 >> 3)) * kPlanes + kg;  // halo tile slot n16 = (side, position row)
     const u32x4* const halo_f = halo + ((kRows - 1) * kHaloCols + 2 * (n16 >> 3)) * kPlanes + kg;  // ... of position row y' = H: the chunk's last row
     // main staging task of this lane: column X0 + lane, k-group = wave: eight dword loads (buffer row `brow` of the bordered tensor)
-    const int st_voff = (X0 + 4 + lane) * 4;
+    const int st_voff = (2 * st_pair * Hp * Wp + X0 + 4 + 4 * st_g) * 4;
     unsigned st[kDepth][8];
     auto stage_load = [&](unsigned(&dst)[8], int chunk, int brow, bool in_loop = false) {
         if ((GANCE_UPFIRS_ABLATE & 4) && in_loop) return;
         const int soff = ((chunk * kKC + wave * 8) * Hp + brow) * Wp * 4;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) dst[e] = __builtin_amdgcn_raw_buffer_load_b32(x_rsrc, st_voff, soff + e * HpWp4, 0);
+        for (int e = 0; e < 2; ++e) {
+            const u32x4 q4 = __builtin_amdgcn_raw_buffer_load_b128(x_rsrc, st_voff, soff + e * HpWp4, 0);  // channel 2 pair + e, four columns
+#pragma unroll
+            for (int c = 0; c < 4; ++c) dst[2 * c + e] = q4[c];  // (dst[2 c], dst[2 c + 1]: the pair at column c)
+        }
+    };
+    // the main tasks hold two channels at four positions (the halo tasks eight channels of one position: scale8)
+    auto scale_pair = [&](unsigned(&raw)[8], int chunk) {
+        if constexpr (!kPre) {
+            const f32x2 s2 = *reinterpret_cast<const f32x2*>(s_lds + chunk * kKC + 8 * wave + 2 * st_pair);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                raw[2 * c] = __builtin_bit_cast(unsigned, __builtin_bit_cast(float, raw[2 * c]) * s2[0]);
+                raw[2 * c + 1] = __builtin_bit_cast(unsigned, __builtin_bit_cast(float, raw[2 * c + 1]) * s2[1]);
+            }
+        }
+    };
+    // 4 x 4 transpose over the four lane rows (16 lanes each): register c of row r (channel pair r, position c of the lane's four) becomes
+    // register i of row r = what register r of row i was (pair i, position r)
+    auto transpose_rows = [](u32x4& u) {
+        auto a02 = __builtin_amdgcn_permlane32_swap(u[0], u[2], false, false);
+        auto a13 = __builtin_amdgcn_permlane32_swap(u[1], u[3], false, false);
+        auto b01 = __builtin_amdgcn_permlane16_swap(a02[0], a13[0], false, false);
+        auto b23 = __builtin_amdgcn_permlane16_swap(a02[1], a13[1], false, false);
+        u = u32x4{b01[0], b01[1], b23[0], b23[1]};
     };
     // (style of the channels this lane stages: the consumer's chunk is known where the write happens)
     auto scale8 = [&](unsigned(&raw)[8], int chunk, int group) {
@@ -231,9 +274,11 @@ __device__ __forceinline__ void upfirs_body(const UpFirArgs& p) {
         }
     };
     auto stage_store = [&](unsigned(&raw)[8], int slot, int chunk) {
-        scale8(raw, chunk, wave);
+        scale_pair(raw, chunk);
         u32x4 part[3];
         split_unit(raw, part);
+#pragma unroll
+        for (int q = 0; q < 3; ++q) transpose_rows(part[q]);
 #pragma unroll
         for (int q = 0; q < 3; ++q)
             if (!(GANCE_UPFIRS_ABLATE & 16)) ring_w[slot * kSlotUnits + q * 4 * kPlaneStride] = part[q];
@@ -265,6 +310,22 @@ __device__ __forceinline__ void upfirs_body(const UpFirArgs& p) {
     // needs the dy = -1 taps, which that row handles first, and the image is hot in L2 (every block of the layer reads it) ----
     u32x4 A[9][3];
     const int a_voff = lane * 16;
+    // The fragments of the NEXT chunk come through LDS (round 5): the four waves hold the same 27 KB, and four copies per chunk through the
+    // CU's vector-memory path were a quarter of its traffic and 27 of the 63 operations a wave may have outstanding. Each wave fetches seven
+    // (six) pieces by LDS-DMA in row 0 of a chunk (the buffer was read in the last row of the chunk before); they are older than every
+    // staging load that is still in flight when the last row needs them, so the counted wait for them (in front of row 7's barrier: all
+    // but the youngest 24 operations = row 0's halo loads and rows 0 .. 7's staging loads) waits for nothing else.
+    auto weights_dma = [&](int chunk) {
+#pragma unroll
+        for (int k = 0; k < 7; ++k)
+            if (k < 6 || wave < 3)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, (lds_ptr_t)(w_lds + (wave + 4 * k) * 64), 16, lane * 16, (chunk * 27 + wave + 4 * k) * 1024, 0, 0);
+    };
+    const u32x4* const w_r = w_lds + lane;
+    auto read_a3 = [&](int t, u32x4(&dst)[3]) {
+#pragma unroll
+        for (int q = 0; q < 3; ++q) dst[q] = w_r[(t * 3 + q) * 64];
+    };
     auto load_a3 = [&](int chunk, int t, u32x4(&dst)[3]) {
 #pragma unroll
         for (int q = 0; q < 3; ++q) dst[q] = __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, a_voff, (chunk * 27 + t * 3 + q) * 1024, 0);
@@ -275,8 +336,8 @@ __device__ __forceinline__ void upfirs_body(const UpFirArgs& p) {
     auto load_b = [&](int slot, u32x4(&dst)[2][3]) {
 #pragma unroll
         for (int q = 0; q < 3; ++q) {
-            dst[0][q] = ring_r[slot * kSlotUnits + q * 4 * kPlaneStride + 1];
-            dst[1][q] = ring_r[slot * kSlotUnits + q * 4 * kPlaneStride];
+            dst[0][q] = ring_r0[slot * kSlotUnits + q * 4 * kPlaneStride];
+            dst[1][q] = ring_r1[slot * kSlotUnits + q * 4 * kPlaneStride];
         }
     };
 
@@ -343,6 +404,7 @@ __device__ __forceinline__ void upfirs_body(const UpFirArgs& p) {
                 // row j + 5: issue its loads into the registers that row j + 2 leaves. (9 rows per chunk is odd: the fragment buffers
                 // alternate by j + chunk parity; the chunk loop is unrolled by two and a step has an even number of chunks)
                 const int cur = (j + ab) & 1;
+                if (j == 0) weights_dma(n_chunk);
                 if (j == 0) halo_load(n_step, n_chunk);
                 if (j == 4) halo_store(n_chunk, ab ^ 1);
                 load_b((j + 1) % kRing, Bf[cur ^ 1]);
@@ -411,9 +473,10 @@ __device__ __forceinline__ void upfirs_body(const UpFirArgs& p) {
                                                                                     __builtin_bit_cast(bf16x8, hf[kTerms[term][0]]), acchf, 0, 0, 0);
                             }
                         }
-                        load_a3(n_chunk, t, A[t]);
+                        read_a3(t, A[t]);
                     }
                 }
+                if (j == kRows - 2) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");  // (the next chunk's weight fragments: see weights_dma)
                 if (!(GANCE_UPFIRS_ABLATE & 32)) lds_barrier();
             }
         };
