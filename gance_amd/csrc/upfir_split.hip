@@ -53,7 +53,7 @@
 
 // Timing ablations (wrong results; only in builds with -DGANCE_UPFIRS_ABLATE=<flags>, Makefile target ../libgance_hip_upfirsab<flags>.so, used
 // through GANCE_HIP_LIBRARY): 1 no split arithmetic (the raw values are written), 2 no epilogue, 4 no global loads of patch rows in the row
-// loop, 8 no MFMAs, 16 no LDS writes of staged rows, 32 no barrier per row, 64 no halo tile / edge copy
+// loop, 8 no MFMAs, 16 no LDS writes of staged rows, 32 no barrier per row, 64 no halo tile / edge copy, 128 no output stores
 #ifndef GANCE_UPFIRS_ABLATE
 #define GANCE_UPFIRS_ABLATE 0
 #endif
@@ -379,6 +379,8 @@ __device__ __forceinline__ void upfirs_body(const UpFirArgs& p) {
 
     // part products, smallest first: {x part, w part}
     constexpr int kTerms[6][2] = {{2, 0}, {0, 2}, {1, 1}, {1, 0}, {0, 1}, {0, 0}};
+    // the taps in an order whose neighbours accumulate into different tiles: (y'-1 EE) (y'-1 EO) (y'-1 OE) (y'-1 OO) (y' EE) (y' EO) (y'-1 EE) (y'-1 OE) (y' EE)
+    constexpr int kTapTurn[9] = {0, 4, 6, 8, 2, 5, 1, 7, 3};
 
 #pragma unroll 1
     for (int si = 0; si < steps; ++si) {
@@ -413,16 +415,23 @@ __device__ __forceinline__ void upfirs_body(const UpFirArgs& p) {
                 stage_store(st[(kRows * ab + j + 2) % kDepth], (j + 2) % kRing, j + 2 < kRows ? chunk : n_chunk);
                 stage_load(st[(kRows * ab + j + 2) % kDepth], j + 2 + kDepth < kRows ? chunk : n_chunk, kTH * (j + 2 + kDepth < kRows ? si : n_step) + (j + 2 + kDepth) % kRows, true);
                 if (j + 1 < kRows) {
+                    // Term by term ACROSS the taps, in an order that takes the row's six accumulators in turn: an MFMA that accumulates
+                    // into the result of the one before it waits for it -- v_mfma_f32_16x16x32_bf16 back to back on ONE accumulator runs at
+                    // 44 cycles per instruction, on two at 22, on four at 19, on 32 at 16.5 (tools/experiments/mfma_stream_peak.hip,
+                    // profiles/r05_mfma_stream_peak.txt). Written tap by tap until round 5's last day; hipcc's scheduler had been pulling
+                    // the chains apart by itself (no change in time), the source now says what is meant.
+                    // (per accumulator the terms still arrive smallest first)
 #pragma unroll
-                    for (int t = 0; t < 9; ++t) {
-                        const int row = tap_dy(t) ? j : j - 1;
-                        if (row < 0 || row >= kTH) continue;
+                    for (int term = 0; term < ((GANCE_UPFIRS_ABLATE & 8) ? 0 : 6); ++term)
 #pragma unroll
-                        for (int term = 0; term < ((GANCE_UPFIRS_ABLATE & 8) ? 0 : 6); ++term)
+                        for (int k = 0; k < 9; ++k) {
+                            const int t = kTapTurn[k];
+                            const int row = tap_dy(t) ? j : j - 1;
+                            if (row < 0 || row >= kTH) continue;
                             acc[row][tap_cls(t)] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
                                 __builtin_bit_cast(bf16x8, A[t][kTerms[term][1]]), __builtin_bit_cast(bf16x8, Bf[cur][tap_dx(t)][kTerms[term][0]]),
                                 acc[row][tap_cls(t)], 0, 0, 0);
-                    }
+                        }
                     // The row is ONE branch-free scheduling region: its MFMAs, and for the rows ahead six fragment reads, the edge copy, the
                     // split of a staged row (44 vector instructions, three LDS writes) and eight loads. A bf16 MFMA holds the vector issue
                     // for 8 of its 16 cycles: dealt out two per MFMA the other instructions ride in its shadow; in a clump in front of the
@@ -573,7 +582,8 @@ __device__ __forceinline__ void upfirs_body(const UpFirArgs& p) {
                                 if (kNoise) v += ns2 * *reinterpret_cast<const f32x4*>(nz_lds + (kPassRows * rw + rr) * (2 * kSW) + 4 * cg);
 #pragma unroll
                                 for (int o = 0; o < 4; ++o) v[o] = fmaf(lr6, v[o], lr4 * __builtin_fabsf(v[o]));
-                                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), o_rsrc, o_voff, o_soff + r * OWp * 4, 0);
+                                if (!(GANCE_UPFIRS_ABLATE & 128)) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), o_rsrc, o_voff, o_soff + r * OWp * 4, 0);
+                                else asm volatile("" ::"v"(v));
                             }
                         }
                     }

@@ -10,7 +10,7 @@ def short(name):
 # per resolution) are split by their launch order within a step: PMC_SPLIT="name:launches_per_step;..." (default below).
 import os
 SPLIT = dict(item.rsplit(":", 1) for item in os.environ.get(
-    "PMC_SPLIT", "upfir_fused_kernel:4;upfir_fused_pre_kernel:4;upfir16_fused_kernel:4;upfir16_fused_pre_kernel:4;upfir16x_fused_pre_kernel:4;upfir16x_fused_pre_noise_kernel:4;tile_gemm_kernel:4;winograd64_rgb_kernel:1;winograd43_rgb_kernel:5"
+    "PMC_SPLIT", "upfir_fused_kernel:4;upfir_fused_pre_kernel:4;upfir16_fused_kernel:4;upfir16_fused_pre_kernel:4;upfir16x_fused_pre_kernel:4;upfir16x_fused_pre_noise_kernel:4;upfirs_fused_pre_kernel:4;upfirs_fused_pre_noise_kernel:4;upfirs_fused_kernel:4;upfirr_fused_kernel:4;upfirr_fused_noise_kernel:4;tile_gemm_kernel:4;winograd64_rgb_kernel:1;winograd43_rgb_kernel:5"
 ).split(";") if item)
 seen = collections.Counter()
 rows = collections.defaultdict(lambda: collections.defaultdict(list))
