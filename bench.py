@@ -439,7 +439,7 @@ def batch_sweep(resolution: int, variables, device, batches, steps: int = 20, wa
             for info in launches:
                 if info.name.startswith("conv") and info.flops > 0:
                     kind, _, rest = info.name.partition("_")
-                    forms[rest.split("_")[0] + ("_up" if kind.startswith("convT") else "")] = kind + ("/16" + info.name.rsplit("/16", 1)[1] if "/16" in info.name else "")
+                    forms[rest.split("_")[0] + ("_up" if kind.startswith("convT") else "")] = kind + ("/" + info.name.rsplit("/", 1)[1] if "/" in info.name else "")  # (/16, /16x, /s3, /s3r)
             row = {
                 "frames_per_s": round(batch / (ms_per_call * 1e-3), 2), "ms_per_frame": round(ms_per_call / batch, 4), "ms_per_call": round(ms_per_call, 4),
                 "direct_form_frac_of_fp32_mfma_peak": round(

@@ -134,7 +134,19 @@ def test_config_f_1024_frame_matches_oracle(library) -> None:
     finally:
         engine.close()
     _assert_same_frames(frames2[0], frames[0])
-    _check_frames(frames, image, _oracle_once("plain_1024_first_z_of_seed_1", lambda: ref.synthesize_z(z, variables, resolution, truncation_psi=1.2)))
+    want64 = _oracle_once("plain_1024_first_z_of_seed_1", lambda: ref.synthesize_z(z, variables, resolution, truncation_psi=1.2))
+    _check_frames(frames, image, want64)
+    # The same frame against the oracle run in float32 -- the arithmetic the reference ran (TF1 on float32 tensors): uint8 values may differ
+    # by 1 LSB where a pixel lies within rounding of an integer boundary; the rates (python -m pytest -s prints them) go into DESIGN.md section 4.
+    want32 = ref.synthesize_z(z, variables, resolution, truncation_psi=1.2, dtype=torch.float32)
+    u8_64, u8_32 = ref.convert_images_to_uint8(want64), ref.convert_images_to_uint8(want32)
+    rate = lambda a, b: float((np.abs(a.astype(np.int16) - b.astype(np.int16)) > 0).mean())
+    assert int(np.abs(frames.astype(np.int16) - u8_32.astype(np.int16)).max()) <= 1 and rate(frames, u8_32) < 1e-3
+    print(
+        f"\nuint8 values that differ by 1 LSB at 1024^2 (one frame, {frames.size} values): HIP vs fp64 oracle {rate(frames, u8_64):.2e}, "
+        f"HIP vs fp32 oracle {rate(frames, u8_32):.2e}, fp32 oracle vs fp64 oracle {rate(u8_32, u8_64):.2e}; "
+        f"max |image - oracle| {float(np.abs(image - want64.numpy()).max()):.2e} (fp64), {float(np.abs(image - want32.numpy()).max()):.2e} (fp32)"
+    )
 
 
 def test_config_f_1024_with_every_eligible_layer_in_winograd_form(library) -> None:

@@ -31,7 +31,7 @@ for batch in range(1, max_batch + 1):
         kind, _, rest = step.name.partition("_")
         digits = "".join(ch for ch in kind if ch.isdigit())
         tag = f"{int(digits):2d} {rest.split('/')[0]}"  # (the name's "/16" / "/16x" suffix goes into the form)
-        form = kind.replace(digits, "", 1) + ("/16" + step.name.rsplit("/16", 1)[1] if "/16" in step.name else "")
+        form = kind.replace(digits, "", 1) + ("/" + step.name.rsplit("/", 1)[1] if "/" in step.name else "")  # (/16, /16x, /s3, /s3r)
         seen[tag] = form
         if tag not in table:
             table[tag] = {}
