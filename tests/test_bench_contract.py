@@ -73,7 +73,9 @@ def test_traffic_record_covers_the_dominant_launches_of_the_default_workload() -
         # (the 16 -> 32 up layer in one launch since round 4: 2 048 blocks of 16 channels re-stream the layer's 9.4 MB of weights once per
         # group of samples and every sample's whole input once per channel tile: x8.2 of its 177 MB, 1.5 TB/s for 0.96 ms)
         assert 1.0 <= ratio < (1.5 if key.endswith(("512x512", "1024x1024")) else 10.0), (key, ratio)  # (x1.38 at 1024^2: 18 x 72 patches per 16 x 64 tile, two partial images)
-        assert 0.3 < entry["mfma_busy_fraction"] < 1.0
+        # (the split-operand up launches keep the bf16 matrix cores busy 0.27 ... 0.46 of the launch: six 16-cycle products per fp32 product,
+        # the rest is the wave's own staging and FIR)
+        assert 0.2 < entry["mfma_busy_fraction"] < 1.0
     # another workload: no figure rather than a wrong one
     assert bench.measured_traffic("convV16+rgb_1024x1024_32->32", 512, workload["frames_per_step_per_gpu"])[0] is None
 

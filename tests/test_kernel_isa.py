@@ -43,3 +43,16 @@ def test_upfir16_kernels_fit_two_blocks_per_cu_without_scratch() -> None:
     result = subprocess.run([sys.executable, str(REPO_ROOT / "tools" / "check_upfir16_isa.py")], capture_output=True, text=True, timeout=900)
     assert result.returncode == 0, result.stdout + result.stderr
     assert "upfir16_fused_pre_kernel" in result.stdout
+
+
+@pytest.mark.skipif(shutil.which("hipcc") is None and not Path("/opt/rocm/bin/hipcc").exists(), reason="needs hipcc")
+def test_role_split_up_kernel_fits_two_waves_per_simd_without_scratch() -> None:
+    """
+    The role-split experiment (upfir_split_roles.hip) runs eight waves per block, two per SIMD: its matrix waves hold 64 accumulators, 108
+    weight-fragment registers and two sets of patch fragments in at most 256 registers; a spill there would be a vector-memory access
+    inside the row loop. tools/check_upfirr_isa.py cross-compiles and checks registers, scratch and the K loop's MFMA count.
+    """
+    result = subprocess.run([sys.executable, str(REPO_ROOT / "tools" / "check_upfirr_isa.py")], capture_output=True, text=True, timeout=900)
+    assert result.returncode == 0, result.stdout + result.stderr
+    assert "upfirr_fused_kernel" in result.stdout
+
