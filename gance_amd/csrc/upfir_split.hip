@@ -81,6 +81,9 @@ constexpr int kRing = 3;
 constexpr int kHaloCols = 4;        // input columns X0 - 2, X0 - 1, X0 + 63, X0 + 64
 constexpr int kHaloUnits = kRows * kHaloCols * kPlanes;
 constexpr int kHaloTasks = kRows * kHaloCols * 4;  // (row, column, k-group): 144
+#ifndef GANCE_UPFIRS_WEAVE
+#define GANCE_UPFIRS_WEAVE 2  // other instructions dealt out per MFMA in a row's scheduling region (measured: 1 and 3 are within 1 % of 2)
+#endif
 #ifndef GANCE_UPFIRS_DEPTH
 #define GANCE_UPFIRS_DEPTH 6
 #endif
@@ -440,7 +443,7 @@ __device__ __forceinline__ void upfirs_body(const UpFirArgs& p) {
                     for (int i = 0; i < 54; ++i) {
                         if (i >= (j == 0 ? 18 : 54)) break;                 // (row 0 only has the dy = -1 taps)
                         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // one MFMA
-                        __builtin_amdgcn_sched_group_barrier(0x092, 2, 0);  // two of: vector ALU, vector memory, LDS
+                        __builtin_amdgcn_sched_group_barrier(0x092, GANCE_UPFIRS_WEAVE, 0);  // two of: vector ALU, vector memory, LDS
                     }
                 } else {
                     // The chunk's last row, tap by tap (the dy = -1 taps first: the next chunk's first row needs them first): the row's
