@@ -671,7 +671,9 @@ int synthesize_from_dlat(gance_engine* e, const float* d_dlat, int B, uint8_t* d
             const bool roles = e->upfir_split_roles != 0 && gance::upfirr_supported(c.cin, c.cout, H, H);
             if (roles) gance::upfirr_plan(B, c.cout, H, H, e->num_cus, &u);
             else gance::upfirs_plan(B, c.cout, H, H, e->num_cus, &u);
-            if (e->upfir_split == 2 || (u.total_blocks >= e->num_cus * 3 / 4 && 2 * H <= e->upfir_split_max_res)) {
+            // (from 9/16 of the CUs up -- 9 frames per call at every layer, 16 blocks per frame --: measured, frames/s of whole calls at 8 / 9 / 10 / 11
+            // frames per call: 1053 / 842 / 909 / 940 with the fp32 forms, 953 / ~1000 / 1045 / 1106 with this one)
+            if (e->upfir_split == 2 || (u.total_blocks >= e->num_cus * 9 / 16 && 2 * H <= e->upfir_split_max_res)) {
                 u.pair_form = roles ? 3 : 2;  // (marks the plan: the caller launches launch_upfir_split_roles / launch_upfir_split)
                 if (plan != nullptr) *plan = u;
                 return true;
