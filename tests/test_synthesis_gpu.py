@@ -322,7 +322,7 @@ def test_split_operand_up_layer_keeps_the_fp32_exponent_range(library, log2_scal
         engine.close()
 
 
-@pytest.mark.parametrize("resolution,batch,split", [(16, 17, 0), (8, 40, 0), (32, 7, 0), (64, 2, 0), (128, 1, 0), (32, 16, 1), (32, 16, 2)])
+@pytest.mark.parametrize("resolution,batch,split", [(16, 17, 0), (8, 40, 0), (32, 7, 0), (64, 2, 0), (128, 1, 0), (16, 17, 1), (32, 16, 2)])
 def test_smallest_up_layers_in_scatter_form_match_oracle_layerwise(library, resolution: int, batch: int, split: int, monkeypatch) -> None:
     """
     The 4x4 -> 8x8 and 8x8 -> 16x16 up layers as one dense GEMM each (gemm_forms.hip: pack, GEMM over tap slot x channel rows and
