@@ -84,6 +84,9 @@ constexpr int kHaloTasks = kRows * kHaloCols * 4;  // (row, column, k-group): 14
 #ifndef GANCE_UPFIRS_WEAVE
 #define GANCE_UPFIRS_WEAVE 2  // other instructions dealt out per MFMA in a row's scheduling region (measured: 1 and 3 are within 1 % of 2)
 #endif
+#ifndef GANCE_UPFIRS_MIN_SEG_ROWS
+#define GANCE_UPFIRS_MIN_SEG_ROWS 16  // shortest row segment of a block (upfirs_plan)
+#endif
 #ifndef GANCE_UPFIRS_DEPTH
 #define GANCE_UPFIRS_DEPTH 6
 #endif
@@ -198,14 +201,20 @@ __device__ __forceinline__ void upfirs_body(const UpFirArgs& p) {
     const int m_tile = id % p.m_tiles;
     id /= p.m_tiles;
     const int strip = id % p.strips;
-    const int b = id / p.strips;
+    id /= p.strips;
+    const int seg = id % p.segs;  // row segment of the image (calls too small to fill the chip with whole images: upfirs_plan)
+    const int b = id / p.segs;
     const int m0 = m_tile * kBM;
     const int X0 = strip * kSW;
     const int H = p.H, W = p.W;
     const int Hp = H + 2, Wp = W + 8;
     const int HpWp4 = Hp * Wp * 4;
     const int chunks = p.Cin / kKC;
-    const int steps = H / kTH;
+    // A block sweeps position rows [seg * rows_per_seg, (seg + 1) * rows_per_seg) in steps of 8. A segment below the image's top runs the
+    // step ABOVE it first ("priming": its last three T rows are the carry the segment's first FIR window needs; nothing of it is stored).
+    const int steps = H / kTH;  // of the whole image
+    const int s_begin = seg * (p.rows_per_seg / kTH), s_end = s_begin + p.rows_per_seg / kTH;
+    const int s_first = seg > 0 ? s_begin - 1 : s_begin;
 
     const __amdgpu_buffer_rsrc_t x_rsrc =
         __builtin_amdgcn_make_buffer_rsrc((void*)(p.x + (size_t)b * p.x_b_stride), 0, p.Cin * Hp * Wp * 4, 0x00020000);
@@ -345,10 +354,10 @@ __device__ __forceinline__ void upfirs_body(const UpFirArgs& p) {
     };
 
     // ---- prologue: constants, the zeroed carry, halo buffer of the first chunk, rows 0 and 1 in the ring, rows 2..4 in flight ----
-    stage_load(st[0], 0, 0);
-    stage_load(st[1], 0, 1);
+    stage_load(st[0], 0, kTH * s_first + 0);
+    stage_load(st[1], 0, kTH * s_first + 1);
     load_a3(0, 0, A[0]);
-    halo_load(0, 0);
+    halo_load(s_first, 0);
     if constexpr (!kPre)
         for (int i = tid; i < p.Cin; i += 256) s_lds[i] = p.s[(size_t)b * p.s_stride + i];
     if (tid < kBM) {
@@ -364,7 +373,7 @@ __device__ __forceinline__ void upfirs_body(const UpFirArgs& p) {
     stage_store(st[1], 1, 0);
     halo_store(0, 0);
 #pragma unroll
-    for (int r = 2; r < 2 + kDepth; ++r) stage_load(st[r % kDepth], 0, r);  // (row r of the stream waits in st[r % kDepth])
+    for (int r = 2; r < 2 + kDepth; ++r) stage_load(st[r % kDepth], 0, kTH * s_first + r);  // (row r of the stream waits in st[r % kDepth])
     lds_barrier();
     edge_store(0, 0, 0);
     edge_store(1, 0, 1);
@@ -386,9 +395,10 @@ __device__ __forceinline__ void upfirs_body(const UpFirArgs& p) {
     constexpr int kTapTurn[9] = {0, 4, 6, 8, 2, 5, 1, 7, 3};
 
 #pragma unroll 1
-    for (int si = 0; si < steps; ++si) {
+    for (int si = s_first; si < s_end; ++si) {
         const int y0 = kTH * si;
-        const bool last_step = si + 1 == steps;
+        const bool last_step = si + 1 == steps;  // (of the image: position row y' = H follows)
+        const bool priming = si < s_begin;
         f32x4 acc[kTH][4];
 #pragma unroll
         for (int r = 0; r < kTH; ++r)
@@ -527,7 +537,7 @@ __device__ __forceinline__ void upfirs_body(const UpFirArgs& p) {
             for (int rw = 0; rw < kRowPasses; ++rw) {
                 const int oy0 = 2 * (ys + 4 * rw) - 2;        // output row of the pass's window row r = 0
                 const int r_lo = max(0, -oy0);                 // first step: rows -2, -1 do not exist
-                const int r_hi = min(kPassRows, 2 * H - oy0);  // row y' = H: only rows 2H-2, 2H-1
+                const int r_hi = priming ? 0 : min(kPassRows, 2 * H - oy0);  // row y' = H: only rows 2H-2, 2H-1; a priming step stores nothing
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     // -- dump: accumulator register g = channel 4 g + q4 --
@@ -662,13 +672,23 @@ void upfirs_arrange_weights(const float* w_in, int cin, int cout, const int* up_
 }
 
 void upfirs_plan(int B, int cout, int H, int W, int num_cus, UpFirArgs* a) {
-    (void)num_cus;
     a->m_tiles = cout / kBM;
     a->strips = W / kSW;
     a->step_rows = kTH;
-    a->segs = 1;
-    a->rows_per_seg = H;
-    a->total_blocks = B * a->m_tiles * a->strips;
+    // Row segments only where whole images leave CUs idle: each costs a priming step of 8 rows, so segments of at least
+    // GANCE_UPFIRS_MIN_SEG_ROWS rows, powers of two, until every CU has a block (GANCE_TUNE_UPFIR_SPLIT_SEGS=0: never)
+    static const bool segments = [] { const char* v = std::getenv("GANCE_TUNE_UPFIR_SPLIT_SEGS"); return !(v && std::atoi(v) == 0); }();
+    // ... the number that minimises (rounds of blocks over the CUs) x (rows a block sweeps, its priming step included)
+    int segs = 1;
+    const int base = B * a->m_tiles * a->strips;
+    long long best = (long long)((base + num_cus - 1) / num_cus) * H;
+    for (int n = 2; segments && H / n >= GANCE_UPFIRS_MIN_SEG_ROWS && (H / n) % kTH == 0 && base * (n / 2) < num_cus; n *= 2) {
+        const long long cost = (long long)((base * n + num_cus - 1) / num_cus) * (H / n + kTH);
+        if (cost < best) best = cost, segs = n;
+    }
+    a->segs = segs;
+    a->rows_per_seg = H / segs;
+    a->total_blocks = base * segs;
     a->stagger_phases = 1;
     a->stagger_ticks = 0;
     a->debug_flags = 0;
@@ -696,7 +716,9 @@ hipError_t launch_upfir_split(const UpFirArgs& args, hipStream_t stream) {
         },
         &unused);
     if (e != hipSuccess) return e;
-    if (!upfirs_supported(args.Cin, args.Cout, args.H, args.W) || args.segs != 1) return hipErrorInvalidValue;
+    if (!upfirs_supported(args.Cin, args.Cout, args.H, args.W) || args.segs < 1 || args.rows_per_seg * args.segs != args.H || args.rows_per_seg % kTH != 0 ||
+        args.total_blocks != args.B * args.m_tiles * args.strips * args.segs)
+        return hipErrorInvalidValue;
     const int pre = args.input_prescaled ? 1 : 0, noise = args.noise != nullptr ? 1 : 0;
     hipLaunchKernelGGL(kernels[2 * pre + noise], dim3(args.total_blocks), dim3(256), lds_bytes(pre ? 0 : args.Cin), stream, args);
     return hipGetLastError();
