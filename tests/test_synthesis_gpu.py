@@ -190,10 +190,12 @@ def test_full_size_properties_batch_of_8(library) -> None:
 
 @pytest.mark.parametrize(
     "resolution,batch,noise,conv_form",
-    [(64, 5, True, "auto"), (128, 3, True, "auto"), (256, 2, True, "auto"), (128, 3, False, "winograd43"), (256, 2, False, "winograd43"), (256, 3, True, "winograd43"), (64, 5, True, "winograd43")],
+    [(64, 5, True, "auto"), (256, 2, True, "auto"), (128, 3, False, "winograd43"), (256, 2, False, "winograd43"), (256, 3, True, "winograd43"), (64, 5, True, "winograd43")],
 )
-def test_fused_upsampling_layer_matches_oracle_layerwise(library, resolution: int, batch: int, noise: bool, conv_form: str) -> None:
+def test_fused_upsampling_layer_matches_oracle_layerwise(library, resolution: int, batch: int, noise: bool, conv_form: str, monkeypatch) -> None:
     """
+    (The fp32 kernels: since round 5 the split-operand form would take the layers with inputs >= 64 wide at these batch sizes too --
+    its own cases are test_split_operand_up_layers_match_oracle_layerwise -- so it is switched off here: GANCE_TUNE_UPFIR_SPLIT=0.)
     Conv0_up as ONE kernel (upfir16_fused.hip / upfir_fused.hip: transposed conv + FIR + noise + bias + leaky ReLU),
     forced at a small batch: the planner then cuts the image into row segments (priming steps), 256^2 has
     two 64-column strips (recomputed halo columns) and 8 channel tiles; every term is switched on. The 16 -> 32 and
@@ -202,6 +204,7 @@ def test_fused_upsampling_layer_matches_oracle_layerwise(library, resolution: in
     F(4x4,3x3) kernels on the layers before them ("winograd43": those scale their stores by the up layer's style) the
     layers from 32 -> 64 up run in the kernel's pair form (F(2,2) along x, launch names ending in "/16x").
     """
+    monkeypatch.setenv("GANCE_TUNE_UPFIR_SPLIT", "0")  # (read when the engine is created)
     spec = sg2_spec.make_spec(resolution)
     variables = sg2_spec.make_random_variables(resolution, seed=3, perturb=True)
     if not noise:
@@ -322,7 +325,7 @@ def test_split_operand_up_layer_keeps_the_fp32_exponent_range(library, log2_scal
         engine.close()
 
 
-@pytest.mark.parametrize("resolution,batch,split", [(16, 17, 0), (8, 40, 0), (32, 7, 0), (64, 2, 0), (128, 1, 0), (16, 17, 1), (32, 16, 2)])
+@pytest.mark.parametrize("resolution,batch,split", [(16, 17, 0), (8, 40, 0), (32, 7, 0), (64, 2, 0), (128, 1, 0), (16, 17, 1), (16, 17, 2)])
 def test_smallest_up_layers_in_scatter_form_match_oracle_layerwise(library, resolution: int, batch: int, split: int, monkeypatch) -> None:
     """
     The 4x4 -> 8x8 and 8x8 -> 16x16 up layers as one dense GEMM each (gemm_forms.hip: pack, GEMM over tap slot x channel rows and
