@@ -666,13 +666,15 @@ int synthesize_from_dlat(gance_engine* e, const float* d_dlat, int B, uint8_t* d
         if (!c.up || upfir_mode == 0 || (e->upfir_w[idx] == SIZE_MAX && e->upfir16_w[idx] == SIZE_MAX)) return false;
         gance::UpFirArgs u{};
         u.Cin = c.cin;
-        // the split-operand form (upfir_split.hip) sweeps the whole image height per block: where its launch fills the chip
+        // the split-operand form (upfir_split.hip; a block sweeps the image's height, or a row segment of it where whole images would leave
+        // CUs idle: upfirs_plan): where its launch has blocks for 9/16 of the CUs
         if (e->upfirs_w[idx] != SIZE_MAX && upfir_mode != 0) {
             const bool roles = e->upfir_split_roles != 0 && gance::upfirr_supported(c.cin, c.cout, H, H);
             if (roles) gance::upfirr_plan(B, c.cout, H, H, e->num_cus, &u);
             else gance::upfirs_plan(B, c.cout, H, H, e->num_cus, &u);
-            // (from 9/16 of the CUs up -- 9 frames per call at every layer, 16 blocks per frame --: measured, frames/s of whole calls at 8 / 9 / 10 / 11
-            // frames per call: 1053 / 842 / 909 / 940 with the fp32 forms, 953 / ~1000 / 1045 / 1106 with this one)
+            // (9/16: measured without row segments, 16 blocks per frame at every layer -- whole calls of 8 / 9 / 10 / 11 frames ran at 1053 / 842 / 909 / 940
+            // frames/s in the fp32 forms, at 953 / ~1000 / 1045 / 1106 in this one; with row segments 1 ... 8 frames per call take it too wherever 16-row
+            // segments reach that many blocks: 645 / 895 / 899 / 1080 / 934 / 1055 / 1136 / 1202 frames/s against 614 / 817 / 861 / 960 / - / 980 / - / 1047)
             if (e->upfir_split == 2 || (u.total_blocks >= e->num_cus * 9 / 16 && 2 * H <= e->upfir_split_max_res)) {
                 u.pair_form = roles ? 3 : 2;  // (marks the plan: the caller launches launch_upfir_split_roles / launch_upfir_split)
                 if (plan != nullptr) *plan = u;

@@ -36,7 +36,8 @@
 //     wave). The same buffer serves the one fragment the ring does not hold: column X0 - 1 for the dx = -1 taps of the first lane.
 //   * position row y' = H (T row 2H, the "flush step" of the other kernels) is the dy = -1 taps of the LAST step's ninth patch row:
 //     18 more MFMAs in that step's last row and one more epilogue pass, no step of its own.
-// Whole image height per block (no row segments): the engine takes this form when a launch fills the chip without them.
+// A block sweeps the image's whole height, or -- for calls too small to fill the chip with whole images -- a row SEGMENT of it behind one
+// "priming" step (the step above the segment, computed for its last three T rows only: upfirs_plan picks the number of segments).
 //
 // Weight image (upfirs_arrange_weights): [channel tile of 16][chunk of 32][tap][part][k-group][row m][8 channels] bf16: a lane's A
 // fragment (row m = lane % 16, k-group = lane / 16) is 16 contiguous bytes, a wave's load 1 KB; MFMA row m = 4 q + r holds channel
